@@ -1,0 +1,171 @@
+/*
+ * yagmatch.h -- C ABI of libyagmatch.so, the MI355X-native correlative scan matcher.
+ *
+ * Drop-in boundary for yag-slam's match_scan path.  The reference crosses into native code through
+ * pybind11 (karto_scanmatcher==1.0.0, /root/reference/setup.py:46), not through a C API, so each
+ * entry point below names the pybind11 object/method it replaces:
+ *
+ *   ym_create / ym_destroy        karto_scanmatcher.Wrapper(ScanMatcherConfig)
+ *                                 /root/reference/yag_slam/scan_matching.py:33-38, /root/reference/test.py:24-25
+ *   ym_scan_create / _set_pose    karto_scanmatcher.LocalizedRangeScan(LaserScanConfig, ranges, Pose2, Pose2, num, time)
+ *                                 and its .corrected_pose setter
+ *                                 /root/reference/yag_slam/models.py:37-39,67-75, /root/reference/test.py:27-36
+ *   ym_match_scans                Wrapper.match_scan(query._scan, [b._scan ...], penalty, do_fine)
+ *                                 /root/reference/yag_slam/scan_matching.py:40-42, /root/reference/test.py:38
+ *   ym_match                      same call, for callers that hold plain range arrays (no resident scan)
+ *   ym_match_batch                the serial chain loop of GraphSlam.try_to_close_loop
+ *                                 /root/reference/yag_slam/graph_slam.py:217-236 (one query, many chains)
+ *   ym_result                     the returned object's .response / .covariance / .best_pose
+ *                                 /root/reference/yag_slam/scan_matching.py:42, /root/reference/test.py:39-41
+ *
+ * Conventions: POD only; the caller owns every input buffer and the library copies on entry; no
+ * C++ exception crosses the boundary -- functions return YM_OK (0) or a negative YM_ERR_* and
+ * ym_last_error() gives the text (thread-local).  One ym_matcher owns one HIP stream and one
+ * device workspace: it is NOT re-entrant (the reference's matcher is not either: it owns a mutable
+ * grid and is driven from one worker thread, /root/reference/ros1/slam_node_ros1:223-255).
+ * Distinct matchers are independent.  There is no CPU fallback: without a usable HIP device
+ * ym_create fails with YM_ERR_NO_DEVICE.
+ */
+#ifndef YAGMATCH_H
+#define YAGMATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YM_VERSION 1
+
+enum {
+    YM_OK = 0,
+    YM_ERR_INVALID = -1,     /* bad argument / bad config */
+    YM_ERR_NO_DEVICE = -2,   /* no HIP device, or device index out of range */
+    YM_ERR_HIP = -3,         /* a HIP runtime call failed */
+    YM_ERR_UNSUPPORTED = -4, /* valid request this build cannot serve */
+    YM_ERR_RANGE = -5,       /* Karto's "index out of range" / "unable to find best position" */
+    YM_ERR_BUSY = -6         /* async slot still in flight / not submitted */
+};
+
+enum { YM_SEM_KARTO = 0, YM_SEM_YAGPY = 1 };
+
+/* The 11 keys of yag-slam's config dict (/root/reference/yag_slam/helpers.py:339-351), Karto's
+ * MinimumDistancePenalty, and the semantics switch. */
+typedef struct ym_config {
+    double angle_variance_penalty;
+    double distance_variance_penalty;
+    double coarse_search_angle_offset;
+    double coarse_angle_resolution;
+    double fine_search_angle_resolution;
+    double range_threshold;
+    double minimum_angle_penalty;
+    double minimum_distance_penalty;
+    double search_size;
+    double resolution;
+    double smear_deviation;
+    int32_t use_response_expansion;
+    int32_t semantics; /* YM_SEM_KARTO | YM_SEM_YAGPY */
+} ym_config;
+
+/* LaserScanConfig + ranges + corrected pose (/root/reference/yag_slam/models.py:25-39) */
+typedef struct ym_scan_desc {
+    const double *ranges; /* host pointer, n readings */
+    int32_t n;
+    int32_t reserved;
+    double min_angle;
+    double max_angle;
+    double angle_increment;
+    double min_range;
+    double max_range;
+    double range_threshold;
+    double pose[3]; /* x, y, heading */
+} ym_scan_desc;
+
+typedef struct ym_result {
+    double response;
+    double pose[3];  /* best_pose x, y, heading */
+    double cov[9];   /* row-major 3x3 covariance */
+    double coarse_response; /* best response of the (last) coarse pass */
+    int64_t hypotheses;     /* lattice points scored (all passes, incl. expansions) */
+    int32_t coarse_dims[3]; /* nx, ny, ntheta */
+    int32_t fine_dims[3];   /* nx, ny, ntheta (0 when !refine) */
+    int32_t n_query_points; /* response normaliser */
+    int32_t expansions;     /* response-expansion retries taken */
+    int32_t status;         /* YM_OK or YM_ERR_RANGE for this item */
+    int32_t reserved;
+} ym_result;
+
+typedef struct ym_matcher ym_matcher;
+typedef struct ym_scan ym_scan;
+
+/* ---- library / device ---- */
+int ym_version(void);
+int ym_device_count(void);
+const char *ym_last_error(void);
+
+/* ---- matcher ---- */
+ym_matcher *ym_create(const ym_config *cfg, int device);
+void ym_destroy(ym_matcher *m);
+int ym_get_config(const ym_matcher *m, ym_config *out);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> the matcher's own */
+int ym_set_stream(ym_matcher *m, void *hip_stream);
+int ym_synchronize(ym_matcher *m);
+
+/* ---- resident scans (device twin of LocalizedRangeScan) ---- */
+ym_scan *ym_scan_create(int device, const ym_scan_desc *desc);
+int ym_scan_set_pose(ym_scan *s, double x, double y, double heading);
+int ym_scan_get_pose(const ym_scan *s, double pose[3]);
+int ym_scan_size(const ym_scan *s);
+void ym_scan_destroy(ym_scan *s);
+
+/* ---- the hot path ---- */
+int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base, int n_base,
+             int penalize, int refine, ym_result *out);
+int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base,
+                   int penalize, int refine, ym_result *out);
+
+/* Pipelined form: enqueue on the matcher's stream, collect later.  `slot` in [0, ym_async_slots). */
+int ym_async_slots(const ym_matcher *m);
+int ym_match_scans_async(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base,
+                         int penalize, int refine, int slot);
+int ym_wait(ym_matcher *m, int slot, ym_result *out);
+
+/* One query against n_chains candidate chains; chain c = scans[chain_offsets[c] .. chain_offsets[c+1]).
+ * per_chain (nullable) receives every chain's result; best/best_chain (nullable) the arg-max over
+ * response, ties to the lowest chain index.  If dev_key_out (nullable, DEVICE pointer to 4 x int64)
+ * is given, the packed sortable key {response bits, ~global chain id} and the winner's pose bits are
+ * also left on the device for an RCCL max-reduce across ranks (chain ids offset by chain_id_base). */
+int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans,
+                   const int32_t *chain_offsets, int n_chains, int penalize, int refine,
+                   ym_result *per_chain, ym_result *best, int32_t *best_chain);
+int ym_match_batch_async(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans,
+                         const int32_t *chain_offsets, int n_chains, int penalize, int refine,
+                         int64_t chain_id_base, void *dev_key_out);
+
+/* ---- introspection for parity tests (state of the LAST completed synchronous match) ---- */
+typedef struct ym_grid_info {
+    int32_t width, height, pitch; /* device window (bytes) */
+    int32_t origin_x, origin_y;   /* window cell (0,0) in Karto storage coordinates (incl. border) */
+    int32_t storage_w, storage_h; /* Karto's full storage size the window is cut from */
+    int32_t roi_x, roi_y, roi_w, roi_h;
+    double offset_x, offset_y;    /* world coordinate of ROI cell (0,0) */
+} ym_grid_info;
+int ym_debug_grid_info(ym_matcher *m, int item, ym_grid_info *info);
+int ym_debug_grid(ym_matcher *m, int item, uint8_t *out, int64_t out_bytes); /* height*pitch bytes */
+/* integer correlation sums [itheta][iy][ix] of pass 0 (coarse) / 1 (fine) */
+int ym_debug_sums(ym_matcher *m, int item, int pass, uint32_t *out, int64_t out_count);
+/* query points in the sensor frame (xy interleaved), returns count via *n */
+int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, int32_t *n);
+/* window cell coordinates of the rasterised base points of `item`, per base scan slot:
+ * out[(slot*max_n + i)*2 + {0,1}] = wx, wy  or (INT32_MIN, INT32_MIN) for filtered points */
+int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int32_t *max_n);
+
+/* ---- profiling: HIP-event timing of the correlate kernel on the matcher's stream ---- */
+int ym_profile_enable(ym_matcher *m, int on);
+/* which: 0 = correlate (coarse), 1 = raster, 2 = whole call; returns accumulated ms and launch count */
+int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAGMATCH_H */

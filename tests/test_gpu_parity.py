@@ -1,0 +1,178 @@
+"""HIP path vs CPU oracle ("karto" semantics) through the C ABI, on a real MI355X.
+Integer work (grid bytes, correlation sums) must be bit-exact; fp64 results within 1e-9."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import PlainScan, cfg2_scans  # noqa: E402
+
+
+def _mk_native(plain):
+    from yag_slam_amd.models import LocalizedRangeScan
+    p = plain.corrected_pose
+    return LocalizedRangeScan(plain.ranges, plain.min_angle, plain.max_angle, plain.angle_increment,
+                              plain.min_range, plain.max_range, plain.range_threshold, p.x, p.y, p.euler[-1])
+
+
+def compare(cfg, query, base, penalty, fine, loop=False, resident=True, check_grid=True):
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    o = orc.Oracle(cfg, "karto", loop=loop)
+    ro = o.match_scan(query, base, penalty, fine)
+    m = ScanMatcher(cfg, loop=loop)
+    if resident:
+        rq, rb = _mk_native(query), [_mk_native(b) for b in base]
+    else:
+        rq, rb = query, base
+    r = m.match_scan(rq, rb, penalty, fine)
+    assert r.meta["n_query_points"] == ro["n_query_points"]
+    assert r.meta["expansions"] == ro["expansions"]
+    assert r.meta["hypotheses"] == ro["hypotheses"]
+    if ro["n_query_points"] > 0:
+        assert r.meta["coarse_dims"] == ro["coarse_dims"]
+        if ro["expansions"] == 0:
+            # intermediates of the last pipeline run == the oracle's only run
+            ql = m.debug_query_local()
+            np.testing.assert_allclose(ql, o.query_local(), rtol=0, atol=1e-11)
+            if check_grid:
+                g, info = m.debug_grid()
+                og, oinfo = o.grid_u8()
+                assert info.storage_w == oinfo["width"] and info.roi_x == oinfo["roi"][0] and info.roi_w == oinfo["roi"][2]
+                sub = og[info.origin_y:info.origin_y + info.height, info.origin_x:info.origin_x + info.width]
+                assert np.array_equal(g, sub), "grid window differs: %d cells" % int((g != sub).sum())
+            s0 = m.debug_sums(0, dims=r.meta["coarse_dims"])
+            assert np.array_equal(s0, o.sums(0)), "coarse sums differ"
+            if fine:
+                s1 = m.debug_sums(1, dims=r.meta["fine_dims"])
+                assert np.array_equal(s1, o.sums(1)), "fine sums differ"
+    assert abs(r.response - ro["response"]) <= 1e-12
+    bp = r.best_pose
+    np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], ro["pose"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
+    return r, ro
+
+
+@pytest.mark.parametrize("penalty,fine", [(True, True), (False, True), (True, False), (False, False)])
+def test_cfg2_default(penalty, fine):
+    q, base = cfg2_scans()
+    r, ro = compare(None, q, base, penalty, fine)
+    if fine and not penalty:
+        assert abs(r.best_pose.x - 3.07) < 0.011 and abs(r.best_pose.y - 3.04) < 0.011
+
+
+def test_cfg2_descriptor_entry_matches_resident():
+    q, base = cfg2_scans()
+    compare(None, q, base, True, True, resident=False)
+
+
+def test_cfg2_dirty_scans():
+    q, base = cfg2_scans(dirty=True)
+    compare(None, q, base, True, True)
+
+
+def test_loop_config_coarse_only():
+    q, base = cfg2_scans()
+    compare(None, q, base, False, False, loop=True)
+    compare(None, q, base, False, True, loop=True)
+
+
+def test_rotated_query_and_mixed_headings():
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    mk = lambda r, p: PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 20.0, p)
+    poses = [(4.0 + 0.08 * i, 2.6 + 0.03 * i, 2.0 + 0.05 * i) for i in range(6)]
+    base = [mk(scene.scan_ranges(p, index=200 + i), p) for i, p in enumerate(poses)]
+    q = mk(scene.scan_ranges((4.45, 2.8, 2.33), index=210), (4.4, 2.75, 2.28))
+    compare(None, q, base, True, True)
+    # heading across the +-pi wrap
+    poses = [(4.0, 3.0, 3.10 + 0.01 * i) for i in range(3)]
+    base = [mk(scene.scan_ranges(p, index=220 + i), p) for i, p in enumerate(poses)]
+    q = mk(scene.scan_ranges((4.02, 3.01, -3.12), index=230), (4.0, 3.0, 3.14))
+    compare(None, q, base, True, True)
+
+
+def test_small_lattice_config():
+    from tests.util import load_case
+    c = load_case("small_pen1_fine1")
+    cfg = dict(c["cfg"], search_size=0.32)  # Karto needs search_size/resolution even
+    compare(cfg, c["query"], c["base"], True, True)
+    c = load_case("small_dirty_rot")
+    compare(cfg, c["query"], c["base"], False, True)
+
+
+def test_invalid_configs_fail_like_the_reference():
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd._capi import YmError
+    with pytest.raises(AssertionError):  # helpers.py:370
+        ScanMatcher(dict(resolution=0.01, smear_deviation=0.2))
+    with pytest.raises(YmError):  # odd search_size/resolution: Karto throws in the probability search
+        ScanMatcher(dict(search_size=0.3, resolution=0.02, smear_deviation=0.04))
+
+
+def test_reference_smoke_input():
+    # /root/reference/test.py:29-38: 230 beams x 3.0 m, base (0,0,0), query (1.0,0,1.57), penalize + refine
+    sensor = dict(min_angle=-1.0, angle_increment=float(np.deg2rad(0.5)), min_range=0.0, range_threshold=5.0)
+    mk = lambda p: PlainScan([3.0] * 230, sensor["min_angle"], sensor["angle_increment"], 0.0, 5.0, p)
+    compare(None, mk((1.0, 0.0, 1.57)), [mk((0.0, 0.0, 0.0))], True, True)
+
+
+def test_response_expansion_path():
+    # a query that sees nothing of the base scan: zero response -> three +20 degree retries
+    sensor_mk = lambda r, p: PlainScan(r, -0.5, 0.01, 0.05, 20.0, p)
+    base = [sensor_mk(np.full(101, 2.0), (0.0, 0.0, 0.0))]
+    q = sensor_mk(np.full(101, 2.0), (10.0, 10.0, 0.0))
+    r, ro = compare(dict(search_size=0.3, range_threshold=12.0), q, base, True, True)
+    assert ro["expansions"] == 3 and r.response == 0.0
+    r, ro = compare(dict(search_size=0.3, range_threshold=12.0, use_response_expansion=False), q, base, True, True)
+    assert ro["expansions"] == 0
+
+
+def test_empty_and_ragged_inputs():
+    q, base = cfg2_scans()
+    # no base scans at all
+    compare(None, q, [], True, True)
+    # query without a single valid reading: Karto's early return
+    qe = PlainScan(np.full(1081, np.nan), q.min_angle, q.angle_increment, q.min_range, 20.0, (3.0, 3.0, 0.0))
+    r, ro = compare(None, qe, base[:2], True, True)
+    assert r.response == 0.0 and r.covariance[0][0] == 500.0
+    # ragged chain: scans of different lengths, one empty, one all over-range
+    rag = [base[0],
+           PlainScan(base[1].ranges[:300], q.min_angle, q.angle_increment, q.min_range, 20.0, (2.1, 3.0, 0.0)),
+           PlainScan(np.zeros(0), q.min_angle, q.angle_increment, q.min_range, 20.0, (2.2, 3.0, 0.0)),
+           PlainScan(np.full(500, 25.0), q.min_angle, q.angle_increment, q.min_range, 20.0, (2.3, 3.0, 0.0))]
+    compare(None, q, rag, True, True)
+
+
+def test_batch_matches_single_calls():
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    q, base = cfg2_scans()
+    chains_p = synth.chain_poses(5, chain_len=4, scene=scene)
+    mk = lambda r, p: PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 20.0, p)
+    chains = [[_mk_native(mk(scene.scan_ranges(p, index=300 + 10 * c + i), p)) for i, p in enumerate(ch)]
+              for c, ch in enumerate(chains_p)]
+    m = ScanMatcher(None, loop=True)
+    nq = _mk_native(q)
+    per, best = m.match_scan_batch(nq, chains, False, False)
+    singles = [m.match_scan(nq, ch, False, False) for ch in chains]
+    for a, b in zip(per, singles):
+        assert a.response == b.response
+        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+        assert a.covariance == b.covariance
+    assert best == int(np.argmax([s.response for s in singles]))
+    assert best == 0  # chain 0 is the true neighbourhood
+
+
+def test_async_pipeline_matches_sync():
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    m = ScanMatcher()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    ref = m.match_scan(nq, nb, True, True)
+    for s in range(8):
+        m.match_scan_async(nq, nb, True, True, slot=s)
+    for s in range(8):
+        r = m.wait(s)
+        assert r.response == ref.response and r.covariance == ref.covariance

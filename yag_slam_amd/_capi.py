@@ -1,0 +1,168 @@
+"""ctypes binding of libyagmatch.so (include/yagmatch.h).  Thin: structs, prototypes, error mapping.
+
+The library is built in-tree (yag_slam_amd/libyagmatch.so) by `build()` = `make -C csrc`.  There is
+no fallback: if the library cannot be loaded, or it reports no HIP device, every entry raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyagmatch.so")
+
+YM_OK = 0
+SEM = {"karto": 0, "yagpy": 1}
+
+EXPORTS = (
+    "ym_version", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
+    "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scan_get_pose",
+    "ym_scan_size", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_async_slots",
+    "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_match_batch_async", "ym_debug_grid_info",
+    "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_profile_enable",
+    "ym_profile_read",
+)
+
+
+class YmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libyagmatch error %d: %s" % (code, msg))
+        self.code = code
+
+
+class YmConfig(C.Structure):
+    _fields_ = [
+        ("angle_variance_penalty", C.c_double),
+        ("distance_variance_penalty", C.c_double),
+        ("coarse_search_angle_offset", C.c_double),
+        ("coarse_angle_resolution", C.c_double),
+        ("fine_search_angle_resolution", C.c_double),
+        ("range_threshold", C.c_double),
+        ("minimum_angle_penalty", C.c_double),
+        ("minimum_distance_penalty", C.c_double),
+        ("search_size", C.c_double),
+        ("resolution", C.c_double),
+        ("smear_deviation", C.c_double),
+        ("use_response_expansion", C.c_int32),
+        ("semantics", C.c_int32),
+    ]
+
+
+class YmScanDesc(C.Structure):
+    _fields_ = [
+        ("ranges", C.POINTER(C.c_double)),
+        ("n", C.c_int32),
+        ("reserved", C.c_int32),
+        ("min_angle", C.c_double),
+        ("max_angle", C.c_double),
+        ("angle_increment", C.c_double),
+        ("min_range", C.c_double),
+        ("max_range", C.c_double),
+        ("range_threshold", C.c_double),
+        ("pose", C.c_double * 3),
+    ]
+
+
+class YmResult(C.Structure):
+    _fields_ = [
+        ("response", C.c_double),
+        ("pose", C.c_double * 3),
+        ("cov", C.c_double * 9),
+        ("coarse_response", C.c_double),
+        ("hypotheses", C.c_int64),
+        ("coarse_dims", C.c_int32 * 3),
+        ("fine_dims", C.c_int32 * 3),
+        ("n_query_points", C.c_int32),
+        ("expansions", C.c_int32),
+        ("status", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class YmGridInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "pitch", "origin_x", "origin_y", "storage_w",
+                                        "storage_h", "roi_x", "roi_y", "roi_w", "roi_h")] + [
+        ("pad", C.c_int32), ("offset_x", C.c_double), ("offset_y", C.c_double)]
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 the kernels + C ABI into yag_slam_amd/libyagmatch.so."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """Load (building first if the .so is absent) and prototype the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.ym_version.restype = C.c_int
+    L.ym_device_count.restype = C.c_int
+    L.ym_last_error.restype = C.c_char_p
+    L.ym_create.restype = vp
+    L.ym_create.argtypes = [C.POINTER(YmConfig), C.c_int]
+    L.ym_destroy.argtypes = [vp]
+    L.ym_destroy.restype = None
+    L.ym_get_config.argtypes = [vp, C.POINTER(YmConfig)]
+    L.ym_set_stream.argtypes = [vp, vp]
+    L.ym_synchronize.argtypes = [vp]
+    L.ym_scan_create.restype = vp
+    L.ym_scan_create.argtypes = [C.c_int, C.POINTER(YmScanDesc)]
+    L.ym_scan_set_pose.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    L.ym_scan_get_pose.argtypes = [vp, dp]
+    L.ym_scan_size.argtypes = [vp]
+    L.ym_scan_destroy.argtypes = [vp]
+    L.ym_scan_destroy.restype = None
+    L.ym_match.argtypes = [vp, C.POINTER(YmScanDesc), C.POINTER(YmScanDesc), C.c_int, C.c_int, C.c_int,
+                           C.POINTER(YmResult)]
+    L.ym_match_scans.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(YmResult)]
+    L.ym_async_slots.argtypes = [vp]
+    L.ym_match_scans_async.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ym_wait.argtypes = [vp, C.c_int, C.POINTER(YmResult)]
+    L.ym_match_batch.argtypes = [vp, vp, C.POINTER(vp), ip, C.c_int, C.c_int, C.c_int, C.POINTER(YmResult),
+                                 C.POINTER(YmResult), ip]
+    L.ym_match_batch_async.argtypes = [vp, vp, C.POINTER(vp), ip, C.c_int, C.c_int, C.c_int, C.c_int64, vp]
+    L.ym_debug_grid_info.argtypes = [vp, C.c_int, C.POINTER(YmGridInfo)]
+    L.ym_debug_grid.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int64]
+    L.ym_debug_sums.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int64]
+    L.ym_debug_query_local.argtypes = [vp, C.c_int, dp, C.c_int32, ip]
+    L.ym_debug_cells.argtypes = [vp, C.c_int, ip, C.c_int64, ip]
+    L.ym_profile_enable.argtypes = [vp, C.c_int]
+    L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != YM_OK:
+        raise YmError(rc, lib().ym_last_error().decode(errors="replace"))
+    return rc
+
+
+def last_error():
+    return lib().ym_last_error().decode(errors="replace")
+
+
+def config_struct(cfg, semantics="karto"):
+    """ScanMatcherConfig / dict -> YmConfig"""
+    d = cfg if isinstance(cfg, dict) else cfg.as_dict()
+    c = YmConfig()
+    for name, _ in YmConfig._fields_:
+        if name == "semantics":
+            c.semantics = SEM[semantics] if isinstance(semantics, str) else int(semantics)
+        elif name == "use_response_expansion":
+            c.use_response_expansion = int(bool(d["use_response_expansion"]))
+        elif name == "minimum_distance_penalty":
+            c.minimum_distance_penalty = float(d.get("minimum_distance_penalty", 0.5))
+        else:
+            setattr(c, name, float(d[name]))
+    return c

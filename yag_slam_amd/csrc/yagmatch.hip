@@ -1,0 +1,930 @@
+// yagmatch.hip -- host runtime + C ABI of libyagmatch.so (see include/yagmatch.h).
+//
+// One ym_matcher = one HIP stream + one device workspace.  A call (B items) is: one H2D copy of
+// the call descriptor, a fixed sequence of kernel launches (ym_kernels.hpp), one D2H copy of the
+// per-item result states.  Everything between stays in HBM.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/yagmatch.h"
+#include "ym_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return set_err(YM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                           __FILE__, __LINE__);                                                \
+    } while (0)
+
+double kt_round_h(double v) { return v >= 0.0 ? std::floor(v + 0.5) : std::ceil(v - 0.5); }
+bool kt_double_equal_h(double a, double b) {
+    double d = a - b;
+    return d < 0.0 ? d >= -YM_KT_TOLERANCE : d <= YM_KT_TOLERANCE;
+}
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int kAsyncSlots = 64;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    int ensure(size_t n) {
+        if (n <= cap) return YM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T)));
+        cap = want;
+        return YM_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinnedBuf {
+    unsigned char *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return YM_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = align_up(n + n / 4 + 256, 256);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault));
+        cap = want;
+        return YM_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// a scan as a call sees it: device ranges + metadata + pose
+struct CallScan {
+    const double *d_ranges;
+    int n;
+    double min_angle, angle_inc, min_range, range_threshold;
+    double pose[3];
+    double max_valid; // largest reading that survives range gating (bounds the query's reach)
+};
+
+struct CallItem {
+    int query;
+    int base_begin, base_count;
+};
+
+struct Call {
+    std::vector<CallScan> scans;
+    std::vector<CallItem> items;
+    int penalize = 1, refine = 1;
+    double coarse_angle_off = 0; // response expansion widens this
+    int expansions = 0;
+};
+
+struct Slot {
+    PinnedBuf desc;    // YmScanRef[] + YmItem[] staged for the H2D copy
+    PinnedBuf result;  // YmItemState[] landed by the D2H copy
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+    Call call;         // kept for response-expansion re-runs and result assembly
+    YmLattice coarse{}, fine{};
+    int n_items = 0;
+    int64_t chain_id_base = 0;
+};
+
+struct ProfEvents {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+    size_t used = 0;
+    double ms = 0;
+    int64_t launches = 0;
+};
+
+}  // namespace
+
+struct ym_scan {
+    int device;
+    double *d_ranges;
+    int n;
+    double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
+    double pose[3];
+    double max_valid_karto, max_valid_yagpy;
+};
+
+struct ym_matcher {
+    ym_config cfg;
+    int device;
+    hipStream_t own_stream, stream;
+    YmGeom geom;                 // config part filled at create; window part per call
+    std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)
+    DevBuf<uint8_t> ktab;
+    // workspace
+    DevBuf<unsigned char> desc;
+    DevBuf<YmItemState> states;
+    DevBuf<double2> qlocal;
+    DevBuf<int2> cells;
+    DevBuf<int32_t> counts;
+    DevBuf<uint8_t> grid;
+    DevBuf<int32_t> offsets;
+    DevBuf<int32_t> hypcell;
+    DevBuf<uint32_t> sums;
+    DevBuf<double> probs;
+    DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
+    PinnedBuf tmp_ranges_host;
+    Slot slots[kAsyncSlots + 1]; // last one serves the synchronous entry points
+    // geometry of the last launched call (debug getters)
+    YmGeom last_geom;
+    YmLattice last_lat[2];
+    int last_B = 0, last_max_n = 0, last_max_base = 0, last_nt_stride = 0, last_dim_stride = 0;
+    size_t last_grid_stride = 0, last_sums_stride[2] = {0, 0};
+    size_t sums_pass_offset[2] = {0, 0};
+    bool last_valid = false;
+    // profiling
+    bool profiling = false;
+    ProfEvents prof[3];
+};
+
+namespace {
+
+// ---------------------------------------------------------------- config -> geometry
+int build_geometry(ym_matcher *m) {
+    const ym_config &c = m->cfg;
+    if (!(c.resolution > 0) || !(c.search_size > 0) || c.smear_deviation < 0 || !(c.range_threshold > 0))
+        return set_err(YM_ERR_INVALID, "invalid matcher parameters (resolution, search_size, range_threshold must be > 0)");
+    if (!(0.5 * c.resolution <= c.smear_deviation && c.smear_deviation <= 10 * c.resolution))
+        return set_err(YM_ERR_INVALID, "Smear deviation must be between %g and %g", 0.5 * c.resolution,
+                       10 * c.resolution);
+    if (!(c.coarse_angle_resolution > 0) || !(c.fine_search_angle_resolution > 0) ||
+        !(c.coarse_search_angle_offset > 0))
+        return set_err(YM_ERR_INVALID, "angle offsets/resolutions must be > 0");
+    if (c.semantics != YM_SEM_KARTO)
+        return set_err(YM_ERR_UNSUPPORTED, "semantics %d is not built into this library yet", c.semantics);
+    YmGeom &g = m->geom;
+    std::memset(&g, 0, sizeof g);
+    // ScanMatcher::Create + CorrelationGrid::CreateGrid
+    g.scale = 1.0 / c.resolution;
+    g.res = 1.0 / g.scale;
+    g.side = (int)(kt_round_h(c.search_size / c.resolution) + 1);
+    const int margin = (int)std::ceil(c.range_threshold / c.resolution);
+    g.roi_w = g.side + 2 * margin;
+    g.half_kernel = (int)kt_round_h(2.0 * c.smear_deviation / c.resolution);
+    if (g.half_kernel > YM_MAX_KERNEL_HALF || g.half_kernel < 1)
+        return set_err(YM_ERR_INVALID, "kernel half size %d out of range", g.half_kernel);
+    g.border = g.half_kernel + 1;
+    g.storage_w = g.roi_w + 2 * g.border;
+    {
+        // Karto asserts an odd grid size; with an even one the last coarse lattice column falls
+        // outside m_pSearchSpaceProbs and MatchScan throws "Index out of range in probability search".
+        const double coff = 0.5 * (g.side - 1) * g.res, cstep = 2 * g.res;
+        const int nx = (int)(kt_round_h(coff * 2.0 / cstep) + 1);
+        const int last = (int)kt_round_h(((nx - 1) * cstep) * g.scale);
+        if (last >= g.side)
+            return set_err(YM_ERR_INVALID,
+                           "search_size / resolution = %g must be an even integer (Karto: index out of range in "
+                           "probability search)", c.search_size / c.resolution);
+    }
+    g.semantics = c.semantics;
+    g.dist_var = c.distance_variance_penalty;
+    g.ang_var = c.angle_variance_penalty;
+    g.min_dist_pen = c.minimum_distance_penalty;
+    g.min_ang_pen = c.minimum_angle_penalty;
+    // CorrelationGrid::CalculateKernel
+    const int h = g.half_kernel, ks = 2 * h + 1;
+    m->kernel.assign((size_t)ks * ks, 0);
+    int zone = 0;
+    for (int i = -h; i <= h; i++)
+        for (int j = -h; j <= h; j++) {
+            const double d = std::hypot(i * g.res, j * g.res);
+            const double z = std::exp(-0.5 * std::pow(d / c.smear_deviation, 2));
+            const unsigned v = (unsigned)kt_round_h(z * YM_OCCUPIED);
+            m->kernel[(size_t)(j + h) + (size_t)ks * (i + h)] = (uint8_t)v;
+            zone += (v == YM_OCCUPIED);
+        }
+    g.zone_count = zone;
+    return YM_OK;
+}
+
+int upload_ktab(ym_matcher *m) {
+    const int h = m->geom.half_kernel, ks = 2 * h + 1;
+    std::vector<uint8_t> q((size_t)(h + 1) * (h + 1));
+    for (int dy = 0; dy <= h; dy++)
+        for (int dx = 0; dx <= h; dx++) q[(size_t)dy * (h + 1) + dx] = m->kernel[(size_t)(dx + h) + (size_t)ks * (dy + h)];
+    int rc = m->ktab.ensure(q.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(m->ktab.p, q.data(), q.size(), hipMemcpyHostToDevice));
+    return YM_OK;
+}
+
+YmLattice make_lattice(const YmGeom &g, double off, double step, double angle_off, double angle_res, int fine,
+                       int penalize) {
+    YmLattice l;
+    std::memset(&l, 0, sizeof l);
+    l.off_x = l.off_y = off;
+    l.step_x = l.step_y = step;
+    l.angle_off = angle_off;
+    l.angle_res = angle_res;
+    l.nx = (int)(kt_round_h(off * 2.0 / step) + 1);
+    l.ny = l.nx;
+    l.nt = (int)(kt_round_h(angle_off * 2.0 / angle_res) + 1);
+    l.fine = fine;
+    l.penalize = penalize;
+    (void)g;
+    return l;
+}
+
+// ---------------------------------------------------------------- profiling helpers
+int prof_begin(ym_matcher *m, int which, hipEvent_t *stop_out) {
+    *stop_out = nullptr;
+    if (!m->profiling) return YM_OK;
+    ProfEvents &p = m->prof[which];
+    if (p.used == p.pairs.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        p.pairs.emplace_back(a, b);
+    }
+    HIP_TRY(hipEventRecord(p.pairs[p.used].first, m->stream));
+    *stop_out = p.pairs[p.used].second;
+    p.used++;
+    return YM_OK;
+}
+int prof_end(ym_matcher *m, hipEvent_t stop) {
+    if (stop) HIP_TRY(hipEventRecord(stop, m->stream));
+    return YM_OK;
+}
+int prof_collect(ym_matcher *m) {
+    for (auto &p : m->prof) {
+        for (size_t i = 0; i < p.used; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventSynchronize(p.pairs[i].second));
+            HIP_TRY(hipEventElapsedTime(&ms, p.pairs[i].first, p.pairs[i].second));
+            p.ms += ms;
+            p.launches++;
+        }
+        p.used = 0;
+    }
+    return YM_OK;
+}
+
+// ---------------------------------------------------------------- launch one call
+int launch_call(ym_matcher *m, Slot &slot) {
+    Call &call = slot.call;
+    const int B = (int)call.items.size();
+    const int nscans = (int)call.scans.size();
+    if (B <= 0) return set_err(YM_ERR_INVALID, "empty call");
+    HIP_TRY(hipSetDevice(m->device));
+    YmGeom g = m->geom;
+    if (g.zone_count > 1)
+        return set_err(YM_ERR_UNSUPPORTED,
+                       "smear_deviation/resolution = %g makes Karto's AddScan order-dependent (kernel has %d taps "
+                       "equal to 100); not supported by this build",
+                       m->cfg.smear_deviation / m->cfg.resolution, g.zone_count);
+
+    // ---- sizes
+    int max_n = 1, max_base = 1;
+    double rq = 0;
+    for (const CallItem &it : call.items) {
+        max_base = std::max(max_base, it.base_count);
+        rq = std::max(rq, call.scans[it.query].max_valid);
+    }
+    for (const CallScan &s : call.scans) max_n = std::max(max_n, s.n);
+    if (max_n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", max_n, YM_MAX_BEAMS);
+
+    // ---- lattices (ScanMatcher::MatchScan)
+    const double coarse_off = 0.5 * (g.side - 1) * g.res;
+    const double coarse_step = 2 * g.res;
+    YmLattice lc = make_lattice(g, coarse_off, coarse_step, call.coarse_angle_off, m->cfg.coarse_angle_resolution, 0,
+                                call.penalize);
+    YmLattice lf = make_lattice(g, coarse_step * 0.5, g.res, 0.5 * m->cfg.coarse_angle_resolution,
+                                m->cfg.fine_search_angle_resolution, 1, call.penalize);
+    slot.coarse = lc;
+    slot.fine = lf;
+
+    // ---- device window: the central part of Karto's storage the query endpoints can reach
+    const int centre = g.border + (g.roi_w - 1) / 2;
+    const double reach = rq + coarse_off + g.res;
+    int wh = (int)std::ceil(reach * g.scale) + 3;
+    wh = std::min(wh, centre);
+    g.win_origin = centre - wh;
+    g.win_w = 2 * wh + 1;
+    const int tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
+    const int tiles_y = (g.win_w + YM_TILE_H - 1) / YM_TILE_H;
+    g.pitch = tiles_x * YM_TILE_W + 64;
+    const size_t grid_stride = align_up((size_t)g.pitch * g.win_w + 64, 256);
+    if ((double)g.pitch * g.win_w > 2.0e9) return set_err(YM_ERR_UNSUPPORTED, "correlation window too large");
+
+    const int nt_stride = std::max(lc.nt, lf.nt);
+    const int dim_stride = std::max(std::max(lc.nx, lc.ny), std::max(lf.nx, lf.ny));
+    const size_t sums_c = (size_t)lc.nt * lc.ny * lc.nx;
+    const size_t sums_f = (size_t)lf.nt * lf.ny * lf.nx;
+
+    int rc;
+    if ((rc = m->states.ensure(B))) return rc;
+    if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
+    if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
+    if ((rc = m->counts.ensure((size_t)B * max_base))) return rc;
+    if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
+    if ((rc = m->offsets.ensure((size_t)B * nt_stride * max_n))) return rc;
+    if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
+    if ((rc = m->sums.ensure((size_t)B * (sums_c + sums_f)))) return rc;
+    if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
+
+    // ---- descriptor blob
+    const size_t scans_bytes = align_up(sizeof(YmScanRef) * nscans, 16);
+    const size_t desc_bytes = scans_bytes + sizeof(YmItem) * B;
+    if ((rc = slot.desc.ensure(desc_bytes))) return rc;
+    if ((rc = slot.result.ensure(sizeof(YmItemState) * B))) return rc;
+    if ((rc = m->desc.ensure(desc_bytes))) return rc;
+    YmScanRef *hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
+    YmItem *hi = reinterpret_cast<YmItem *>(slot.desc.p + scans_bytes);
+    for (int i = 0; i < nscans; i++) {
+        const CallScan &s = call.scans[i];
+        hs[i].ranges = s.d_ranges;
+        hs[i].n = s.n;
+        hs[i].pad = 0;
+        hs[i].min_angle = s.min_angle;
+        hs[i].angle_inc = s.angle_inc;
+        hs[i].min_range = s.min_range;
+        hs[i].range_threshold = s.range_threshold;
+        hs[i].pose[0] = s.pose[0]; hs[i].pose[1] = s.pose[1]; hs[i].pose[2] = s.pose[2];
+    }
+    for (int i = 0; i < B; i++) {
+        hi[i].query = call.items[i].query;
+        hi[i].base_begin = call.items[i].base_begin;
+        hi[i].base_count = call.items[i].base_count;
+        hi[i].pad = 0;
+    }
+    hipStream_t st = m->stream;
+    hipEvent_t ev_call = nullptr, ev_k = nullptr;
+    if ((rc = prof_begin(m, 2, &ev_call))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->desc.p, slot.desc.p, desc_bytes, hipMemcpyHostToDevice, st));
+    const YmScanRef *d_scans = reinterpret_cast<const YmScanRef *>(m->desc.p);
+    const YmItem *d_items = reinterpret_cast<const YmItem *>(m->desc.p + scans_bytes);
+
+    // ---- K1
+    {
+        ym::PrepareArgs a;
+        a.scans = d_scans; a.items = d_items; a.g = g; a.states = m->states.p; a.qlocal = m->qlocal.p;
+        a.cells = m->cells.p; a.counts = m->counts.p; a.max_n = max_n; a.max_base = max_base;
+        const size_t lds = (size_t)max_n * 21 + 16;
+        hipLaunchKernelGGL(ym::prepare_kernel, dim3(max_base + 1, B), dim3(256), lds, st, a);
+    }
+    // ---- K2
+    {
+        ym::RasterArgs a;
+        a.cells = m->cells.p; a.counts = m->counts.p; a.items = d_items; a.g = g; a.grid = m->grid.p;
+        a.grid_stride = grid_stride; a.ktab = m->ktab.p; a.max_n = max_n; a.max_base = max_base;
+        if ((rc = prof_begin(m, 1, &ev_k))) return rc;
+        hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(256), 0, st, a);
+        if ((rc = prof_end(m, ev_k))) return rc;
+    }
+    // ---- passes
+    m->sums_pass_offset[0] = 0;
+    m->sums_pass_offset[1] = (size_t)B * sums_c;
+    for (int pass = 0; pass < (call.refine ? 2 : 1); pass++) {
+        const YmLattice &lat = pass ? lf : lc;
+        const size_t sums_stride = pass ? sums_f : sums_c;
+        uint32_t *sums = m->sums.p + m->sums_pass_offset[pass];
+        {
+            ym::OffsetsArgs a;
+            a.g = g; a.lat = lat; a.states = m->states.p; a.qlocal = m->qlocal.p; a.offsets = m->offsets.p;
+            a.hypcell = m->hypcell.p; a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride;
+            hipLaunchKernelGGL(ym::offsets_kernel, dim3((max_n + 255) / 256, lat.nt + 1, B), dim3(256), 0, st, a);
+        }
+        {
+            ym::CorrArgs a;
+            a.g = g; a.lat = lat; a.grid = m->grid.p; a.grid_stride = grid_stride; a.offsets = m->offsets.p;
+            a.hypcell = m->hypcell.p; a.states = m->states.p; a.sums = sums; a.sums_stride = sums_stride;
+            a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride;
+            ev_k = nullptr;
+            if (pass == 0 && (rc = prof_begin(m, 0, &ev_k))) return rc;
+            hipLaunchKernelGGL(ym::correlate_generic_kernel, dim3((lat.nx * lat.ny + 255) / 256, lat.nt, B),
+                               dim3(256), 0, st, a);
+            if ((rc = prof_end(m, ev_k))) return rc;
+        }
+        {
+            ym::ReduceArgs a;
+            a.g = g; a.lat = lat; a.sums = sums; a.sums_stride = sums_stride; a.states = m->states.p;
+            a.probs = m->probs.p; a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p;
+            a.grid_stride = grid_stride; a.offsets = m->offsets.p; a.max_n = max_n; a.nt_stride = nt_stride;
+            hipLaunchKernelGGL(ym::reduce_kernel, dim3(B), dim3(1024), 0, st, a);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(slot.result.p, m->states.p, sizeof(YmItemState) * B, hipMemcpyDeviceToHost, st));
+    if ((rc = prof_end(m, ev_call))) return rc;
+    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(slot.done, st));
+    slot.in_flight = true;
+    slot.n_items = B;
+
+    m->last_geom = g;
+    m->last_lat[0] = lc;
+    m->last_lat[1] = lf;
+    m->last_B = B; m->last_max_n = max_n; m->last_max_base = max_base;
+    m->last_nt_stride = nt_stride; m->last_dim_stride = dim_stride;
+    m->last_grid_stride = grid_stride;
+    m->last_sums_stride[0] = sums_c; m->last_sums_stride[1] = call.refine ? sums_f : 0;
+    m->last_valid = true;
+    return YM_OK;
+}
+
+void state_to_result(const ym_matcher *m, const Slot &slot, const YmItemState &s, int expansions, int64_t prior_hyp,
+                     ym_result *r) {
+    std::memset(r, 0, sizeof *r);
+    r->response = s.response;
+    for (int i = 0; i < 3; i++) r->pose[i] = s.mean[i];
+    for (int i = 0; i < 9; i++) r->cov[i] = s.cov[i];
+    r->coarse_response = s.coarse_response;
+    r->coarse_dims[0] = slot.coarse.nx; r->coarse_dims[1] = slot.coarse.ny; r->coarse_dims[2] = slot.coarse.nt;
+    int64_t hyp = (int64_t)slot.coarse.nx * slot.coarse.ny * slot.coarse.nt;
+    if (slot.call.refine) {
+        r->fine_dims[0] = slot.fine.nx; r->fine_dims[1] = slot.fine.ny; r->fine_dims[2] = slot.fine.nt;
+        hyp += (int64_t)slot.fine.nx * slot.fine.ny * slot.fine.nt;
+    }
+    if (s.nq == 0) { // MatchScan returns before any correlation
+        hyp = 0;
+        std::memset(r->coarse_dims, 0, sizeof r->coarse_dims);
+        std::memset(r->fine_dims, 0, sizeof r->fine_dims);
+    }
+    r->hypotheses = prior_hyp + hyp;
+    r->n_query_points = s.nq;
+    r->expansions = expansions;
+    r->status = s.status;
+    (void)m;
+}
+
+// wait for a slot; handle Karto's response expansion (re-run with a wider coarse angle range)
+int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */) {
+    if (!slot.in_flight) return set_err(YM_ERR_BUSY, "slot has no call in flight");
+    HIP_TRY(hipEventSynchronize(slot.done));
+    slot.in_flight = false;
+    const int B = slot.n_items;
+    const YmItemState *hs = reinterpret_cast<const YmItemState *>(slot.result.p);
+    std::vector<int> redo;
+    std::vector<int64_t> prior(B, 0);
+    for (int i = 0; i < B; i++) {
+        state_to_result(m, slot, hs[i], 0, 0, &out[i]);
+        if (m->cfg.use_response_expansion && kt_double_equal_h(hs[i].coarse_response, 0.0)) redo.push_back(i);
+    }
+    // up to three retries, +20 degrees each (ScanMatcher::MatchScan).  A retry re-runs the whole
+    // pipeline for the affected items with the wider coarse angle range (rare path).
+    const Call base_call = slot.call;
+    const int64_t nxy = (int64_t)slot.coarse.nx * slot.coarse.ny;
+    double off = m->cfg.coarse_search_angle_offset;
+    for (int attempt = 1; attempt <= 3 && !redo.empty(); attempt++) {
+        const int64_t prev_hyp = nxy * (int64_t)(kt_round_h(off * 2.0 / m->cfg.coarse_angle_resolution) + 1);
+        off += 20.0 * YM_KT_PI / 180.0;
+        Slot &s2 = m->slots[kAsyncSlots];
+        Call sub;
+        sub.scans = base_call.scans;
+        sub.penalize = base_call.penalize;
+        sub.refine = base_call.refine;
+        sub.coarse_angle_off = off;
+        for (int i : redo) {
+            prior[i] += prev_hyp;
+            sub.items.push_back(base_call.items[i]);
+        }
+        s2.call = sub;
+        int rc = launch_call(m, s2);
+        if (rc) return rc;
+        HIP_TRY(hipEventSynchronize(s2.done));
+        s2.in_flight = false;
+        const YmItemState *h2 = reinterpret_cast<const YmItemState *>(s2.result.p);
+        std::vector<int> still;
+        for (size_t j = 0; j < redo.size(); j++) {
+            const int i = redo[j];
+            state_to_result(m, s2, h2[j], attempt, prior[i], &out[i]);
+            if (kt_double_equal_h(h2[j].coarse_response, 0.0)) still.push_back(i);
+        }
+        redo.swap(still);
+    }
+    return YM_OK;
+}
+
+int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
+    if (!s) return set_err(YM_ERR_INVALID, "null scan");
+    o->d_ranges = s->d_ranges;
+    o->n = s->n;
+    o->min_angle = s->min_angle;
+    o->angle_inc = s->angle_inc;
+    o->min_range = s->min_range;
+    o->range_threshold = s->range_threshold;
+    o->pose[0] = s->pose[0]; o->pose[1] = s->pose[1]; o->pose[2] = s->pose[2];
+    o->max_valid = semantics == YM_SEM_YAGPY ? s->max_valid_yagpy : s->max_valid_karto;
+    return YM_OK;
+}
+
+void max_valid_ranges(const double *r, int n, double min_range, double rt, double *karto, double *yagpy) {
+    double k = 0, y = 0;
+    for (int i = 0; i < n; i++) {
+        const double v = r[i];
+        if (v >= min_range && v <= rt) k = std::max(k, v);
+        if (!(v > rt || std::isnan(v))) y = std::max(y, std::fabs(v));
+    }
+    *karto = k;
+    *yagpy = y;
+}
+
+int check_desc(const ym_scan_desc *d) {
+    if (!d) return set_err(YM_ERR_INVALID, "null scan descriptor");
+    if (d->n < 0 || (d->n > 0 && !d->ranges)) return set_err(YM_ERR_INVALID, "scan has n=%d but no ranges", d->n);
+    if (d->n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", d->n, YM_MAX_BEAMS);
+    return YM_OK;
+}
+
+int build_single_call(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base, int penalize,
+                      int refine, Call *call) {
+    if (!m || !query) return set_err(YM_ERR_INVALID, "null argument");
+    if (n_base < 0 || (n_base > 0 && !base)) return set_err(YM_ERR_INVALID, "bad base scan list");
+    call->scans.resize(1 + n_base);
+    int rc = scan_to_call(query, m->cfg.semantics, &call->scans[0]);
+    if (rc) return rc;
+    if (query->device != m->device) return set_err(YM_ERR_INVALID, "query scan lives on another device");
+    for (int i = 0; i < n_base; i++) {
+        if ((rc = scan_to_call(base[i], m->cfg.semantics, &call->scans[1 + i]))) return rc;
+        if (base[i]->device != m->device) return set_err(YM_ERR_INVALID, "base scan lives on another device");
+    }
+    call->items.assign(1, CallItem{0, 1, n_base});
+    call->penalize = penalize ? 1 : 0;
+    call->refine = refine ? 1 : 0;
+    call->coarse_angle_off = m->cfg.coarse_search_angle_offset;
+    return YM_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int ym_version(void) { return YM_VERSION; }
+
+int ym_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ym_last_error(void) { return g_err.c_str(); }
+
+ym_matcher *ym_create(const ym_config *cfg, int device) {
+    if (!cfg) { set_err(YM_ERR_INVALID, "null config"); return nullptr; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_err(YM_ERR_NO_DEVICE, "no HIP device available (libyagmatch has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { set_err(YM_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, n); return nullptr; }
+    ym_matcher *m = new ym_matcher();
+    m->cfg = *cfg;
+    m->device = device;
+    m->own_stream = nullptr;
+    if (build_geometry(m) != YM_OK) { delete m; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err(YM_ERR_HIP, "cannot create a stream on device %d", device);
+        delete m;
+        return nullptr;
+    }
+    m->stream = m->own_stream;
+    if (upload_ktab(m) != YM_OK) { ym_destroy(m); return nullptr; }
+    return m;
+}
+
+void ym_destroy(ym_matcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->ktab.release(); m->desc.release(); m->states.release(); m->qlocal.release(); m->cells.release();
+    m->counts.release(); m->grid.release(); m->offsets.release(); m->hypcell.release(); m->sums.release();
+    m->probs.release(); m->tmp_ranges.release(); m->tmp_ranges_host.release();
+    for (Slot &s : m->slots) {
+        s.desc.release();
+        s.result.release();
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto &p : m->prof)
+        for (auto &e : p.pairs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    delete m;
+}
+
+int ym_get_config(const ym_matcher *m, ym_config *out) {
+    if (!m || !out) return set_err(YM_ERR_INVALID, "null argument");
+    *out = m->cfg;
+    return YM_OK;
+}
+
+int ym_set_stream(ym_matcher *m, void *hip_stream) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->own_stream;
+    return YM_OK;
+}
+
+int ym_synchronize(ym_matcher *m) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return YM_OK;
+}
+
+// ---- scans
+ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
+    if (check_desc(d) != YM_OK) return nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err(YM_ERR_NO_DEVICE, "no HIP device available"); return nullptr; }
+    if (device < 0 || device >= n) { set_err(YM_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, n); return nullptr; }
+    ym_scan *s = new ym_scan();
+    s->device = device;
+    s->n = d->n;
+    s->min_angle = d->min_angle; s->max_angle = d->max_angle; s->angle_inc = d->angle_increment;
+    s->min_range = d->min_range; s->max_range = d->max_range; s->range_threshold = d->range_threshold;
+    s->pose[0] = d->pose[0]; s->pose[1] = d->pose[1]; s->pose[2] = d->pose[2];
+    s->d_ranges = nullptr;
+    max_valid_ranges(d->ranges, d->n, d->min_range, d->range_threshold, &s->max_valid_karto, &s->max_valid_yagpy);
+    if (hipSetDevice(device) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&s->d_ranges), sizeof(double) * std::max(1, d->n)) != hipSuccess) {
+        set_err(YM_ERR_HIP, "cannot allocate device ranges");
+        delete s;
+        return nullptr;
+    }
+    if (d->n > 0 && hipMemcpy(s->d_ranges, d->ranges, sizeof(double) * d->n, hipMemcpyHostToDevice) != hipSuccess) {
+        set_err(YM_ERR_HIP, "cannot upload ranges");
+        (void)hipFree(s->d_ranges);
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+int ym_scan_set_pose(ym_scan *s, double x, double y, double heading) {
+    if (!s) return set_err(YM_ERR_INVALID, "null scan");
+    s->pose[0] = x; s->pose[1] = y; s->pose[2] = heading;
+    return YM_OK;
+}
+
+int ym_scan_get_pose(const ym_scan *s, double pose[3]) {
+    if (!s || !pose) return set_err(YM_ERR_INVALID, "null argument");
+    pose[0] = s->pose[0]; pose[1] = s->pose[1]; pose[2] = s->pose[2];
+    return YM_OK;
+}
+
+int ym_scan_size(const ym_scan *s) { return s ? s->n : YM_ERR_INVALID; }
+
+void ym_scan_destroy(ym_scan *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->d_ranges) (void)hipFree(s->d_ranges);
+    delete s;
+}
+
+// ---- hot path
+int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base, int penalize,
+                   int refine, ym_result *out) {
+    if (!out) return set_err(YM_ERR_INVALID, "null result");
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    Slot &slot = m->slots[kAsyncSlots];
+    Call call;
+    int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
+    if (rc) return rc;
+    slot.call = call;
+    if ((rc = launch_call(m, slot))) return rc;
+    return finish_call(m, slot, out);
+}
+
+int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base, int n_base, int penalize, int refine,
+             ym_result *out) {
+    if (!m || !out) return set_err(YM_ERR_INVALID, "null argument");
+    if (n_base < 0 || (n_base > 0 && !base)) return set_err(YM_ERR_INVALID, "bad base scan list");
+    int rc;
+    if ((rc = check_desc(query))) return rc;
+    size_t total = (size_t)query->n;
+    for (int i = 0; i < n_base; i++) {
+        if ((rc = check_desc(&base[i]))) return rc;
+        total += (size_t)base[i].n;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    // the staging buffers may still feed an earlier async copy on this stream
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if ((rc = m->tmp_ranges.ensure(total + 1))) return rc;
+    if ((rc = m->tmp_ranges_host.ensure(sizeof(double) * (total + 1)))) return rc;
+    double *hr = reinterpret_cast<double *>(m->tmp_ranges_host.p);
+    Call call;
+    call.scans.resize(1 + n_base);
+    size_t at = 0;
+    for (int i = 0; i <= n_base; i++) {
+        const ym_scan_desc &d = i == 0 ? *query : base[i - 1];
+        if (d.n > 0) std::memcpy(hr + at, d.ranges, sizeof(double) * d.n);
+        CallScan &c = call.scans[i];
+        c.d_ranges = m->tmp_ranges.p + at;
+        c.n = d.n;
+        c.min_angle = d.min_angle; c.angle_inc = d.angle_increment; c.min_range = d.min_range;
+        c.range_threshold = d.range_threshold;
+        c.pose[0] = d.pose[0]; c.pose[1] = d.pose[1]; c.pose[2] = d.pose[2];
+        double k, y;
+        max_valid_ranges(d.ranges, d.n, d.min_range, d.range_threshold, &k, &y);
+        c.max_valid = m->cfg.semantics == YM_SEM_YAGPY ? y : k;
+        at += (size_t)d.n;
+    }
+    if (total > 0)
+        HIP_TRY(hipMemcpyAsync(m->tmp_ranges.p, hr, sizeof(double) * total, hipMemcpyHostToDevice, m->stream));
+    call.items.assign(1, CallItem{0, 1, n_base});
+    call.penalize = penalize ? 1 : 0;
+    call.refine = refine ? 1 : 0;
+    call.coarse_angle_off = m->cfg.coarse_search_angle_offset;
+    Slot &slot = m->slots[kAsyncSlots];
+    slot.call = call;
+    if ((rc = launch_call(m, slot))) return rc;
+    return finish_call(m, slot, out);
+}
+
+int ym_async_slots(const ym_matcher *m) { return m ? kAsyncSlots : YM_ERR_INVALID; }
+
+int ym_match_scans_async(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base, int penalize,
+                         int refine, int slot_idx) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    if (slot_idx < 0 || slot_idx >= kAsyncSlots) return set_err(YM_ERR_INVALID, "slot %d out of range", slot_idx);
+    Slot &slot = m->slots[slot_idx];
+    if (slot.in_flight) return set_err(YM_ERR_BUSY, "slot %d still holds an uncollected call", slot_idx);
+    Call call;
+    int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
+    if (rc) return rc;
+    slot.call = call;
+    return launch_call(m, slot);
+}
+
+int ym_wait(ym_matcher *m, int slot_idx, ym_result *out) {
+    if (!m || !out) return set_err(YM_ERR_INVALID, "null argument");
+    if (slot_idx < 0 || slot_idx >= kAsyncSlots) return set_err(YM_ERR_INVALID, "slot %d out of range", slot_idx);
+    Slot &slot = m->slots[slot_idx];
+    std::vector<ym_result> tmp(std::max(1, slot.n_items));
+    int rc = finish_call(m, slot, tmp.data());
+    if (rc) return rc;
+    *out = tmp[0];
+    return YM_OK;
+}
+
+int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
+                   int n_chains, int penalize, int refine, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
+    if (!m || !query || !chain_offsets) return set_err(YM_ERR_INVALID, "null argument");
+    if (n_chains <= 0) return set_err(YM_ERR_INVALID, "n_chains must be > 0");
+    const int n_scans = chain_offsets[n_chains];
+    if (n_scans < 0 || (n_scans > 0 && !scans)) return set_err(YM_ERR_INVALID, "bad scan list");
+    Call call;
+    call.scans.resize(1 + (size_t)n_scans);
+    int rc = scan_to_call(query, m->cfg.semantics, &call.scans[0]);
+    if (rc) return rc;
+    for (int i = 0; i < n_scans; i++)
+        if ((rc = scan_to_call(scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
+    call.items.resize(n_chains);
+    for (int c = 0; c < n_chains; c++) {
+        if (chain_offsets[c + 1] < chain_offsets[c]) return set_err(YM_ERR_INVALID, "chain_offsets must be non-decreasing");
+        call.items[c] = CallItem{0, 1 + chain_offsets[c], chain_offsets[c + 1] - chain_offsets[c]};
+    }
+    call.penalize = penalize ? 1 : 0;
+    call.refine = refine ? 1 : 0;
+    call.coarse_angle_off = m->cfg.coarse_search_angle_offset;
+    Slot &slot = m->slots[kAsyncSlots];
+    slot.call = call;
+    if ((rc = launch_call(m, slot))) return rc;
+    std::vector<ym_result> res(n_chains);
+    if ((rc = finish_call(m, slot, res.data()))) return rc;
+    int bi = 0;
+    for (int c = 1; c < n_chains; c++)
+        if (res[c].response > res[bi].response) bi = c;
+    if (per_chain) std::memcpy(per_chain, res.data(), sizeof(ym_result) * n_chains);
+    if (best) *best = res[bi];
+    if (best_chain) *best_chain = bi;
+    return YM_OK;
+}
+
+int ym_match_batch_async(ym_matcher *, const ym_scan *, const ym_scan *const *, const int32_t *, int, int, int, int64_t,
+                         void *) {
+    return set_err(YM_ERR_UNSUPPORTED, "ym_match_batch_async is not implemented in this build yet");
+}
+
+// ---- debug getters
+int ym_debug_grid_info(ym_matcher *m, int item, ym_grid_info *info) {
+    if (!m || !info) return set_err(YM_ERR_INVALID, "null argument");
+    if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
+    const YmGeom &g = m->last_geom;
+    info->width = g.win_w; info->height = g.win_w; info->pitch = g.pitch;
+    info->origin_x = g.win_origin; info->origin_y = g.win_origin;
+    info->storage_w = g.storage_w; info->storage_h = g.storage_w;
+    info->roi_x = g.border; info->roi_y = g.border; info->roi_w = g.roi_w; info->roi_h = g.roi_w;
+    YmItemState s;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(&s, m->states.p + item, sizeof s, hipMemcpyDeviceToHost));
+    info->offset_x = s.off_x; info->offset_y = s.off_y;
+    return YM_OK;
+}
+
+int ym_debug_grid(ym_matcher *m, int item, uint8_t *out, int64_t out_bytes) {
+    if (!m || !out) return set_err(YM_ERR_INVALID, "null argument");
+    if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
+    const int64_t need = (int64_t)m->last_geom.pitch * m->last_geom.win_w;
+    if (out_bytes < need) return set_err(YM_ERR_INVALID, "grid buffer too small: need %lld bytes", (long long)need);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(out, m->grid.p + (size_t)item * m->last_grid_stride, (size_t)need, hipMemcpyDeviceToHost));
+    return YM_OK;
+}
+
+int ym_debug_sums(ym_matcher *m, int item, int pass, uint32_t *out, int64_t out_count) {
+    if (!m || !out || pass < 0 || pass > 1) return set_err(YM_ERR_INVALID, "bad argument");
+    if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
+    const size_t n = m->last_sums_stride[pass];
+    if (n == 0) return set_err(YM_ERR_INVALID, "pass %d did not run", pass);
+    if ((size_t)out_count < n) return set_err(YM_ERR_INVALID, "sums buffer too small: need %zu entries", n);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(out, m->sums.p + m->sums_pass_offset[pass] + (size_t)item * n, n * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
+    return YM_OK;
+}
+
+int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, int32_t *n) {
+    if (!m || !out_xy || !n) return set_err(YM_ERR_INVALID, "null argument");
+    if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
+    YmItemState s;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(&s, m->states.p + item, sizeof s, hipMemcpyDeviceToHost));
+    *n = s.nq;
+    if (cap < s.nq) return set_err(YM_ERR_INVALID, "buffer too small: need %d points", s.nq);
+    if (s.nq > 0)
+        HIP_TRY(hipMemcpy(out_xy, m->qlocal.p + (size_t)item * m->last_max_n, sizeof(double2) * s.nq, hipMemcpyDeviceToHost));
+    return YM_OK;
+}
+
+int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int32_t *max_n) {
+    if (!m || !max_n) return set_err(YM_ERR_INVALID, "null argument");
+    if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
+    *max_n = m->last_max_n;
+    const size_t per = (size_t)m->last_max_base * m->last_max_n;
+    if (!out) return YM_OK;
+    if ((size_t)out_count < per * 2) return set_err(YM_ERR_INVALID, "buffer too small: need %zu ints", per * 2);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    std::vector<int32_t> counts(m->last_max_base);
+    HIP_TRY(hipMemcpy(counts.data(), m->counts.p + (size_t)item * m->last_max_base, sizeof(int32_t) * m->last_max_base,
+                      hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, m->cells.p + (size_t)item * per, sizeof(int2) * per, hipMemcpyDeviceToHost));
+    for (int s = 0; s < m->last_max_base; s++)
+        for (int i = counts[s]; i < m->last_max_n; i++) {
+            out[((size_t)s * m->last_max_n + i) * 2] = INT32_MIN;
+            out[((size_t)s * m->last_max_n + i) * 2 + 1] = INT32_MIN;
+        }
+    return YM_OK;
+}
+
+// ---- profiling
+int ym_profile_enable(ym_matcher *m, int on) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    m->profiling = on != 0;
+    return YM_OK;
+}
+
+int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launches, int reset) {
+    if (!m || which < 0 || which > 2) return set_err(YM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    int rc = prof_collect(m);
+    if (rc) return rc;
+    if (ms_total) *ms_total = m->prof[which].ms;
+    if (launches) *launches = m->prof[which].launches;
+    if (reset) { m->prof[which].ms = 0; m->prof[which].launches = 0; }
+    return YM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// ym_types.h -- plain structs shared by host code and gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#define YM_OCCUPIED 100
+#define YM_KT_TOLERANCE 1e-06
+#define YM_MAX_VARIANCE 500.0
+#define YM_PENALTY_GAIN 0.2
+#define YM_KT_PI 3.14159265358979323846
+#define YM_KT_2PI 6.28318530717958647692
+#define YM_CELL_NONE INT32_MIN
+#define YM_MAX_BEAMS 8192          // per scan; bounds the LDS staging of one scan
+#define YM_MAX_KERNEL_HALF 20      // sigma <= 10*res  ->  half = Round(2*sigma/res) <= 20
+
+// Grid geometry of one matcher configuration + the device window chosen for one call.
+// Karto: ScanMatcher::Create / CorrelationGrid::CreateGrid.  The device never allocates Karto's
+// full (search + 2*range_threshold)/res square: it keeps the central window that the query's
+// endpoints can reach (all other cells are provably never read).
+struct YmGeom {
+    double scale;        // 1 / resolution      (CoordinateConverter::m_Scale)
+    double res;          // 1 / scale           (Grid::GetResolution())
+    int32_t side;        // search-space side   Round(S/res) + 1
+    int32_t roi_w;       // ROI width = height  side + 2*ceil(rt/res)
+    int32_t border;      // half_kernel + 1     (ROI origin inside the storage)
+    int32_t storage_w;   // roi_w + 2*border
+    int32_t half_kernel; // Round(2*sigma/res)
+    int32_t zone_count;  // kernel taps equal to 100 (1 = only the centre)
+    // device window, in Karto storage coordinates
+    int32_t win_origin;  // storage coordinate of window cell (0,0), same for x and y
+    int32_t win_w;       // window width = height in cells
+    int32_t pitch;       // bytes per window row (multiple of 64, >= win_w + 64)
+    int32_t semantics;
+    // penalties (Karto CorrelateScan)
+    double dist_var, ang_var, min_dist_pen, min_ang_pen;
+};
+
+// one search lattice (coarse or fine pass)
+struct YmLattice {
+    int32_t nx, ny, nt;
+    int32_t fine;      // 0 coarse, 1 fine
+    int32_t penalize;
+    int32_t pad;
+    double off_x, off_y;     // half extents (metres)
+    double step_x, step_y;   // lattice step (metres)
+    double angle_off, angle_res;
+};
+
+// device-visible scan descriptor (one per scan referenced by a call)
+struct YmScanRef {
+    const double *ranges; // DEVICE pointer
+    int32_t n;
+    int32_t pad;
+    double min_angle, angle_inc, min_range, range_threshold;
+    double pose[3];
+};
+
+// one batch item = one (query, chain) problem
+struct YmItem {
+    int32_t query;      // index into the scan-ref table
+    int32_t base_begin; // first base scan in the scan-ref table
+    int32_t base_count;
+    int32_t pad;
+};
+
+// per-item device state handed from kernel to kernel, and finally copied back
+struct YmItemState {
+    double pose[3];       // query pose (search centre of the coarse pass)
+    double off_x, off_y;  // world coordinate of ROI cell (0,0)
+    double center[3];     // centre of the NEXT pass (coarse: pose, fine: coarse mean)
+    double mean[3];       // result of the last pass
+    double response;      // clamped best response of the last pass
+    double coarse_response;
+    double cov[9];
+    int32_t nq;           // number of query point readings (normaliser)
+    int32_t status;
+    int32_t regular[2];   // per pass: hypothesis cells form an exact lattice (fast path legal)
+    int32_t pad[2];
+};

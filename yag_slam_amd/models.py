@@ -1,0 +1,158 @@
+"""Scan data model: drop-in for /root/reference/yag_slam/models.py:24-116.
+
+`LocalizedRangeScan` keeps the reference's constructor signature, pose properties with
+write-through to the native twin (models.py:67-75), `points()/points_local()`, `copy()` and `num`.
+The native twin `_scan` is a device-resident `ym_scan` (ranges in HBM) instead of the reference's
+karto_scanmatcher C++ object (models.py:37-39); it is created on first use by a matcher so that
+scans can be constructed on machines without a GPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from .transform import Transform
+
+
+def point_readings(ranges, x, y, t, min_angle, angle_increment, range_threshold):
+    """Endpoints of the readings with r <= range_threshold and not NaN, like
+    `_get_point_readings` (/root/reference/yag_slam/helpers.py:58-68).  Host-side convenience for
+    callers of `points()`; the matcher projects on the device."""
+    r = np.asarray(ranges, dtype=np.float64)
+    idx = np.nonzero(~((r > range_threshold) | np.isnan(r)))[0]
+    ang = t + min_angle + idx * angle_increment
+    return x + r[idx] * np.cos(ang), y + r[idx] * np.sin(ang)
+
+
+class LocalizedRangeScan:
+    def __init__(self, ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold,
+                 x, y, t):
+        self.ranges = np.array(ranges, dtype=np.float64).copy()
+        self.min_angle = min_angle
+        self.max_angle = max_angle
+        self.angle_increment = angle_increment
+        self.min_range = min_range
+        self.max_range = max_range
+        self.range_threshold = range_threshold
+
+        self._odom_pose = Transform.from_position_euler(x, y, 0, 0, 0, t)
+        self._corrected_pose = Transform.from_position_euler(x, y, 0, 0, 0, t)
+        self._id = 0
+        self._native = None      # ym_scan* (device twin), created lazily
+        self._native_device = None
+
+    # ---- native twin ---------------------------------------------------------------------
+    def native(self, device=0):
+        """Device-resident twin (ym_scan*), uploaded once; pose is written through on every set."""
+        if self._native is not None and self._native_device == device:
+            return self._native
+        self._release()
+        L = _capi.lib()
+        d = _capi.YmScanDesc()
+        r = np.ascontiguousarray(self.ranges, dtype=np.float64)
+        d.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
+        d.n = int(r.shape[0])
+        d.min_angle = float(self.min_angle)
+        d.max_angle = float(self.max_angle)
+        d.angle_increment = float(self.angle_increment)
+        d.min_range = float(self.min_range)
+        d.max_range = float(self.max_range)
+        d.range_threshold = float(self.range_threshold)
+        p = self._corrected_pose
+        d.pose[0], d.pose[1], d.pose[2] = p.x, p.y, p.euler[-1]
+        h = L.ym_scan_create(int(device), C.byref(d))
+        if not h:
+            raise _capi.YmError(-1, _capi.last_error())
+        self._native, self._native_device = h, device
+        return h
+
+    def _release(self):
+        if getattr(self, "_native", None) is not None:
+            try:
+                _capi.lib().ym_scan_destroy(self._native)
+            except Exception:
+                pass
+            self._native = None
+
+    def __del__(self):
+        self._release()
+
+    @property
+    def _scan(self):
+        return self.native(self._native_device or 0)
+
+    # ---- serialisation hooks used by yag-slam's serde (models.py:41-53) -------------------
+    @classmethod
+    def deserialize(cls, args):
+        return cls._deserialize(**args)
+
+    @classmethod
+    def _deserialize(cls, ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold,
+                     odom_pose, corrected_pose, num):
+        out = cls(ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold, 0, 0, 0)
+        odom_pose = {k: v for k, v in odom_pose.items() if k != "___name"}
+        corrected_pose = {k: v for k, v in corrected_pose.items() if k != "___name"}
+        out.odom_pose = Transform(**odom_pose)
+        out.corrected_pose = Transform(**corrected_pose)
+        out.num = num
+        return out
+
+    @property
+    def num(self):
+        return self._id
+
+    @num.setter
+    def num(self, val):
+        self._id = val
+
+    def _get_pose(self, odom=False):
+        return self._odom_pose if odom else self._corrected_pose
+
+    def _set_pose(self, val, odom=False):
+        if odom:
+            self._odom_pose = val
+        else:
+            self._corrected_pose = val
+            if self._native is not None:
+                _capi.check(_capi.lib().ym_scan_set_pose(self._native, float(val.x), float(val.y),
+                                                         float(val.euler[-1])))
+
+    @property
+    def odom_pose(self):
+        return self._get_pose(True)
+
+    @odom_pose.setter
+    def odom_pose(self, val):
+        self._set_pose(val, True)
+
+    @property
+    def corrected_pose(self):
+        return self._get_pose(False)
+
+    @corrected_pose.setter
+    def corrected_pose(self, val):
+        self._set_pose(val, False)
+
+    def points(self, odom=False):
+        p = self.corrected_pose if not odom else self.odom_pose
+        return self.points_for_pose2d(p.x, p.y, p.euler[-1])
+
+    def points_local(self):
+        return self.points_for_pose2d(0, 0, 0)
+
+    def points_for_pose2d(self, x, y, t):
+        return point_readings(self.ranges, x, y, t, self.min_angle, self.angle_increment, self.range_threshold)
+
+    def copy(self):
+        p = self.corrected_pose
+        return LocalizedRangeScan(self.ranges.copy(), self.min_angle, self.max_angle, self.angle_increment,
+                                  self.min_range, self.max_range, self.range_threshold, p.x, p.y, p.euler[-1])
+
+    @classmethod
+    def from_json(cls, d, x, y, t, invert=True):
+        ranges = d['ranges']
+        if invert:
+            ranges = ranges[::-1]
+        return cls(ranges, d['angle_min'], d['angle_max'], d['angle_increment'], d['range_min'], d['range_max'],
+                   d['range_max'] * 0.9, x, y, t)

@@ -1,0 +1,180 @@
+"""Matcher plugin: drop-in for /root/reference/yag_slam/scan_matching.py:29-42 (Scan2DMatcherCpp).
+
+`ScanMatcher(config_dict, loop).match_scan(query, base_scans, penalty, do_fine)` returns the
+reference's `ScanMatcherResult(response, covariance, best_pose, meta)` namedtuple; `.config` is the
+attribute bag yag-slam serialises (graph_slam.py:82-83).  All numerics run in libyagmatch.so on
+the MI355X; this file only marshals scans and results across the ctypes boundary.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _capi
+from .config import default_config, default_config_loop, make_config
+from .models import LocalizedRangeScan
+from .transform import Transform
+
+ScanMatcherResult = namedtuple('ScanMatcherResult', ['response', 'covariance', 'best_pose', 'meta'])
+
+
+def _pose_of(scan):
+    p = scan.corrected_pose
+    return float(p.x), float(p.y), float(p.euler[-1])
+
+
+def _desc_of(scan, keep):
+    """ym_scan_desc from any duck-typed LocalizedRangeScan (host ranges are uploaded per call)."""
+    d = _capi.YmScanDesc()
+    r = np.ascontiguousarray(scan.ranges, dtype=np.float64)
+    keep.append(r)
+    d.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
+    d.n = int(r.shape[0])
+    d.min_angle = float(scan.min_angle)
+    d.max_angle = float(getattr(scan, "max_angle", scan.min_angle + (d.n - 1) * scan.angle_increment))
+    d.angle_increment = float(scan.angle_increment)
+    d.min_range = float(scan.min_range)
+    d.max_range = float(getattr(scan, "max_range", 0.0))
+    d.range_threshold = float(scan.range_threshold)
+    d.pose[0], d.pose[1], d.pose[2] = _pose_of(scan)
+    return d
+
+
+def _result(r):
+    cov = [[r.cov[3 * i + j] for j in range(3)] for i in range(3)]
+    meta = {
+        "coarse_response": r.coarse_response, "hypotheses": int(r.hypotheses),
+        "coarse_dims": tuple(r.coarse_dims[:]), "fine_dims": tuple(r.fine_dims[:]),
+        "n_query_points": int(r.n_query_points), "expansions": int(r.expansions), "status": int(r.status),
+    }
+    return ScanMatcherResult(r.response, cov, Transform.from_position_euler(r.pose[0], r.pose[1], 0, 0, 0, r.pose[2]),
+                             meta)
+
+
+class ScanMatcher(object):
+    """MI355X correlative scan matcher behind yag-slam's matcher plugin surface."""
+
+    def __init__(self, config_dict=None, loop=False, semantics="karto", device=0):
+        cfg = default_config if not loop else default_config_loop
+        cfg = cfg.copy()
+        if config_dict:
+            cfg.update(config_dict)
+        self.config = make_config(cfg)
+        self.semantics = semantics
+        self.device = int(device)
+        self._lib = _capi.lib()
+        self._cfg = _capi.config_struct(self.config, semantics)
+        self._m = self._lib.ym_create(C.byref(self._cfg), self.device)
+        if not self._m:
+            raise _capi.YmError(-1, _capi.last_error())
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.ym_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- handles -------------------------------------------------------------------------
+    def _native(self, scan):
+        """ym_scan* of a scan with the CURRENT corrected pose (resident if it is our LocalizedRangeScan)."""
+        if isinstance(scan, LocalizedRangeScan):
+            h = scan.native(self.device)
+            x, y, t = _pose_of(scan)
+            _capi.check(self._lib.ym_scan_set_pose(h, x, y, t))
+            return h
+        return None
+
+    # ---- the plugin call -------------------------------------------------------------------
+    def match_scan(self, query, base_scans, penalty=True, do_fine=False):
+        res = _capi.YmResult()
+        handles = [self._native(s) for s in [query] + list(base_scans)]
+        if all(h is not None for h in handles):
+            arr = (C.c_void_p * max(1, len(base_scans)))(*handles[1:])
+            _capi.check(self._lib.ym_match_scans(self._m, handles[0], arr, len(base_scans), int(bool(penalty)),
+                                                 int(bool(do_fine)), C.byref(res)))
+        else:
+            keep = []
+            q = _desc_of(query, keep)
+            b = (_capi.YmScanDesc * max(1, len(base_scans)))(*[_desc_of(s, keep) for s in base_scans])
+            _capi.check(self._lib.ym_match(self._m, C.byref(q), b, len(base_scans), int(bool(penalty)),
+                                           int(bool(do_fine)), C.byref(res)))
+        if res.status != 0:
+            raise _capi.YmError(res.status, "Mapper FATAL ERROR - unable to find best position / index out of range")
+        return _result(res)
+
+    def match_scan_batch(self, query, chains, penalty=False, do_fine=False):
+        """One query against many candidate chains (the loop of graph_slam.py:217-236 in one call).
+        Returns (per_chain_results, best_index)."""
+        flat, offs = [], [0]
+        for ch in chains:
+            flat.extend(ch)
+            offs.append(len(flat))
+        hq = self._require_native(query)
+        hs = (C.c_void_p * max(1, len(flat)))(*[self._require_native(s) for s in flat])
+        co = (C.c_int32 * len(offs))(*offs)
+        per = (_capi.YmResult * len(chains))()
+        best = _capi.YmResult()
+        bi = C.c_int32(-1)
+        _capi.check(self._lib.ym_match_batch(self._m, hq, hs, co, len(chains), int(bool(penalty)), int(bool(do_fine)),
+                                             per, C.byref(best), C.byref(bi)))
+        return [_result(r) for r in per], int(bi.value)
+
+    def _require_native(self, scan):
+        h = self._native(scan)
+        if h is None:
+            raise TypeError("match_scan_batch needs yag_slam_amd.models.LocalizedRangeScan instances")
+        return h
+
+    # ---- pipelined form ----------------------------------------------------------------------
+    def match_scan_async(self, query, base_scans, penalty=True, do_fine=False, slot=0):
+        hq = self._require_native(query)
+        arr = (C.c_void_p * max(1, len(base_scans)))(*[self._require_native(s) for s in base_scans])
+        _capi.check(self._lib.ym_match_scans_async(self._m, hq, arr, len(base_scans), int(bool(penalty)),
+                                                   int(bool(do_fine)), int(slot)))
+
+    def wait(self, slot=0):
+        res = _capi.YmResult()
+        _capi.check(self._lib.ym_wait(self._m, int(slot), C.byref(res)))
+        return _result(res)
+
+    def synchronize(self):
+        _capi.check(self._lib.ym_synchronize(self._m))
+
+    # ---- introspection for the parity tests --------------------------------------------------
+    def debug_grid(self, item=0):
+        info = _capi.YmGridInfo()
+        _capi.check(self._lib.ym_debug_grid_info(self._m, item, C.byref(info)))
+        buf = np.zeros((info.height, info.pitch), dtype=np.uint8)
+        _capi.check(self._lib.ym_debug_grid(self._m, item, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size))
+        return buf[:, :info.width], info
+
+    def debug_sums(self, pass_=0, item=0, dims=None):
+        nx, ny, nt = dims
+        buf = np.zeros((nt, ny, nx), dtype=np.uint32)
+        _capi.check(self._lib.ym_debug_sums(self._m, item, pass_, buf.ctypes.data_as(C.POINTER(C.c_uint32)), buf.size))
+        return buf
+
+    def debug_query_local(self, item=0, cap=8192):
+        buf = np.zeros((cap, 2))
+        n = C.c_int32()
+        _capi.check(self._lib.ym_debug_query_local(self._m, item, buf.ctypes.data_as(C.POINTER(C.c_double)), cap,
+                                                   C.byref(n)))
+        return buf[:n.value].copy()
+
+    def profile(self, on=True):
+        _capi.check(self._lib.ym_profile_enable(self._m, int(bool(on))))
+
+    def profile_read(self, which=0, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        _capi.check(self._lib.ym_profile_read(self._m, which, C.byref(ms), C.byref(n), int(bool(reset))))
+        return ms.value, n.value
+
+
+# names the reference exports (scan_matching.py:32,224)
+Scan2DMatcherCpp = ScanMatcher
+Scan2DMatcher = ScanMatcher
