@@ -69,21 +69,23 @@ struct DevBuf {
 };
 
 struct PinnedBuf {
-    unsigned char *p = nullptr;
+    unsigned char *p = nullptr;   // host address
+    unsigned char *dp = nullptr;  // the same memory as the device sees it
     size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return YM_OK;
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = dp = nullptr;
         cap = 0;
         size_t want = align_up(n + n / 4 + 256, 256);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dp), p, 0));
         cap = want;
         return YM_OK;
     }
     void release() {
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = dp = nullptr;
         cap = 0;
     }
 };
@@ -147,15 +149,17 @@ struct ym_matcher {
     std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)
     DevBuf<uint8_t> ktab;
     // workspace
-    DevBuf<unsigned char> desc;
     DevBuf<YmItemState> states;
     DevBuf<double2> qlocal;
     DevBuf<int2> cells;
-    DevBuf<int32_t> counts;
     DevBuf<uint8_t> grid;
-    DevBuf<int32_t> offsets;
+    DevBuf<int32_t> offsets;   // coarse lookup tables
+    DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
-    DevBuf<uint32_t> sums;
+    DevBuf<uint32_t> partial;  // per beam-chunk partial sums of the coarse lattice
+    DevBuf<uint32_t> sums;     // coarse sums, then fine sums
+    DevBuf<double> resp;
+    DevBuf<double> blockmax;
     DevBuf<double> probs;
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
@@ -340,29 +344,52 @@ int launch_call(ym_matcher *m, Slot &slot) {
     g.pitch = tiles_x * YM_TILE_W + 64;
     const size_t grid_stride = align_up((size_t)g.pitch * g.win_w + 64, 256);
     if ((double)g.pitch * g.win_w > 2.0e9) return set_err(YM_ERR_UNSUPPORTED, "correlation window too large");
+    if (lf.nx > 64 || lf.ny > 64 || lf.nt > 1024 || (int64_t)lf.nx * lf.ny * lf.nt > YM_MAX_FINE_HYP)
+        return set_err(YM_ERR_UNSUPPORTED, "fine lattice %dx%dx%d exceeds the built-in limit", lf.nx, lf.ny, lf.nt);
 
-    const int nt_stride = std::max(lc.nt, lf.nt);
-    const int dim_stride = std::max(std::max(lc.nx, lc.ny), std::max(lf.nx, lf.ny));
+    // ---- coarse correlate decomposition
+    const int sx = (int)kt_round_h(lc.step_x * g.scale);
+    if (sx != 1 && sx != 2) return set_err(YM_ERR_UNSUPPORTED, "coarse lattice step of %d cells", sx);
+    const int G = 16 / sx;
+    const int ngx = (lc.nx + G - 1) / G;
+    const int nx_pad = ngx * G;
+    const int njobs = lc.ny * ngx;
+    const int job_blocks = (njobs + YM_CORR_THREADS - 1) / YM_CORR_THREADS;
+    // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams
+    const double waves_one_chunk = (double)((njobs + 63) / 64) * lc.nt * B;
+    int n_chunks = (int)std::ceil(2048.0 / std::max(1.0, waves_one_chunk));
+    n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
+    n_chunks = std::max(n_chunks, (max_n + 511) / 512);
+    int chunk = (max_n + n_chunks - 1) / n_chunks;
+    chunk = (chunk + 7) / 8 * 8;
+    n_chunks = (max_n + chunk - 1) / chunk;
+
+    const int nt_stride = lc.nt;
+    const int dim_stride = std::max(lc.nx, lc.ny);
     const size_t sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     const size_t sums_f = (size_t)lf.nt * lf.ny * lf.nx;
+    const size_t partial_stride = (size_t)n_chunks * lc.nt * lc.ny * nx_pad;
+    const int score_blocks = (int)((sums_c + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS);
 
     int rc;
     if ((rc = m->states.ensure(B))) return rc;
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
-    if ((rc = m->counts.ensure((size_t)B * max_base))) return rc;
     if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
     if ((rc = m->offsets.ensure((size_t)B * nt_stride * max_n))) return rc;
+    if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
+    if ((rc = m->partial.ensure((size_t)B * partial_stride + 16))) return rc;
     if ((rc = m->sums.ensure((size_t)B * (sums_c + sums_f)))) return rc;
+    if ((rc = m->resp.ensure((size_t)B * sums_c))) return rc;
+    if ((rc = m->blockmax.ensure((size_t)B * score_blocks))) return rc;
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
 
-    // ---- descriptor blob
+    // ---- call descriptor: written into pinned host memory the kernels read directly
     const size_t scans_bytes = align_up(sizeof(YmScanRef) * nscans, 16);
     const size_t desc_bytes = scans_bytes + sizeof(YmItem) * B;
     if ((rc = slot.desc.ensure(desc_bytes))) return rc;
     if ((rc = slot.result.ensure(sizeof(YmItemState) * B))) return rc;
-    if ((rc = m->desc.ensure(desc_bytes))) return rc;
     YmScanRef *hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
     YmItem *hi = reinterpret_cast<YmItem *>(slot.desc.p + scans_bytes);
     for (int i = 0; i < nscans; i++) {
@@ -382,64 +409,66 @@ int launch_call(ym_matcher *m, Slot &slot) {
         hi[i].base_count = call.items[i].base_count;
         hi[i].pad = 0;
     }
+    const YmScanRef *d_scans = reinterpret_cast<const YmScanRef *>(slot.desc.dp);
+    const YmItem *d_items = reinterpret_cast<const YmItem *>(slot.desc.dp + scans_bytes);
     hipStream_t st = m->stream;
     hipEvent_t ev_call = nullptr, ev_k = nullptr;
     if ((rc = prof_begin(m, 2, &ev_call))) return rc;
-    HIP_TRY(hipMemcpyAsync(m->desc.p, slot.desc.p, desc_bytes, hipMemcpyHostToDevice, st));
-    const YmScanRef *d_scans = reinterpret_cast<const YmScanRef *>(m->desc.p);
-    const YmItem *d_items = reinterpret_cast<const YmItem *>(m->desc.p + scans_bytes);
 
-    // ---- K1
+    // ---- K1 prepare
     {
         ym::PrepareArgs a;
-        a.scans = d_scans; a.items = d_items; a.g = g; a.states = m->states.p; a.qlocal = m->qlocal.p;
-        a.cells = m->cells.p; a.counts = m->counts.p; a.max_n = max_n; a.max_base = max_base;
+        a.scans = d_scans; a.items = d_items; a.g = g; a.lat = lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
+        a.cells = m->cells.p; a.offsets = m->offsets.p; a.hypcell = m->hypcell.p;
+        a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride;
         const size_t lds = (size_t)max_n * 21 + 16;
-        hipLaunchKernelGGL(ym::prepare_kernel, dim3(max_base + 1, B), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(ym::prepare_kernel, dim3(max_base + 1, B), dim3(YM_PREP_THREADS), lds, st, a);
     }
-    // ---- K2
+    // ---- K2 raster
     {
         ym::RasterArgs a;
-        a.cells = m->cells.p; a.counts = m->counts.p; a.items = d_items; a.g = g; a.grid = m->grid.p;
+        a.cells = m->cells.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
         a.grid_stride = grid_stride; a.ktab = m->ktab.p; a.max_n = max_n; a.max_base = max_base;
         if ((rc = prof_begin(m, 1, &ev_k))) return rc;
-        hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
     }
-    // ---- passes
+    // ---- K4 coarse correlate
+    {
+        ym::CorrArgs a;
+        a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.offsets = m->offsets.p;
+        a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = partial_stride;
+        a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.chunk = chunk; a.n_chunks = n_chunks;
+        a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx;
+        if ((rc = prof_begin(m, 0, &ev_k))) return rc;
+        const dim3 grid_dim(job_blocks, lc.nt * n_chunks, B);
+        if (sx == 2) hipLaunchKernelGGL(ym::correlate_kernel<2>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        else hipLaunchKernelGGL(ym::correlate_kernel<1>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        if ((rc = prof_end(m, ev_k))) return rc;
+    }
+    // ---- K5a score
     m->sums_pass_offset[0] = 0;
     m->sums_pass_offset[1] = (size_t)B * sums_c;
-    for (int pass = 0; pass < (call.refine ? 2 : 1); pass++) {
-        const YmLattice &lat = pass ? lf : lc;
-        const size_t sums_stride = pass ? sums_f : sums_c;
-        uint32_t *sums = m->sums.p + m->sums_pass_offset[pass];
-        {
-            ym::OffsetsArgs a;
-            a.g = g; a.lat = lat; a.states = m->states.p; a.qlocal = m->qlocal.p; a.offsets = m->offsets.p;
-            a.hypcell = m->hypcell.p; a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride;
-            hipLaunchKernelGGL(ym::offsets_kernel, dim3((max_n + 255) / 256, lat.nt + 1, B), dim3(256), 0, st, a);
-        }
-        {
-            ym::CorrArgs a;
-            a.g = g; a.lat = lat; a.grid = m->grid.p; a.grid_stride = grid_stride; a.offsets = m->offsets.p;
-            a.hypcell = m->hypcell.p; a.states = m->states.p; a.sums = sums; a.sums_stride = sums_stride;
-            a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride;
-            ev_k = nullptr;
-            if (pass == 0 && (rc = prof_begin(m, 0, &ev_k))) return rc;
-            hipLaunchKernelGGL(ym::correlate_generic_kernel, dim3((lat.nx * lat.ny + 255) / 256, lat.nt, B),
-                               dim3(256), 0, st, a);
-            if ((rc = prof_end(m, ev_k))) return rc;
-        }
-        {
-            ym::ReduceArgs a;
-            a.g = g; a.lat = lat; a.sums = sums; a.sums_stride = sums_stride; a.states = m->states.p;
-            a.probs = m->probs.p; a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p;
-            a.grid_stride = grid_stride; a.offsets = m->offsets.p; a.max_n = max_n; a.nt_stride = nt_stride;
-            hipLaunchKernelGGL(ym::reduce_kernel, dim3(B), dim3(1024), 0, st, a);
-        }
+    {
+        ym::ScoreArgs a;
+        a.g = g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = partial_stride; a.states = m->states.p;
+        a.sums = m->sums.p; a.sums_stride = sums_c; a.resp = m->resp.p; a.blockmax = m->blockmax.p;
+        a.n_chunks = n_chunks; a.nx_pad = nx_pad; a.n_blocks = score_blocks;
+        hipLaunchKernelGGL(ym::score_kernel, dim3(score_blocks, B), dim3(YM_SCORE_THREADS), 0, st, a);
+    }
+    // ---- K6 finish (coarse tail + fine pass), results land in pinned host memory
+    {
+        ym::FinishArgs a;
+        a.g = g; a.lc = lc; a.lf = lf; a.refine = call.refine; a.max_n = max_n; a.nt_stride = lf.nt;
+        a.n_blocks = score_blocks; a.states = m->states.p;
+        a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
+        a.resp = m->resp.p; a.sums_stride = sums_c; a.blockmax = m->blockmax.p; a.probs = m->probs.p;
+        a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = grid_stride;
+        a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
+        a.fsums_stride = sums_f;
+        hipLaunchKernelGGL(ym::finish_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(slot.result.p, m->states.p, sizeof(YmItemState) * B, hipMemcpyDeviceToHost, st));
     if ((rc = prof_end(m, ev_call))) return rc;
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(slot.done, st));
@@ -622,9 +651,10 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc.release(); m->states.release(); m->qlocal.release(); m->cells.release();
-    m->counts.release(); m->grid.release(); m->offsets.release(); m->hypcell.release(); m->sums.release();
-    m->probs.release(); m->tmp_ranges.release(); m->tmp_ranges_host.release();
+    m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->grid.release();
+    m->offsets.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
+    m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
+    m->tmp_ranges_host.release();
     for (Slot &s : m->slots) {
         s.desc.release();
         s.result.release();
@@ -896,15 +926,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
     if ((size_t)out_count < per * 2) return set_err(YM_ERR_INVALID, "buffer too small: need %zu ints", per * 2);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    std::vector<int32_t> counts(m->last_max_base);
-    HIP_TRY(hipMemcpy(counts.data(), m->counts.p + (size_t)item * m->last_max_base, sizeof(int32_t) * m->last_max_base,
-                      hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out, m->cells.p + (size_t)item * per, sizeof(int2) * per, hipMemcpyDeviceToHost));
-    for (int s = 0; s < m->last_max_base; s++)
-        for (int i = counts[s]; i < m->last_max_n; i++) {
-            out[((size_t)s * m->last_max_n + i) * 2] = INT32_MIN;
-            out[((size_t)s * m->last_max_n + i) * 2 + 1] = INT32_MIN;
-        }
     return YM_OK;
 }
 

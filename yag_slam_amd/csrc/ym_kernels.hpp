@@ -1,14 +1,17 @@
 // ym_kernels.hpp -- gfx950 kernels of the correlative scan matcher (karto semantics).
 //
-// Pipeline of one call (B independent items, one item = one query scan vs one chain of base scans):
-//   prepare_kernel   point readings, valid-point filter, grid cells        (Karto LocalizedRangeScan::Update,
-//                                                                           ScanMatcher::FindValidPoints, AddScan)
-//   raster_kernel    correlation-grid window with the Gaussian max-smear   (AddScans + CorrelationGrid::SmearPoint)
-//   offsets_kernel   per-angle cell-offset table + hypothesis cells        (GridIndexLookup::ComputeOffsets)
-//   correlate_*      integer gather-reduce over the (x, y, theta) lattice  (CorrelateScan loops + GetResponse)
-//   reduce_kernel    response, penalty, arg-max, tie mean, covariances     (CorrelateScan tail,
-//                                                                           ComputePositionalCovariance,
-//                                                                           ComputeAngularCovariance)
+// Pipeline of one call (B independent items; one item = one query scan vs one chain of base scans):
+//   prepare_kernel    point readings, valid-point filter, grid cells, coarse lookup table
+//                     (Karto LocalizedRangeScan::Update, ScanMatcher::FindValidPoints, AddScan,
+//                      GridIndexLookup::ComputeOffsets)
+//   raster_kernel     correlation-grid window with the Gaussian max-smear
+//                     (ScanMatcher::AddScans + CorrelationGrid::SmearPoint)
+//   correlate_kernel  integer gather-reduce over the coarse (x, y, theta) lattice, split over beam
+//                     chunks into partial sums (CorrelateScan loops + GetResponse)
+//   score_kernel      partial sums -> sums -> response (+ penalty), per-block maxima
+//   finish_kernel     coarse arg-max / tie mean / positional covariance, then the whole fine pass
+//                     (offsets, 3x3xN correlate, arg-max, angular covariance) in one block per item
+//                     (CorrelateScan tail, ComputePositionalCovariance, ComputeAngularCovariance)
 // All fp64 arithmetic is written operation-for-operation like oracle/ym_oracle.c and the library is
 // compiled with -ffp-contract=off, so responses are bit-identical to the oracle's.
 #pragma once
@@ -44,7 +47,7 @@ __device__ __forceinline__ int world_to_grid(double w, double off, double scale)
     return (int)kt_round((w - off) * scale);
 }
 
-// ------------------------------------------------------------------ block helpers (256 or 1024 threads)
+// ------------------------------------------------------------------ block helpers
 // exclusive prefix position of `flag` inside the block + block total; wave = 64 lanes
 __device__ __forceinline__ int block_scan_flag(bool flag, int *total, int *wave_counts) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -86,32 +89,49 @@ struct OpAddD { __device__ double operator()(double a, double b) const { return 
 struct OpAddU { __device__ unsigned operator()(unsigned a, unsigned b) const { return a + b; } };
 struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
 
+// GridIndexLookup::ComputeOffsets for one angle and one point -> window-linear offset
+__device__ __forceinline__ int lookup_offset(double2 p, double cosine, double sine, double off_x, double off_y,
+                                             double scale, int pitch) {
+    const double ox = cosine * p.x - sine * p.y;
+    const double oy = sine * p.x + cosine * p.y;
+    const int gx = world_to_grid(ox + off_x, off_x, scale);
+    const int gy = world_to_grid(oy + off_y, off_y, scale);
+    return gx + gy * pitch;
+}
+
+// hypothesis cells of one lattice axis: WorldToGrid(centre + (start + i*step)), window coordinates
+__device__ __forceinline__ int hyp_cell(double centre, double start, int i, double step, double off, const YmGeom &g) {
+    const double v = start + i * step;
+    return world_to_grid(centre + v, off, g.scale) + g.border - g.win_origin;
+}
+
 // ================================================================== K1 prepare
+#define YM_PREP_THREADS 1024
 struct PrepareArgs {
-    const YmScanRef *scans;
+    const YmScanRef *scans;  // pinned host memory (device-mapped) or device memory
     const YmItem *items;
     YmGeom g;
+    YmLattice lat;           // coarse lattice
     YmItemState *states;
-    double2 *qlocal;   // [B][max_n]
-    int2 *cells;       // [B][max_base][max_n]  window cell of every compacted base point (or NONE)
-    int32_t *counts;   // [B][max_base]         compacted point count per base slot
-    int32_t max_n, max_base;
+    double2 *qlocal;         // [B][max_n]
+    int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
+    int32_t *offsets;        // [B][nt_stride][max_n] coarse lookup table
+    int32_t *hypcell;        // [B][2][dim_stride]
+    int32_t max_n, max_base, nt_stride, dim_stride;
 };
 
-// grid (max_base + 1, B), 256 threads, dynamic LDS = max_n * 21 bytes
+// grid (max_base + 1, B), 1024 threads, dynamic LDS = max_n * 21 bytes
 // blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.
-__global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs a) {
+__global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ int wave_counts[4];
+    __shared__ int wave_counts[YM_PREP_THREADS / 64];
+    constexpr int NT = YM_PREP_THREADS;
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const YmItem it = a.items[b];
     const bool is_query = blockIdx.x == 0;
     const int slot = (int)blockIdx.x - 1;
-    if (!is_query && slot >= it.base_count) {
-        if (tid == 0) a.counts[(size_t)b * a.max_base + slot] = 0;
-        return;
-    }
+    if (!is_query && slot >= it.base_count) return;
     const YmScanRef sr = a.scans[is_query ? it.query : it.base_begin + slot];
     const YmScanRef qr = a.scans[it.query];
     double *sx = reinterpret_cast<double *>(lds_raw);
@@ -125,7 +145,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs a) {
     const double py = (is_query && yag) ? 0.0 : sr.pose[1];
     const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
     int running = 0;
-    for (int c0 = 0; c0 < sr.n; c0 += 256) {
+    for (int c0 = 0; c0 < sr.n; c0 += NT) {
         const int i = c0 + tid;
         double r = 0.0;
         bool ok = false;
@@ -144,28 +164,62 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs a) {
     }
     const int np = running;
     __syncthreads();
+    // world offset of ROI cell (0,0): MatchScan, "set scan pose to be center of grid"
+    const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
 
     if (is_query) {
         if (tid == 0) {
             YmItemState &st = a.states[b];
             st.pose[0] = sr.pose[0]; st.pose[1] = sr.pose[1]; st.pose[2] = sr.pose[2];
             st.center[0] = sr.pose[0]; st.center[1] = sr.pose[1]; st.center[2] = sr.pose[2];
-            st.off_x = sr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
-            st.off_y = sr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+            st.off_x = off_x;
+            st.off_y = off_y;
             st.nq = np;
             st.status = 0;
             st.regular[0] = st.regular[1] = 0;
+            st.base_count = it.base_count;
         }
         // sensor-frame coordinates (karto: Transform(pose).InverseTransformPose; yagpy: points_local)
         double2 *ql = a.qlocal + (size_t)b * a.max_n;
-        if (yag || (sr.pose[0] == 0.0 && sr.pose[1] == 0.0 && sr.pose[2] == 0.0)) {
-            for (int i = tid; i < np; i += 256) ql[i] = make_double2(sx[i], sy[i]);
-        } else {
-            const double cr = cos(0.0 - sr.pose[2]), sn = sin(0.0 - sr.pose[2]);
-            for (int i = tid; i < np; i += 256) {
+        const bool identity = yag || (sr.pose[0] == 0.0 && sr.pose[1] == 0.0 && sr.pose[2] == 0.0);
+        const double cr = cos(0.0 - sr.pose[2]), sn = sin(0.0 - sr.pose[2]);
+        __syncthreads();
+        for (int i = tid; i < np; i += NT) {
+            double2 l;
+            if (identity) {
+                l = make_double2(sx[i], sy[i]);
+            } else {
                 const double dx = sx[i] - sr.pose[0], dy = sy[i] - sr.pose[1];
-                ql[i] = make_double2(cr * dx + (0.0 - sn) * dy, sn * dx + cr * dy);
+                l = make_double2(cr * dx + (0.0 - sn) * dy, sn * dx + cr * dy);
             }
+            ql[i] = l;
+            sx[i] = l.x; // keep the local points in LDS for the lookup table below
+            sy[i] = l.y;
+        }
+        __syncthreads();
+        // coarse lookup table (GridIndexLookup::ComputeOffsets), centre heading = query heading
+        const double start_angle = sr.pose[2] - a.lat.angle_off;
+        int32_t *offs = a.offsets + (size_t)b * a.nt_stride * a.max_n;
+        for (int k = 0; k < a.lat.nt; k++) {
+            const double angle = start_angle + k * a.lat.angle_res;
+            const double cosine = cos(angle), sine = sin(angle);
+            for (int i = tid; i < np; i += NT)
+                offs[(size_t)k * a.max_n + i] =
+                    lookup_offset(make_double2(sx[i], sy[i]), cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+        }
+        // coarse hypothesis cells + regularity flag
+        int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+        int32_t *cy = cx + a.dim_stride;
+        for (int i = tid; i < a.lat.nx; i += NT) cx[i] = hyp_cell(sr.pose[0], -a.lat.off_x, i, a.lat.step_x, off_x, a.g);
+        for (int i = tid; i < a.lat.ny; i += NT) cy[i] = hyp_cell(sr.pose[1], -a.lat.off_y, i, a.lat.step_y, off_y, a.g);
+        __syncthreads();
+        if (tid == 0) {
+            const int stx = (int)kt_round(a.lat.step_x * a.g.scale), sty = (int)kt_round(a.lat.step_y * a.g.scale);
+            int reg = 1;
+            for (int i = 1; i < a.lat.nx; i++) reg &= (cx[i] == cx[0] + i * stx);
+            for (int i = 1; i < a.lat.ny; i++) reg &= (cy[i] == cy[0] + i * sty);
+            a.states[b].regular[0] = reg;
         }
         return;
     }
@@ -175,7 +229,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs a) {
     // the run that ends at chain node t = nxt[s] is kept or dropped by the sign of ss(s, t).
     const double min_sq = yag ? 0.2 * 0.2 : 0.1 * 0.1;
     const double vpx = qr.pose[0], vpy = qr.pose[1];
-    for (int i = tid; i < np; i += 256) {
+    for (int i = tid; i < np; i += NT) {
         const double fx = sx[i], fy = sy[i];
         int j = i + 1;
         for (; j < np; j++) {
@@ -186,54 +240,65 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs a) {
         chain[i] = 0;
     }
     __syncthreads();
-    if (tid == 0) {
-        for (int i = 0; i < np; i = nxt[i]) chain[i] = 1;
-        a.counts[(size_t)b * a.max_base + slot] = np;
+    if (tid < 64) {
+        // One wave walks the chain.  The window nxt[base .. base+64) sits in one VGPR; hops inside
+        // the window are v_readlane with a scalar lane index instead of dependent LDS reads.
+        int cur = 0;
+        while (cur < np) {
+            const int base = cur;
+            const int idx = base + tid;
+            const int v = idx < np ? nxt[idx] : np;
+            unsigned long long mask = 0ull;
+            while (cur < base + 64 && cur < np) {
+                mask |= 1ull << (cur - base);
+                cur = __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(cur - base));
+            }
+            if (idx < np && ((mask >> tid) & 1ull)) chain[idx] = 1;
+        }
     }
     __syncthreads();
-    // world offset of ROI cell (0,0): same expression the query block stores
-    const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
-    const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
-    for (int i = tid; i < np; i += 256) {
-        bool keep = false;
-        int s = yag ? i - 1 : i;
-        if (s >= 0) {
-            while (!chain[s]) s--;
-            const int t = nxt[s];
-            if (t < np) {
-                const double fx = sx[s], fy = sy[s], cx = sx[t], cy = sy[t];
-                const double aa = vpy - fy;
-                const double bb = fx - vpx;
-                const double cc = fy * vpx - fx * vpy;
-                const double ss = cx * aa + cy * bb + cc;
-                keep = yag ? (ss > 0.0) : !(ss < 0.0);
-            }
-        }
+    for (int i = tid; i < a.max_n; i += NT) {
         int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
-        if (keep) {
-            int gx, gy;
-            if (yag) {
-                gx = (int)rint((sx[i] - off_x) / a.g.res);
-                gy = (int)rint((sy[i] - off_y) / a.g.res);
-            } else {
-                gx = world_to_grid(sx[i], off_x, a.g.scale);
-                gy = world_to_grid(sy[i], off_y, a.g.scale);
+        if (i < np) {
+            bool keep = false;
+            int s = yag ? i - 1 : i;
+            if (s >= 0) {
+                while (!chain[s]) s--;
+                const int t = nxt[s];
+                if (t < np) {
+                    const double fx = sx[s], fy = sy[s], cx = sx[t], cy = sy[t];
+                    const double aa = vpy - fy;
+                    const double bb = fx - vpx;
+                    const double cc = fy * vpx - fx * vpy;
+                    const double ss = cx * aa + cy * bb + cc;
+                    keep = yag ? (ss > 0.0) : !(ss < 0.0);
+                }
             }
-            if (gx >= 0 && gx < a.g.roi_w && gy >= 0 && gy < a.g.roi_w)
-                c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
+            if (keep) {
+                int gx, gy;
+                if (yag) {
+                    gx = (int)rint((sx[i] - off_x) / a.g.res);
+                    gy = (int)rint((sy[i] - off_y) / a.g.res);
+                } else {
+                    gx = world_to_grid(sx[i], off_x, a.g.scale);
+                    gy = world_to_grid(sy[i], off_y, a.g.scale);
+                }
+                if (gx >= 0 && gx < a.g.roi_w && gy >= 0 && gy < a.g.roi_w)
+                    c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
+            }
         }
         cells[i] = c;
     }
 }
 
 // ================================================================== K2 raster
-#define YM_TILE_W 64
-#define YM_TILE_H 16
+#define YM_TILE_W 128
+#define YM_TILE_H 64
+#define YM_RASTER_THREADS 1024
 struct RasterArgs {
     const int2 *cells;
-    const int32_t *counts;
-    const YmItem *items;
+    const YmItemState *states;
     YmGeom g;
     uint8_t *grid;        // [B][win_w rows][pitch]
     size_t grid_stride;   // bytes per item
@@ -241,14 +306,14 @@ struct RasterArgs {
     int32_t max_n, max_base;
 };
 
-// grid (tiles_x, tiles_y, B), 256 threads.  Each block owns one 64x16 tile of the window and writes
-// every byte of it exactly once (so no separate clear pass exists).  The max-stamp of Karto's
-// SmearPoint over a set of occupied cells equals, per cell, the kernel value at the nearest occupied
-// cell inside the (2h+1)^2 window; with a radially monotone kernel that is
+// grid (tiles_x, tiles_y, B), 1024 threads.  Each block owns one 128x64 tile of the window and
+// writes every byte of it exactly once (so no separate clear pass exists).  The max-stamp of
+// Karto's SmearPoint over a set of occupied cells equals, per cell, the kernel value at the
+// nearest occupied cell inside the (2h+1)^2 window; with a radially monotone kernel that is
 //   max_dy ktab[|dy|][ min |dx| of an occupied cell in row y+dy within h ],
 // computed as a row pass followed by a column pass in LDS.
-__global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
-    constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF;
+__global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a) {
+    constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF, NT = YM_RASTER_THREADS;
     __shared__ unsigned char occ[(TH + 2 * HM) * (TW + 2 * HM)];
     __shared__ unsigned char grow[(TH + 2 * HM) * TW];
     __shared__ unsigned char kt[(HM + 1) * (HM + 1)];
@@ -257,33 +322,33 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
     const int h = a.g.half_kernel;
     const int OW = TW + 2 * h, OH = TH + 2 * h;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    for (int i = tid; i < OW * OH; i += 256) occ[i] = 0;
-    for (int i = tid; i < (h + 1) * (h + 1); i += 256) kt[i] = a.ktab[i];
+    for (int i = tid; i < (OW * OH + 3) / 4; i += NT) reinterpret_cast<uint32_t *>(occ)[i] = 0u;
+    for (int i = tid; i < (h + 1) * (h + 1); i += NT) kt[i] = a.ktab[i];
     __syncthreads();
-    const int nb = a.items[b].base_count;
+    const int total = a.states[b].base_count * a.max_n;
+    const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     int any = 0;
-    for (int s = 0; s < nb; s++) {
-        const int cnt = a.counts[(size_t)b * a.max_base + s];
-        const int2 *cells = a.cells + ((size_t)b * a.max_base + s) * a.max_n;
-        for (int i = tid; i < cnt; i += 256) {
-            const int2 c = cells[i];
-            const int lx = c.x - (tx0 - h), ly = c.y - (ty0 - h);
-            if (c.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
-                occ[ly * OW + lx] = 1;
-                any = 1;
-            }
+#pragma unroll 4
+    for (int i = tid; i < total; i += NT) {
+        const int2 c = cells[i];
+        const int lx = c.x - (tx0 - h), ly = c.y - (ty0 - h);
+        if (c.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+            occ[ly * OW + lx] = 1;
+            any = 1;
         }
     }
     any = __syncthreads_or(any);
     uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
-    const int y = tid >> 4, x4 = (tid & 15) * 4;
-    const bool row_ok = (ty0 + y) < a.g.win_w && (tx0 + x4) < a.g.pitch;
+    // thread -> 8 consecutive cells of one tile row
+    const int y = tid >> 4, x8 = (tid & 15) * 8;
+    const bool row_ok = (ty0 + y) < a.g.win_w;
+    uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
     if (!any) {
-        if (row_ok) *reinterpret_cast<uint32_t *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x4) = 0u;
+        if (row_ok) *dst = make_uint2(0u, 0u);
         return;
     }
     // row pass: nearest occupied |dx| <= h, 255 = none
-    for (int i = tid; i < OH * TW; i += 256) {
+    for (int i = tid; i < OH * TW; i += NT) {
         const int ry = i / TW, rx = i % TW;
         const unsigned char *row = occ + ry * OW + rx + h;
         int best = 255;
@@ -292,10 +357,10 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
         grow[i] = (unsigned char)best;
     }
     __syncthreads();
-    uint32_t packed = 0;
+    uint32_t packed[2] = {0u, 0u};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int x = x4 + q;
+    for (int q = 0; q < 8; q++) {
+        const int x = x8 + q;
         int v = 0;
         for (int dy = -h; dy <= h; dy++) {
             const int d = grow[(y + h + dy) * TW + x];
@@ -304,65 +369,13 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterArgs a) {
                 v = k > v ? k : v;
             }
         }
-        packed |= (uint32_t)v << (8 * q);
+        packed[q >> 2] |= (uint32_t)v << (8 * (q & 3));
     }
-    if (row_ok) *reinterpret_cast<uint32_t *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x4) = packed;
+    if (row_ok) *dst = make_uint2(packed[0], packed[1]);
 }
 
-// ================================================================== K3 offsets + hypothesis cells
-struct OffsetsArgs {
-    YmGeom g;
-    YmLattice lat;
-    YmItemState *states;
-    const double2 *qlocal;
-    int32_t *offsets;  // [B][nt_stride][max_n]  window-linear cell offsets per angle
-    int32_t *hypcell;  // [B][2][dim_stride]     window x cells (ix) then window y cells (iy)
-    int32_t max_n, nt_stride, dim_stride;
-};
-
-// grid (ceil(max_n / 256), nt + 1, B); blockIdx.y == nt computes the hypothesis cells.
-__global__ __launch_bounds__(256) void offsets_kernel(OffsetsArgs a) {
-    const int b = blockIdx.z;
-    const YmItemState &st = a.states[b];
-    const int k = blockIdx.y;
-    if (k == a.lat.nt) {
-        if (blockIdx.x != 0) return;
-        // CorrelateScan: gridPoint = WorldToGrid(centre + (x, y)), per axis
-        int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
-        int32_t *cy = cx + a.dim_stride;
-        const double start_x = -a.lat.off_x, start_y = -a.lat.off_y;
-        for (int i = threadIdx.x; i < a.lat.nx; i += 256) {
-            const double x = start_x + i * a.lat.step_x;
-            cx[i] = world_to_grid(st.center[0] + x, st.off_x, a.g.scale) + a.g.border - a.g.win_origin;
-        }
-        for (int i = threadIdx.x; i < a.lat.ny; i += 256) {
-            const double y = start_y + i * a.lat.step_y;
-            cy[i] = world_to_grid(st.center[1] + y, st.off_y, a.g.scale) + a.g.border - a.g.win_origin;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int sx = (int)kt_round(a.lat.step_x * a.g.scale), sy = (int)kt_round(a.lat.step_y * a.g.scale);
-            int reg = 1;
-            for (int i = 1; i < a.lat.nx; i++) reg &= (cx[i] == cx[0] + i * sx);
-            for (int i = 1; i < a.lat.ny; i++) reg &= (cy[i] == cy[0] + i * sy);
-            a.states[b].regular[a.lat.fine] = reg;
-        }
-        return;
-    }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= st.nq) return;
-    const double start_angle = st.center[2] - a.lat.angle_off;
-    const double angle = start_angle + k * a.lat.angle_res;
-    const double cosine = cos(angle), sine = sin(angle);
-    const double2 p = a.qlocal[(size_t)b * a.max_n + i];
-    const double ox = cosine * p.x - sine * p.y;
-    const double oy = sine * p.x + cosine * p.y;
-    const int gx = world_to_grid(ox + st.off_x, st.off_x, a.g.scale);
-    const int gy = world_to_grid(oy + st.off_y, st.off_y, a.g.scale);
-    a.offsets[((size_t)b * a.nt_stride + k) * a.max_n + i] = gx + gy * a.g.pitch;
-}
-
-// ================================================================== K4 correlate (generic path)
+// ================================================================== K4 correlate (coarse lattice)
+#define YM_CORR_THREADS 256
 struct CorrArgs {
     YmGeom g;
     YmLattice lat;
@@ -371,165 +384,256 @@ struct CorrArgs {
     const int32_t *offsets;
     const int32_t *hypcell;
     const YmItemState *states;
-    uint32_t *sums;     // [B][nt][ny][nx]
-    size_t sums_stride; // per item
+    uint32_t *partial;     // [B][n_chunks][nt][ny][nx_pad]
+    size_t partial_stride; // per item
     int32_t max_n, nt_stride, dim_stride;
+    int32_t chunk;         // beams per chunk (<= 512 keeps the 16-bit lanes from overflowing)
+    int32_t n_chunks;
+    int32_t ngx;           // x groups per row = ceil(nx / G)
+    int32_t nx_pad;        // ngx * G
+    int32_t sx;            // cell stride between x-adjacent hypotheses (1 or 2)
 };
 
-// One thread per hypothesis, x fastest so a wave reads one short row segment per beam.
-// grid (ceil(nx*ny / 256), nt, B).  ScanMatcher::GetResponse, integer part.
-__global__ __launch_bounds__(256) void correlate_generic_kernel(CorrArgs a) {
-    const int b = blockIdx.z, k = blockIdx.y;
-    const int h = blockIdx.x * 256 + threadIdx.x;
-    const int nxy = a.lat.nx * a.lat.ny;
-    if (h >= nxy) return;
-    const int iy = h / a.lat.nx, ix = h - iy * a.lat.nx;
+// Lane job = G x-adjacent hypotheses of one lattice row for one angle: G = 8 when the lattice
+// steps 2 cells (coarse search), 16 when it steps 1.  For every beam of its chunk the lane loads
+// the 16 grid bytes that hold those hypotheses' cells (row segment start + wave-uniform beam
+// offset) and accumulates them in 16-bit lanes.  No cross-lane reduction; partial sums per beam
+// chunk are added up by score_kernel.  grid (ceil(ny*ngx / 256), nt * n_chunks, B).
+template <int SX>
+__global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
+    constexpr int G = 16 / SX;      // hypotheses per lane
+    constexpr int NACC = 4 * (SX == 1 ? 2 : 1);
+    const int b = blockIdx.z;
+    const int k = blockIdx.y % a.lat.nt, chunk = blockIdx.y / a.lat.nt;
+    const int job = blockIdx.x * YM_CORR_THREADS + threadIdx.x;
+    const int njobs = a.lat.ny * a.ngx;
+    if (job >= njobs) return;
+    const int iy = job / a.ngx, xg = job - iy * a.ngx;
+    const YmItemState &st = a.states[b];
+    const int nq = st.nq;
+    const int i0 = chunk * a.chunk;
+    const int i1 = min(nq, i0 + a.chunk);
     const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
     const int32_t *cy = cx + a.dim_stride;
-    const int base = cy[iy] * a.g.pitch + cx[ix];
-    const int nq = a.states[b].nq;
-    const int32_t *__restrict__ offs = a.offsets + ((size_t)b * a.nt_stride + k) * a.max_n;
     const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
-    const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
-    unsigned sum = 0;
-    int i = 0;
-    for (; i + 8 <= nq; i += 8) {
-        unsigned v[8];
+    const int32_t *__restrict__ offs = a.offsets + ((size_t)b * a.nt_stride + k) * a.max_n;
+    uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+                    (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
+
+    if (st.regular[0]) {
+        const uint32_t lane_off = (uint32_t)(cy[iy] * a.g.pitch + cx[0] + xg * G * SX);
+        uint32_t acc[NACC];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const unsigned idx = (unsigned)(base + offs[i + u]);
-            v[u] = idx < limit ? grid[idx] : 0u;
+        for (int j = 0; j < NACC; j++) acc[j] = 0u;
+#pragma unroll 8
+        for (int i = i0; i < i1; i++) {
+            uint4 w;
+            __builtin_memcpy(&w, grid + (uint32_t)(lane_off + (uint32_t)offs[i]), 16);
+            if (SX == 2) {
+                acc[0] += w.x & 0x00FF00FFu; acc[1] += w.y & 0x00FF00FFu;
+                acc[2] += w.z & 0x00FF00FFu; acc[3] += w.w & 0x00FF00FFu;
+            } else {
+                acc[0] += w.x & 0x00FF00FFu; acc[1] += (w.x >> 8) & 0x00FF00FFu;
+                acc[2] += w.y & 0x00FF00FFu; acc[3] += (w.y >> 8) & 0x00FF00FFu;
+                acc[4] += w.z & 0x00FF00FFu; acc[5] += (w.z >> 8) & 0x00FF00FFu;
+                acc[6] += w.w & 0x00FF00FFu; acc[7] += (w.w >> 8) & 0x00FF00FFu;
+            }
+        }
+        uint32_t r[G];
+        if (SX == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { r[2 * j] = acc[j] & 0xFFFFu; r[2 * j + 1] = acc[j] >> 16; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
+                r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) sum += v[u];
+        for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+    } else {
+        // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
+        const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+        for (int j = 0; j < G; j++) {
+            const int ix = xg * G + j;
+            unsigned sum = 0;
+            if (ix < a.lat.nx) {
+                const int base = cy[iy] * a.g.pitch + cx[ix];
+                for (int i = i0; i < i1; i++) {
+                    const unsigned idx = (unsigned)(base + offs[i]);
+                    sum += idx < limit ? grid[idx] : 0u;
+                }
+            }
+            out[j] = sum;
+        }
     }
-    for (; i < nq; i++) {
-        const unsigned idx = (unsigned)(base + offs[i]);
-        sum += idx < limit ? grid[idx] : 0u;
-    }
-    a.sums[(size_t)b * a.sums_stride + ((size_t)k * a.lat.ny + iy) * a.lat.nx + ix] = sum;
 }
 
-// ================================================================== K5 reduce
-struct ReduceArgs {
+// ================================================================== K5a score
+#define YM_SCORE_THREADS 256
+struct ScoreArgs {
     YmGeom g;
     YmLattice lat;
-    const uint32_t *sums;
+    const uint32_t *partial;
+    size_t partial_stride;
+    const YmItemState *states;
+    uint32_t *sums;       // [B][nt][ny][nx]
     size_t sums_stride;
-    YmItemState *states;
-    double *probs;        // [B][ny*nx] scratch: max over theta per (x, y)   (m_pSearchSpaceProbs)
-    size_t probs_stride;
-    const uint8_t *grid;
-    size_t grid_stride;
-    const int32_t *offsets;
-    int32_t max_n, nt_stride;
+    double *resp;         // [B][nt][ny][nx]
+    double *blockmax;     // [B][n_blocks]
+    int32_t n_chunks, nx_pad, n_blocks;
 };
 
-__device__ __forceinline__ double hyp_response(const ReduceArgs &a, unsigned sum, int nq, double sq_dist,
+__device__ __forceinline__ double hyp_response(const YmGeom &g, int penalize, unsigned sum, int nq, double sq_dist,
                                                double angle, double center_t) {
     double response = 0.0;
     if (nq != 0) {
         response = (double)sum;
         response /= (double)(nq * YM_OCCUPIED);
     }
-    if (a.lat.penalize && !kt_double_equal(response, 0.0)) {
-        double dp = 1.0 - (YM_PENALTY_GAIN * sq_dist / a.g.dist_var);
-        dp = dp > a.g.min_dist_pen ? dp : a.g.min_dist_pen;
+    if (penalize && !kt_double_equal(response, 0.0)) {
+        double dp = 1.0 - (YM_PENALTY_GAIN * sq_dist / g.dist_var);
+        dp = dp > g.min_dist_pen ? dp : g.min_dist_pen;
         const double sq_ang = (angle - center_t) * (angle - center_t);
-        double ap = 1.0 - (YM_PENALTY_GAIN * sq_ang / a.g.ang_var);
-        ap = ap > a.g.min_ang_pen ? ap : a.g.min_ang_pen;
+        double ap = 1.0 - (YM_PENALTY_GAIN * sq_ang / g.ang_var);
+        ap = ap > g.min_ang_pen ? ap : g.min_ang_pen;
         response *= (dp * ap);
     }
     return response;
 }
 
-// grid (B), 1024 threads.
-__global__ __launch_bounds__(1024) void reduce_kernel(ReduceArgs a) {
+// one thread per coarse hypothesis: add the beam-chunk partials, normalise, penalise.
+// grid (n_blocks, B)
+__global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     __shared__ double scratch[16];
-    __shared__ unsigned uscratch[16];
+    const int b = blockIdx.y;
+    const YmItemState &st = a.states[b];
+    const int nx = a.lat.nx, ny = a.lat.ny, nt = a.lat.nt, nxy = nx * ny;
+    const int h = blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
+    double r = -1.0;
+    if (h < nxy * nt) {
+        const int k = h / nxy, c = h - k * nxy;
+        const int iy = c / nx, ix = c - iy * nx;
+        const uint32_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
+        const size_t cstride = (size_t)nt * ny * a.nx_pad;
+        unsigned sum = 0;
+        for (int c2 = 0; c2 < a.n_chunks; c2++) sum += p[(size_t)c2 * cstride];
+        const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
+        const double ct = st.center[2];
+        const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
+        r = hyp_response(a.g, a.lat.penalize, sum, st.nq, x * x + y * y, angle, ct);
+        a.sums[(size_t)b * a.sums_stride + h] = sum;
+        a.resp[(size_t)b * a.sums_stride + h] = r;
+    }
+    const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
+    if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + blockIdx.x] = m;
+}
+
+// ================================================================== K6 finish
+#define YM_FINISH_THREADS 1024
+#define YM_MAX_FINE_HYP 4096
+struct FinishArgs {
+    YmGeom g;
+    YmLattice lc, lf;
+    int32_t refine;
+    int32_t max_n, nt_stride, n_blocks;
+    YmItemState *states;
+    YmItemState *host_out;    // pinned host memory, written directly (nullable)
+    const double *resp;       // coarse responses [B][nt][ny][nx]
+    size_t sums_stride;
+    const double *blockmax;
+    double *probs;            // [B][ny*nx] scratch: max over theta per (x, y)  (m_pSearchSpaceProbs)
+    size_t probs_stride;
+    const uint8_t *grid;
+    size_t grid_stride;
+    const double2 *qlocal;
+    int32_t *foffsets;        // [B][nt_f][max_n] fine lookup table (scratch)
+    uint32_t *fsums;          // [B][nt_f*ny_f*nx_f] fine sums (kept for parity tests)
+    size_t fsums_stride;
+};
+
+// grid (B), 1024 threads: everything after the coarse responses, one block per item.
+__global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a) {
+    constexpr int NT = YM_FINISH_THREADS;
+    __shared__ double scratch[16];
+    __shared__ int iscratch[16];
+    __shared__ unsigned s_fsum[YM_MAX_FINE_HYP];
+    __shared__ double s_fresp[YM_MAX_FINE_HYP];
+    __shared__ int s_cx[64], s_cy[64];
+    __shared__ unsigned s_asum[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     YmItemState &st = a.states[b];
-    const int nx = a.lat.nx, ny = a.lat.ny, nt = a.lat.nt, nxy = nx * ny;
     const int nq = st.nq;
-    const double cxw = st.center[0], cyw = st.center[1], ct = st.center[2];
-    const double start_x = -a.lat.off_x, start_y = -a.lat.off_y;
-    const double start_angle = ct - a.lat.angle_off;
-    const uint32_t *sums = a.sums + (size_t)b * a.sums_stride;
-    double *probs = a.probs + (size_t)b * a.probs_stride;
-
     if (nq == 0) {
         // MatchScan: "scan has no readings; cannot do scan matching" -> pose, maximum covariance, 0
-        if (tid == 0 && !a.lat.fine) {
+        if (tid == 0) {
             for (int i = 0; i < 9; i++) st.cov[i] = 0.0;
             st.cov[0] = YM_MAX_VARIANCE; st.cov[4] = YM_MAX_VARIANCE;
-            st.cov[8] = 4 * (a.lat.angle_res * a.lat.angle_res);
+            st.cov[8] = 4 * (a.lc.angle_res * a.lc.angle_res);
             for (int i = 0; i < 3; i++) { st.mean[i] = st.pose[i]; st.center[i] = st.pose[i]; }
             st.response = 0.0;
-            st.coarse_response = 1.0; // not a "zero response" in the expansion sense: nothing to retry
+            st.coarse_response = 1.0; // nothing to retry with a wider angle
+            if (a.host_out) a.host_out[b] = st;
         }
         return;
     }
+    const uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
+    const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+    double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double mean[3] = {0, 0, 0};
+    int status = 0;
+    double best;
 
-    // pass A: best response; per-(x,y) max over theta
-    double lbest = -1.0;
-    for (int c = tid; c < nxy; c += 1024) {
-        const int iy = c / nx, ix = c - iy * nx;
-        const double x = start_x + ix * a.lat.step_x, y = start_y + iy * a.lat.step_y;
-        const double sq = x * x + y * y;
-        double cm = -1.0;
-        for (int k = 0; k < nt; k++) {
-            const double angle = start_angle + k * a.lat.angle_res;
-            const double r = hyp_response(a, sums[(size_t)k * nxy + c], nq, sq, angle, ct);
-            cm = r > cm ? r : cm;
-        }
-        probs[c] = cm > 0.0 ? cm : 0.0; // the probability grid starts cleared to 0
-        lbest = cm > lbest ? cm : lbest;
-    }
-    const double best = block_reduce(lbest, OpMaxD(), -1.0, scratch);
-
-    // pass B: mean of all hypotheses with DoubleEqual(response, best)
-    double ax = 0, ay = 0, tx = 0, ty = 0;
-    int cnt = 0;
-    for (int c = tid; c < nxy; c += 1024) {
-        const int iy = c / nx, ix = c - iy * nx;
-        const double x = start_x + ix * a.lat.step_x, y = start_y + iy * a.lat.step_y;
-        const double sq = x * x + y * y;
-        for (int k = 0; k < nt; k++) {
-            const double angle = start_angle + k * a.lat.angle_res;
-            const double r = hyp_response(a, sums[(size_t)k * nxy + c], nq, sq, angle, ct);
+    // ------------------------------------------------------------- coarse tail
+    {
+        const YmLattice &L = a.lc;
+        const int nx = L.nx, ny = L.ny, nt = L.nt, nxy = nx * ny, nh = nxy * nt;
+        const double cxw = st.pose[0], cyw = st.pose[1], ct = st.pose[2];
+        const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
+        const double *resp = a.resp + (size_t)b * a.sums_stride;
+        double *probs = a.probs + (size_t)b * a.probs_stride;
+        double lb = -1.0;
+        for (int i = tid; i < a.n_blocks; i += NT) { const double v = a.blockmax[(size_t)b * a.n_blocks + i]; lb = v > lb ? v : lb; }
+        best = block_reduce(lb, OpMaxD(), -1.0, scratch);
+        // mean of all hypotheses with DoubleEqual(response, best)
+        double ax = 0, ay = 0, tx = 0, ty = 0;
+        int cnt = 0;
+        for (int h = tid; h < nh; h += NT) {
+            const double r = resp[h];
             if (kt_double_equal(r, best)) {
-                const double hd = kt_normalize_angle(angle);
+                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+                const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+                const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
                 ax += cxw + x; ay += cyw + y;
                 tx += cos(hd); ty += sin(hd);
                 cnt++;
             }
         }
-    }
-    ax = block_reduce(ax, OpAddD(), 0.0, scratch);
-    ay = block_reduce(ay, OpAddD(), 0.0, scratch);
-    tx = block_reduce(tx, OpAddD(), 0.0, scratch);
-    ty = block_reduce(ty, OpAddD(), 0.0, scratch);
-    {
-        __shared__ int iscratch[16];
+        // per-(x,y) maximum over theta: the search-space probability grid
+        for (int c = tid; c < nxy; c += NT) {
+            double cm = 0.0; // the grid starts cleared
+            for (int k = 0; k < nt; k++) { const double r = resp[(size_t)k * nxy + c]; cm = r > cm ? r : cm; }
+            probs[c] = cm;
+        }
+        ax = block_reduce(ax, OpAddD(), 0.0, scratch);
+        ay = block_reduce(ay, OpAddD(), 0.0, scratch);
+        tx = block_reduce(tx, OpAddD(), 0.0, scratch);
+        ty = block_reduce(ty, OpAddD(), 0.0, scratch);
         cnt = block_reduce(cnt, OpAddI(), 0, iscratch);
-    }
-    double mean[3] = {0, 0, 0};
-    int status = st.status;
-    if (cnt > 0) {
-        ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
-        mean[0] = ax; mean[1] = ay; mean[2] = atan2(ty, tx);
-    } else {
-        status = -5; // "Unable to find best position"
-    }
-
-    if (!a.lat.fine) {
+        if (cnt > 0) {
+            ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
+            mean[0] = ax; mean[1] = ay; mean[2] = atan2(ty, tx);
+        } else {
+            status = -5; // "Unable to find best position"
+        }
         // ComputePositionalCovariance
         double norm = 0, axx = 0, axy = 0, ayy = 0;
         const double dx = mean[0] - cxw, dy = mean[1] - cyw;
         if (!(best < YM_KT_TOLERANCE)) {
-            for (int c = tid; c < nxy; c += 1024) {
+            for (int c = tid; c < nxy; c += NT) {
                 const int iy = c / nx, ix = c - iy * nx;
-                const double x = start_x + ix * a.lat.step_x, y = start_y + iy * a.lat.step_y;
+                const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
                 const double response = probs[c];
                 if (response >= (best - 0.1)) {
                     norm += response;
@@ -543,70 +647,146 @@ __global__ __launch_bounds__(1024) void reduce_kernel(ReduceArgs a) {
         axx = block_reduce(axx, OpAddD(), 0.0, scratch);
         axy = block_reduce(axy, OpAddD(), 0.0, scratch);
         ayy = block_reduce(ayy, OpAddD(), 0.0, scratch);
-        if (tid == 0) {
-            double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            if (best < YM_KT_TOLERANCE) {
-                cov[0] = YM_MAX_VARIANCE; cov[4] = YM_MAX_VARIANCE;
-                cov[8] = 4 * (a.lat.angle_res * a.lat.angle_res);
-            } else {
-                if (norm > YM_KT_TOLERANCE) {
-                    double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
-                    const double vthth = 4 * (a.lat.angle_res * a.lat.angle_res);
-                    const double min_xx = 0.1 * (a.lat.step_x * a.lat.step_x);
-                    const double min_yy = 0.1 * (a.lat.step_y * a.lat.step_y);
-                    vxx = vxx > min_xx ? vxx : min_xx;
-                    vyy = vyy > min_yy ? vyy : min_yy;
-                    const double mult = 1.0 / best;
-                    cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
-                    cov[8] = vthth;
-                }
-                if (kt_double_equal(cov[0], 0.0)) cov[0] = YM_MAX_VARIANCE;
-                if (kt_double_equal(cov[4], 0.0)) cov[4] = YM_MAX_VARIANCE;
+        if (best < YM_KT_TOLERANCE) {
+            cov[0] = YM_MAX_VARIANCE; cov[4] = YM_MAX_VARIANCE;
+            cov[8] = 4 * (L.angle_res * L.angle_res);
+        } else {
+            if (norm > YM_KT_TOLERANCE) {
+                double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
+                const double vthth = 4 * (L.angle_res * L.angle_res);
+                const double min_xx = 0.1 * (L.step_x * L.step_x);
+                const double min_yy = 0.1 * (L.step_y * L.step_y);
+                vxx = vxx > min_xx ? vxx : min_xx;
+                vyy = vyy > min_yy ? vyy : min_yy;
+                const double mult = 1.0 / best;
+                cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
+                cov[8] = vthth;
             }
-            for (int i = 0; i < 9; i++) st.cov[i] = cov[i];
+            if (kt_double_equal(cov[0], 0.0)) cov[0] = YM_MAX_VARIANCE;
+            if (kt_double_equal(cov[4], 0.0)) cov[4] = YM_MAX_VARIANCE;
         }
-    } else {
+    }
+    const double coarse_response = best > 1.0 ? 1.0 : best;
+    double response = coarse_response;
+
+    // ------------------------------------------------------------- fine pass (CorrelateScan, doingFineMatch)
+    if (a.refine) {
+        const YmLattice &L = a.lf;
+        const int nx = L.nx, ny = L.ny, nt = L.nt, nxy = nx * ny, nh = nxy * nt;
+        const double cxw = mean[0], cyw = mean[1], ct = mean[2];
+        const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
+        int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
+        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        // lookup table around the coarse mean heading
+        for (int w = tid; w < nt * nq; w += NT) {
+            const int k = w / nq, i = w - k * nq;
+            const double angle = start_angle + k * L.angle_res;
+            foff[(size_t)k * a.max_n + i] = lookup_offset(ql[i], cos(angle), sin(angle), st.off_x, st.off_y, a.g.scale, a.g.pitch);
+        }
+        for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(cxw, start_x, i, L.step_x, st.off_x, a.g);
+        for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, st.off_y, a.g);
+        for (int h = tid; h < nh; h += NT) s_fsum[h] = 0u;
+        __syncthreads();
+        // gather-reduce: work item = (hypothesis, beam segment)
+        const int nseg = max(1, min(NT / max(nh, 1), (nq + 31) / 32));
+        const int seg = (nq + nseg - 1) / nseg;
+        for (int w = tid; w < nh * nseg; w += NT) {
+            const int h = w % nh, s = w / nh;
+            const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+            const int base = s_cy[iy] * a.g.pitch + s_cx[ix];
+            const int32_t *offs = foff + (size_t)k * a.max_n;
+            const int e = min(nq, (s + 1) * seg);
+            unsigned sum = 0;
+#pragma unroll 8
+            for (int i = s * seg; i < e; i++) {
+                const unsigned idx = (unsigned)(base + offs[i]);
+                sum += idx < limit ? grid[idx] : 0u;
+            }
+            atomicAdd(&s_fsum[h], sum);
+        }
+        __syncthreads();
+        double lb = -1.0;
+        uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride;
+        for (int h = tid; h < nh; h += NT) {
+            const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+            const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+            const double r = hyp_response(a.g, L.penalize, s_fsum[h], nq, x * x + y * y, start_angle + k * L.angle_res, ct);
+            s_fresp[h] = r;
+            fs[h] = s_fsum[h];
+            lb = r > lb ? r : lb;
+        }
+        best = block_reduce(lb, OpMaxD(), -1.0, scratch);
+        double ax = 0, ay = 0, tx = 0, ty = 0;
+        int cnt = 0;
+        for (int h = tid; h < nh; h += NT) {
+            if (kt_double_equal(s_fresp[h], best)) {
+                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+                const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+                const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
+                ax += cxw + x; ay += cyw + y;
+                tx += cos(hd); ty += sin(hd);
+                cnt++;
+            }
+        }
+        ax = block_reduce(ax, OpAddD(), 0.0, scratch);
+        ay = block_reduce(ay, OpAddD(), 0.0, scratch);
+        tx = block_reduce(tx, OpAddD(), 0.0, scratch);
+        ty = block_reduce(ty, OpAddD(), 0.0, scratch);
+        cnt = block_reduce(cnt, OpAddI(), 0, iscratch);
+        if (cnt > 0) {
+            ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
+            mean[0] = ax; mean[1] = ay; mean[2] = atan2(ty, tx);
+        } else {
+            status = -5;
+        }
         // ComputeAngularCovariance: re-score every fine angle at the cell of the mean pose
         const double best_angle = kt_normalize_angle_difference(mean[2], ct);
         const int gx = world_to_grid(mean[0], st.off_x, a.g.scale) + a.g.border - a.g.win_origin;
         const int gy = world_to_grid(mean[1], st.off_y, a.g.scale) + a.g.border - a.g.win_origin;
         const int base = gy * a.g.pitch + gx;
-        const uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
-        const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+        for (int k = tid; k < nt; k += NT) s_asum[k] = 0u;
+        __syncthreads();
+        const int nseg2 = max(1, min(NT / max(nt, 1), (nq + 31) / 32));
+        const int seg2 = (nq + nseg2 - 1) / nseg2;
+        for (int w = tid; w < nt * nseg2; w += NT) {
+            const int k = w % nt, s = w / nt;
+            const int32_t *offs = foff + (size_t)k * a.max_n;
+            const int e = min(nq, (s + 1) * seg2);
+            unsigned sum = 0;
+#pragma unroll 8
+            for (int i = s * seg2; i < e; i++) {
+                const unsigned idx = (unsigned)(base + offs[i]);
+                sum += idx < limit ? grid[idx] : 0u;
+            }
+            atomicAdd(&s_asum[k], sum);
+        }
+        __syncthreads();
         double norm = 0.0, acc = 0.0;
         for (int k = 0; k < nt; k++) {
-            const int32_t *offs = a.offsets + ((size_t)b * a.nt_stride + k) * a.max_n;
-            unsigned s = 0;
-            for (int i = tid; i < nq; i += 1024) {
-                const unsigned idx = (unsigned)(base + offs[i]);
-                s += idx < limit ? grid[idx] : 0u;
-            }
-            s = block_reduce(s, OpAddU(), 0u, uscratch);
-            const double angle = start_angle + k * a.lat.angle_res;
-            double response = 0.0;
-            if (nq != 0) { response = (double)s; response /= (double)(nq * YM_OCCUPIED); }
-            if (response >= (best - 0.1)) {
-                norm += response;
-                acc += ((angle - best_angle) * (angle - best_angle)) * response;
+            const double angle = start_angle + k * L.angle_res;
+            double r = (double)s_asum[k];
+            r /= (double)(nq * YM_OCCUPIED);
+            if (r >= (best - 0.1)) {
+                norm += r;
+                acc += ((angle - best_angle) * (angle - best_angle)) * r;
             }
         }
-        if (tid == 0) {
-            if (norm > YM_KT_TOLERANCE) {
-                if (acc < YM_KT_TOLERANCE) acc = a.lat.angle_res * a.lat.angle_res;
-                acc /= norm;
-            } else {
-                acc = 1000 * (a.lat.angle_res * a.lat.angle_res);
-            }
-            st.cov[8] = acc;
+        if (norm > YM_KT_TOLERANCE) {
+            if (acc < YM_KT_TOLERANCE) acc = L.angle_res * L.angle_res;
+            acc /= norm;
+        } else {
+            acc = 1000 * (L.angle_res * L.angle_res);
         }
+        cov[8] = acc;
+        response = best > 1.0 ? 1.0 : best;
     }
     if (tid == 0) {
-        st.mean[0] = mean[0]; st.mean[1] = mean[1]; st.mean[2] = mean[2];
-        st.center[0] = mean[0]; st.center[1] = mean[1]; st.center[2] = mean[2]; // centre of the fine pass
-        const double clamped = best > 1.0 ? 1.0 : best;
-        st.response = clamped;
-        if (!a.lat.fine) st.coarse_response = clamped;
+        for (int i = 0; i < 9; i++) st.cov[i] = cov[i];
+        for (int i = 0; i < 3; i++) { st.mean[i] = mean[i]; st.center[i] = mean[i]; }
+        st.response = response;
+        st.coarse_response = coarse_response;
         st.status = status;
+        if (a.host_out) a.host_out[b] = st;
     }
 }
 

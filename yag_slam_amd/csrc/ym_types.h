@@ -74,5 +74,6 @@ struct YmItemState {
     int32_t nq;           // number of query point readings (normaliser)
     int32_t status;
     int32_t regular[2];   // per pass: hypothesis cells form an exact lattice (fast path legal)
-    int32_t pad[2];
+    int32_t base_count;   // chain length of this item (copied from the call descriptor)
+    int32_t pad;
 };
