@@ -18,7 +18,8 @@ EXPORTS = (
     "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scan_get_pose",
     "ym_scan_size", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_match_batch_async", "ym_debug_grid_info",
-    "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_profile_enable",
+    "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_stamps",
+    "ym_profile_enable",
     "ym_profile_read",
 )
 
@@ -136,6 +137,7 @@ def lib():
     L.ym_debug_sums.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int64]
     L.ym_debug_query_local.argtypes = [vp, C.c_int, dp, C.c_int32, ip]
     L.ym_debug_cells.argtypes = [vp, C.c_int, ip, C.c_int64, ip]
+    L.ym_debug_stamps.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.c_int32]
     L.ym_profile_enable.argtypes = [vp, C.c_int]
     L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]
     _lib = L

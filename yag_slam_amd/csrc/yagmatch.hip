@@ -161,6 +161,8 @@ struct ym_matcher {
     DevBuf<double> resp;
     DevBuf<double> blockmax;
     DevBuf<double> probs;
+    DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
+    bool stamps_on = false;
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
     Slot slots[kAsyncSlots + 1]; // last one serves the synchronous entry points
@@ -236,11 +238,29 @@ int build_geometry(ym_matcher *m) {
     return YM_OK;
 }
 
-int upload_ktab(ym_matcher *m) {
+// smear kernel as a function of the squared cell distance, with the proof obligation the raster
+// kernel relies on: inside the (2h+1)^2 window the kernel value depends only on dx^2+dy^2 and
+// never increases with it.
+int upload_lut(ym_matcher *m) {
     const int h = m->geom.half_kernel, ks = 2 * h + 1;
-    std::vector<uint8_t> q((size_t)(h + 1) * (h + 1));
+    const int n = 2 * h * h + 1;
+    std::vector<int> lut(n, -1);
     for (int dy = 0; dy <= h; dy++)
-        for (int dx = 0; dx <= h; dx++) q[(size_t)dy * (h + 1) + dx] = m->kernel[(size_t)(dx + h) + (size_t)ks * (dy + h)];
+        for (int dx = 0; dx <= h; dx++) {
+            const int v = m->kernel[(size_t)(dx + h) + (size_t)ks * (dy + h)];
+            int &e = lut[dx * dx + dy * dy];
+            if (e >= 0 && e != v)
+                return set_err(YM_ERR_UNSUPPORTED, "smear kernel is not a function of squared distance at d2=%d", dx * dx + dy * dy);
+            e = v;
+        }
+    int prev = 255;
+    std::vector<uint8_t> q(n + 8, 0);
+    for (int i = 0; i < n; i++) {
+        if (lut[i] < 0) { q[i] = (uint8_t)prev; continue; } // unreachable distance: never looked up
+        if (lut[i] > prev) return set_err(YM_ERR_UNSUPPORTED, "smear kernel is not monotone at d2=%d", i);
+        prev = lut[i];
+        q[i] = (uint8_t)lut[i];
+    }
     int rc = m->ktab.ensure(q.size());
     if (rc) return rc;
     HIP_TRY(hipMemcpy(m->ktab.p, q.data(), q.size(), hipMemcpyHostToDevice));
@@ -344,8 +364,10 @@ int launch_call(ym_matcher *m, Slot &slot) {
     g.pitch = tiles_x * YM_TILE_W + 64;
     const size_t grid_stride = align_up((size_t)g.pitch * g.win_w + 64, 256);
     if ((double)g.pitch * g.win_w > 2.0e9) return set_err(YM_ERR_UNSUPPORTED, "correlation window too large");
-    if (lf.nx > 64 || lf.ny > 64 || lf.nt > 1024 || (int64_t)lf.nx * lf.ny * lf.nt > YM_MAX_FINE_HYP)
+    if (lf.nx > 64 || lf.ny > 64 || lf.nt > YM_MAX_FINE_NT || (int64_t)lf.nx * lf.ny * lf.nt > YM_MAX_FINE_HYP)
         return set_err(YM_ERR_UNSUPPORTED, "fine lattice %dx%dx%d exceeds the built-in limit", lf.nx, lf.ny, lf.nt);
+    if (lc.nt > YM_MAX_COARSE_NT)
+        return set_err(YM_ERR_UNSUPPORTED, "%d coarse angles exceed the built-in limit of %d", lc.nt, YM_MAX_COARSE_NT);
 
     // ---- coarse correlate decomposition
     const int sx = (int)kt_round_h(lc.step_x * g.scale);
@@ -361,8 +383,9 @@ int launch_call(ym_matcher *m, Slot &slot) {
     n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
     n_chunks = std::max(n_chunks, (max_n + 511) / 512);
     int chunk = (max_n + n_chunks - 1) / n_chunks;
-    chunk = (chunk + 7) / 8 * 8;
+    chunk = (chunk + 15) / 16 * 16;
     n_chunks = (max_n + chunk - 1) / chunk;
+    const int off_stride = n_chunks * chunk; // lookup rows are zero-padded to whole chunks
 
     const int nt_stride = lc.nt;
     const int dim_stride = std::max(lc.nx, lc.ny);
@@ -376,7 +399,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
-    if ((rc = m->offsets.ensure((size_t)B * nt_stride * max_n))) return rc;
+    if ((rc = m->offsets.ensure((size_t)B * nt_stride * off_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
     if ((rc = m->partial.ensure((size_t)B * partial_stride + 16))) return rc;
@@ -412,6 +435,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     const YmScanRef *d_scans = reinterpret_cast<const YmScanRef *>(slot.desc.dp);
     const YmItem *d_items = reinterpret_cast<const YmItem *>(slot.desc.dp + scans_bytes);
     hipStream_t st = m->stream;
+    unsigned long long *stamps = m->stamps_on ? m->stamps.p : nullptr;
     hipEvent_t ev_call = nullptr, ev_k = nullptr;
     if ((rc = prof_begin(m, 2, &ev_call))) return rc;
 
@@ -419,16 +443,24 @@ int launch_call(ym_matcher *m, Slot &slot) {
     {
         ym::PrepareArgs a;
         a.scans = d_scans; a.items = d_items; a.g = g; a.lat = lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
-        a.cells = m->cells.p; a.offsets = m->offsets.p; a.hypcell = m->hypcell.p;
-        a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride;
-        const size_t lds = (size_t)max_n * 21 + 16;
+        a.cells = m->cells.p; a.offsets = m->offsets.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
+        a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.stamps = stamps;
+        a.off_stride = off_stride;
+        a.use_inline = (B == 1 && nscans <= YM_INLINE_SCANS) ? 1 : 0;
+        a.pad0 = 0;
+        std::memset(&a.inl, 0, sizeof a.inl);
+        if (a.use_inline) { // descriptor travels in the kernel arguments: no host-memory reads on the device
+            a.inl.item = hi[0];
+            for (int i = 0; i < nscans; i++) a.inl.scans[i] = hs[i];
+        }
+        const size_t lds = YM_PREP_LDS_BYTES(max_n);
         hipLaunchKernelGGL(ym::prepare_kernel, dim3(max_base + 1, B), dim3(YM_PREP_THREADS), lds, st, a);
     }
     // ---- K2 raster
     {
         ym::RasterArgs a;
         a.cells = m->cells.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
-        a.grid_stride = grid_stride; a.ktab = m->ktab.p; a.max_n = max_n; a.max_base = max_base;
+        a.grid_stride = grid_stride; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
         if ((rc = prof_begin(m, 1, &ev_k))) return rc;
         hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
@@ -439,7 +471,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.offsets = m->offsets.p;
         a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = partial_stride;
         a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.chunk = chunk; a.n_chunks = n_chunks;
-        a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx;
+        a.off_stride = off_stride;
+        a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 grid_dim(job_blocks, lc.nt * n_chunks, B);
         if (sx == 2) hipLaunchKernelGGL(ym::correlate_kernel<2>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
@@ -453,7 +486,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
         ym::ScoreArgs a;
         a.g = g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = partial_stride; a.states = m->states.p;
         a.sums = m->sums.p; a.sums_stride = sums_c; a.resp = m->resp.p; a.blockmax = m->blockmax.p;
-        a.n_chunks = n_chunks; a.nx_pad = nx_pad; a.n_blocks = score_blocks;
+        a.n_chunks = n_chunks; a.nx_pad = nx_pad; a.n_blocks = score_blocks; a.stamps = stamps;
+        a.probs = reinterpret_cast<unsigned long long *>(m->probs.p); a.probs_stride = (size_t)lc.nx * lc.ny;
         hipLaunchKernelGGL(ym::score_kernel, dim3(score_blocks, B), dim3(YM_SCORE_THREADS), 0, st, a);
     }
     // ---- K6 finish (coarse tail + fine pass), results land in pinned host memory
@@ -465,7 +499,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.resp = m->resp.p; a.sums_stride = sums_c; a.blockmax = m->blockmax.p; a.probs = m->probs.p;
         a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = grid_stride;
         a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
-        a.fsums_stride = sums_f;
+        a.fsums_stride = sums_f; a.stamps = stamps;
         hipLaunchKernelGGL(ym::finish_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
@@ -643,7 +677,15 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
         return nullptr;
     }
     m->stream = m->own_stream;
-    if (upload_ktab(m) != YM_OK) { ym_destroy(m); return nullptr; }
+    if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess) {
+        set_err(YM_ERR_HIP, "cannot raise the dynamic LDS limit of prepare_kernel");
+        ym_destroy(m);
+        return nullptr;
+    }
+    if (m->stamps.ensure(32) != YM_OK) { ym_destroy(m); return nullptr; }
+    (void)hipMemset(m->stamps.p, 0, 32 * sizeof(unsigned long long));
     return m;
 }
 
@@ -654,7 +696,7 @@ void ym_destroy(ym_matcher *m) {
     m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->grid.release();
     m->offsets.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
-    m->tmp_ranges_host.release();
+    m->tmp_ranges_host.release(); m->stamps.release();
     for (Slot &s : m->slots) {
         s.desc.release();
         s.result.release();
@@ -927,6 +969,16 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(out, m->cells.p + (size_t)item * per, sizeof(int2) * per, hipMemcpyDeviceToHost));
+    return YM_OK;
+}
+
+int ym_debug_stamps(ym_matcher *m, int enable, uint64_t *out, int32_t count) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (out && count > 0)
+        HIP_TRY(hipMemcpy(out, m->stamps.p, sizeof(uint64_t) * std::min(count, 32), hipMemcpyDeviceToHost));
+    m->stamps_on = enable != 0;
     return YM_OK;
 }
 

@@ -66,11 +66,47 @@ __device__ __forceinline__ int block_scan_flag(bool flag, int *total, int *wave_
     return base + pre;
 }
 
-template <typename T, typename Op>
-__device__ __forceinline__ T wave_reduce(T v, Op op) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
-    return v;
+// ---- wave64 reductions on DPP row operations (no LDS traffic).  After the four row steps every
+// lane of a 16-lane row holds its row's result; the four row results are combined through
+// v_readlane, so the combination order is fixed (bit-reproducible fp64 sums).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#define YM_DPP_QUAD_1032 0xB1
+#define YM_DPP_QUAD_2301 0x4E
+#define YM_DPP_ROW_ROR4 0x124
+#define YM_DPP_ROW_ROR8 0x128
+template <typename Op>
+__device__ __forceinline__ double wave_reduce(double v, Op op) {
+    v = op(v, dpp_f64<YM_DPP_QUAD_1032>(v));
+    v = op(v, dpp_f64<YM_DPP_QUAD_2301>(v));
+    v = op(v, dpp_f64<YM_DPP_ROW_ROR4>(v));
+    v = op(v, dpp_f64<YM_DPP_ROW_ROR8>(v));
+    return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+template <typename Op>
+__device__ __forceinline__ int wave_reduce(int v, Op op) {
+    v = op(v, dpp_i32<YM_DPP_QUAD_1032>(v));
+    v = op(v, dpp_i32<YM_DPP_QUAD_2301>(v));
+    v = op(v, dpp_i32<YM_DPP_ROW_ROR4>(v));
+    v = op(v, dpp_i32<YM_DPP_ROW_ROR8>(v));
+    return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+              op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+template <typename Op>
+__device__ __forceinline__ unsigned wave_reduce(unsigned v, Op op) {
+    struct Wrap { Op op; __device__ int operator()(int a, int b) const { return (int)op((unsigned)a, (unsigned)b); } };
+    return (unsigned)wave_reduce((int)v, Wrap{op});
 }
 // block-wide reduce, result valid in every thread; scratch >= 16 entries of T
 template <typename T, typename Op>
@@ -88,6 +124,19 @@ struct OpMaxD { __device__ double operator()(double a, double b) const { return 
 struct OpAddD { __device__ double operator()(double a, double b) const { return a + b; } };
 struct OpAddU { __device__ unsigned operator()(unsigned a, unsigned b) const { return a + b; } };
 struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
+
+// development aid: block (0,0,0) thread 0 records the 100 MHz wall clock at phase boundaries
+#define YM_STAMP(args, idx)                                                                       \
+    do {                                                                                          \
+        if ((args).stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
+            (args).stamps[idx] = wall_clock64();                                                  \
+    } while (0)
+
+#define YM_STAMP_B1(args, idx)                                                                    \
+    do {                                                                                          \
+        if ((args).stamps && threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) \
+            (args).stamps[idx] = wall_clock64();                                                  \
+    } while (0)
 
 // GridIndexLookup::ComputeOffsets for one angle and one point -> window-linear offset
 __device__ __forceinline__ int lookup_offset(double2 p, double cosine, double sine, double off_x, double off_y,
@@ -107,9 +156,18 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 
 // ================================================================== K1 prepare
 #define YM_PREP_THREADS 1024
+#define YM_PREP_LDS_BYTES(max_n) ((size_t)(max_n) * 25 + ((size_t)(max_n) / 64 + 2) * 4 + 16)
+#define YM_INLINE_SCANS 16
+struct YmInlineDesc {        // call descriptor passed in the kernel arguments (single item, few scans)
+    YmItem item;
+    YmScanRef scans[YM_INLINE_SCANS];
+};
 struct PrepareArgs {
-    const YmScanRef *scans;  // pinned host memory (device-mapped) or device memory
+    const YmScanRef *scans;  // pinned host memory (device-mapped); unused when use_inline
     const YmItem *items;
+    int32_t use_inline;
+    int32_t pad0;
+    YmInlineDesc inl;
     YmGeom g;
     YmLattice lat;           // coarse lattice
     YmItemState *states;
@@ -117,27 +175,35 @@ struct PrepareArgs {
     int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
     int32_t *offsets;        // [B][nt_stride][max_n] coarse lookup table
     int32_t *hypcell;        // [B][2][dim_stride]
+    double *probs;           // [B][ny*nx] cleared here, filled by score_kernel
     int32_t max_n, max_base, nt_stride, dim_stride;
+    int32_t off_stride;      // entries per angle in `offsets` (>= max_n, multiple of the correlate unroll)
+    unsigned long long *stamps;
 };
 
-// grid (max_base + 1, B), 1024 threads, dynamic LDS = max_n * 21 bytes
+// grid (max_base + 1, B), 1024 threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n)
 // blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.
 __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int wave_counts[YM_PREP_THREADS / 64];
+    __shared__ double s_cos[YM_MAX_COARSE_NT], s_sin[YM_MAX_COARSE_NT];
     constexpr int NT = YM_PREP_THREADS;
+    YM_STAMP(a, 0);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const YmItem it = a.items[b];
+    const YmItem it = a.use_inline ? a.inl.item : a.items[b];
     const bool is_query = blockIdx.x == 0;
     const int slot = (int)blockIdx.x - 1;
     if (!is_query && slot >= it.base_count) return;
-    const YmScanRef sr = a.scans[is_query ? it.query : it.base_begin + slot];
-    const YmScanRef qr = a.scans[it.query];
+    const int si = is_query ? it.query : it.base_begin + slot;
+    const YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
+    const YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
     double *sx = reinterpret_cast<double *>(lds_raw);
     double *sy = sx + a.max_n;
     int *nxt = reinterpret_cast<int *>(sy + a.max_n);
-    unsigned char *chain = reinterpret_cast<unsigned char *>(nxt + a.max_n);
+    int *ex = nxt + a.max_n;                     // exit of the chain walk from point i out of its segment
+    int *ent = ex + a.max_n;                     // chain entry node per 64-point segment (max_n/64 + 1)
+    unsigned char *chain = reinterpret_cast<unsigned char *>(ent + a.max_n / 64 + 2);
     const bool yag = a.g.semantics == 1;
 
     // ---- point readings, compacted in beam order (LocalizedRangeScan::Update / _get_point_readings)
@@ -164,6 +230,8 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     }
     const int np = running;
     __syncthreads();
+    YM_STAMP(a, 1);
+    YM_STAMP_B1(a, 20);
     // world offset of ROI cell (0,0): MatchScan, "set scan pose to be center of grid"
     const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
     const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
@@ -200,14 +268,22 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
         __syncthreads();
         // coarse lookup table (GridIndexLookup::ComputeOffsets), centre heading = query heading
         const double start_angle = sr.pose[2] - a.lat.angle_off;
-        int32_t *offs = a.offsets + (size_t)b * a.nt_stride * a.max_n;
-        for (int k = 0; k < a.lat.nt; k++) {
-            const double angle = start_angle + k * a.lat.angle_res;
-            const double cosine = cos(angle), sine = sin(angle);
-            for (int i = tid; i < np; i += NT)
-                offs[(size_t)k * a.max_n + i] =
-                    lookup_offset(make_double2(sx[i], sy[i]), cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+        int32_t *offs = a.offsets + (size_t)b * a.nt_stride * a.off_stride;
+        if (tid < a.lat.nt) { // one fp64 sin/cos per angle, shared through LDS
+            const double angle = start_angle + tid * a.lat.angle_res;
+            s_cos[tid] = cos(angle);
+            s_sin[tid] = sin(angle);
         }
+        __syncthreads();
+        YM_STAMP(a, 2);
+        // entries past the last point are 0 so that the correlate kernel may load them unmasked
+        for (int w = tid; w < a.lat.nt * a.off_stride; w += NT) {
+            const int k = w / a.off_stride, i = w - k * a.off_stride;
+            offs[(size_t)k * a.off_stride + i] =
+                i < np ? lookup_offset(make_double2(sx[i], sy[i]), s_cos[k], s_sin[k], off_x, off_y, a.g.scale, a.g.pitch) : 0;
+        }
+        YM_STAMP(a, 3);
+        for (int i = tid; i < a.lat.nx * a.lat.ny; i += NT) a.probs[(size_t)b * a.lat.nx * a.lat.ny + i] = 0.0;
         // coarse hypothesis cells + regularity flag
         int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
         int32_t *cy = cx + a.dim_stride;
@@ -240,23 +316,33 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
         chain[i] = 0;
     }
     __syncthreads();
-    if (tid < 64) {
-        // One wave walks the chain.  The window nxt[base .. base+64) sits in one VGPR; hops inside
-        // the window are v_readlane with a scalar lane index instead of dependent LDS reads.
-        int cur = 0;
-        while (cur < np) {
-            const int base = cur;
-            const int idx = base + tid;
-            const int v = idx < np ? nxt[idx] : np;
-            unsigned long long mask = 0ull;
-            while (cur < base + 64 && cur < np) {
-                mask |= 1ull << (cur - base);
-                cur = __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(cur - base));
-            }
-            if (idx < np && ((mask >> tid) & 1ull)) chain[idx] = 1;
+    YM_STAMP_B1(a, 21);
+    // Mark the chain 0 -> nxt[0] -> ... without one long serial walk: cut the points into segments
+    // of 64; (1) every point walks to the first node past its own segment, (2) one thread hops from
+    // segment to segment with those exits (<= n/64 hops), (3) one thread per entered segment marks
+    // the chain nodes inside it.
+    constexpr int SEG = 64;
+    const int nseg = (np + SEG - 1) / SEG;
+    for (int i = tid; i < np; i += NT) {
+        const int seg_end = min(np, (i / SEG + 1) * SEG);
+        int j = nxt[i];
+        while (j < seg_end) j = nxt[j];
+        ex[i] = j;
+    }
+    for (int i = tid; i < nseg; i += NT) ent[i] = -1;
+    __syncthreads();
+    if (tid == 0)
+        for (int cur = 0; cur < np; cur = ex[cur]) ent[cur / SEG] = cur;
+    __syncthreads();
+    for (int sgi = tid; sgi < nseg; sgi += NT) {
+        int c = ent[sgi];
+        if (c >= 0) {
+            const int seg_end = min(np, (sgi + 1) * SEG);
+            for (; c < seg_end; c = nxt[c]) chain[c] = 1;
         }
     }
     __syncthreads();
+    YM_STAMP_B1(a, 22);
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
     for (int i = tid; i < a.max_n; i += NT) {
         int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
@@ -290,6 +376,7 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
         }
         cells[i] = c;
     }
+    YM_STAMP_B1(a, 23);
 }
 
 // ================================================================== K2 raster
@@ -302,42 +389,48 @@ struct RasterArgs {
     YmGeom g;
     uint8_t *grid;        // [B][win_w rows][pitch]
     size_t grid_stride;   // bytes per item
-    const uint8_t *ktab;  // (h+1) x (h+1) quadrant of the smear kernel: ktab[|dy|*(h+1) + |dx|]
+    const uint8_t *lut;   // smear kernel value by squared cell distance: lut[dx*dx + dy*dy], 2*h*h + 1 entries
     int32_t max_n, max_base;
+    unsigned long long *stamps;
 };
 
 // grid (tiles_x, tiles_y, B), 1024 threads.  Each block owns one 128x64 tile of the window and
-// writes every byte of it exactly once (so no separate clear pass exists).  The max-stamp of
-// Karto's SmearPoint over a set of occupied cells equals, per cell, the kernel value at the
-// nearest occupied cell inside the (2h+1)^2 window; with a radially monotone kernel that is
-//   max_dy ktab[|dy|][ min |dx| of an occupied cell in row y+dy within h ],
-// computed as a row pass followed by a column pass in LDS.
+// writes every byte of it exactly once (so no separate clear pass exists).  Karto's SmearPoint
+// max-stamps a (2h+1)^2 kernel at every occupied cell; the kernel value depends only on the squared
+// cell distance and never grows with it (checked on the host when the matcher is created), so a
+// cell's final value is lut[min squared distance to an occupied cell inside the (2h+1)^2 window]:
+//   row pass   g(y, x)  = min |dx| <= h with cell (y, x+dx) occupied      (bit scans on a row bitmap)
+//   column pass m(y, x) = min over |dy| <= h of dy^2 + g(y+dy, x)^2        (8 cells per lane)
 __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a) {
     constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF, NT = YM_RASTER_THREADS;
-    __shared__ unsigned char occ[(TH + 2 * HM) * (TW + 2 * HM)];
-    __shared__ unsigned char grow[(TH + 2 * HM) * TW];
-    __shared__ unsigned char kt[(HM + 1) * (HM + 1)];
+    constexpr int RW = 4;  // 64-bit words per bitmap row: TW + 2*HM = 168 bits, + 1 word so a funnel read never leaves the row
+    __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
+    __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
+    __shared__ unsigned char lut[2 * HM * HM + 8];
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
     const int h = a.g.half_kernel;
     const int OW = TW + 2 * h, OH = TH + 2 * h;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    for (int i = tid; i < (OW * OH + 3) / 4; i += NT) reinterpret_cast<uint32_t *>(occ)[i] = 0u;
-    for (int i = tid; i < (h + 1) * (h + 1); i += NT) kt[i] = a.ktab[i];
+    YM_STAMP(a, 4);
+    for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
+    for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
     __syncthreads();
     const int total = a.states[b].base_count * a.max_n;
     const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
+    unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
 #pragma unroll 4
     for (int i = tid; i < total; i += NT) {
         const int2 c = cells[i];
         const int lx = c.x - (tx0 - h), ly = c.y - (ty0 - h);
         if (c.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
-            occ[ly * OW + lx] = 1;
+            atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
             any = 1;
         }
     }
     any = __syncthreads_or(any);
+    YM_STAMP(a, 5);
     uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
     // thread -> 8 consecutive cells of one tile row
     const int y = tid >> 4, x8 = (tid & 15) * 8;
@@ -347,31 +440,42 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
         if (row_ok) *dst = make_uint2(0u, 0u);
         return;
     }
-    // row pass: nearest occupied |dx| <= h, 255 = none
+    // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
+    const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
     for (int i = tid; i < OH * TW; i += NT) {
         const int ry = i / TW, rx = i % TW;
-        const unsigned char *row = occ + ry * OW + rx + h;
-        int best = 255;
-        for (int d = 0; d <= h; d++)
-            if (row[-d] | row[d]) { best = d; break; }
-        grow[i] = (unsigned char)best;
+        const int w = rx >> 6, sft = rx & 63;
+        const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
+        const unsigned long long win = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & wmask;
+        const unsigned long long right = win >> h, left = win & lmask;
+        const int dr = right ? (__ffsll((long long)right) - 1) : 255;
+        const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
+        grow[i] = (unsigned char)(dr < dl ? dr : dl);
     }
     __syncthreads();
+    YM_STAMP(a, 6);
+    unsigned mn[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) mn[q] = 0x7fffffffu;
+    for (int dy = -h; dy <= h; dy++) {
+        const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + h + dy) * TW + x8]);
+        const unsigned d2 = (unsigned)(dy * dy);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned gq = ((q < 4 ? gg.x : gg.y) >> (8 * (q & 3))) & 0xffu;
+            const unsigned cand = gq * gq + d2;  // g = 255 (none) is larger than any real distance
+            mn[q] = cand < mn[q] ? cand : mn[q];
+        }
+    }
     uint32_t packed[2] = {0u, 0u};
+    const unsigned max_d2 = (unsigned)(2 * h * h);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const int x = x8 + q;
-        int v = 0;
-        for (int dy = -h; dy <= h; dy++) {
-            const int d = grow[(y + h + dy) * TW + x];
-            if (d != 255) {
-                const int k = kt[(dy < 0 ? -dy : dy) * (h + 1) + d];
-                v = k > v ? k : v;
-            }
-        }
-        packed[q >> 2] |= (uint32_t)v << (8 * (q & 3));
+        const unsigned v = mn[q] <= max_d2 ? lut[mn[q]] : 0u;
+        packed[q >> 2] |= v << (8 * (q & 3));
     }
     if (row_ok) *dst = make_uint2(packed[0], packed[1]);
+    YM_STAMP(a, 7);
 }
 
 // ================================================================== K4 correlate (coarse lattice)
@@ -386,57 +490,66 @@ struct CorrArgs {
     const YmItemState *states;
     uint32_t *partial;     // [B][n_chunks][nt][ny][nx_pad]
     size_t partial_stride; // per item
-    int32_t max_n, nt_stride, dim_stride;
-    int32_t chunk;         // beams per chunk (<= 512 keeps the 16-bit lanes from overflowing)
+    int32_t max_n, nt_stride, dim_stride, off_stride;
+    int32_t chunk;         // beams per chunk (multiple of 16, <= 512 keeps the 16-bit lanes from overflowing)
     int32_t n_chunks;
     int32_t ngx;           // x groups per row = ceil(nx / G)
     int32_t nx_pad;        // ngx * G
     int32_t sx;            // cell stride between x-adjacent hypotheses (1 or 2)
+    unsigned long long *stamps;
 };
 
 // Lane job = G x-adjacent hypotheses of one lattice row for one angle: G = 8 when the lattice
 // steps 2 cells (coarse search), 16 when it steps 1.  For every beam of its chunk the lane loads
 // the 16 grid bytes that hold those hypotheses' cells (row segment start + wave-uniform beam
 // offset) and accumulates them in 16-bit lanes.  No cross-lane reduction; partial sums per beam
-// chunk are added up by score_kernel.  grid (ceil(ny*ngx / 256), nt * n_chunks, B).
+// chunk are added up by score_kernel.  The loads of a chunk are issued 16 beams at a time without
+// waiting for the point count: table entries past the last beam are 0 and are masked by a scalar.
+// grid (ceil(ny*ngx / 256), nt * n_chunks, B).
 template <int SX>
 __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
     constexpr int G = 16 / SX;      // hypotheses per lane
     constexpr int NACC = 4 * (SX == 1 ? 2 : 1);
+    constexpr int U = 16;           // beams in flight per lane
     const int b = blockIdx.z;
     const int k = blockIdx.y % a.lat.nt, chunk = blockIdx.y / a.lat.nt;
     const int job = blockIdx.x * YM_CORR_THREADS + threadIdx.x;
+    YM_STAMP(a, 8);
     const int njobs = a.lat.ny * a.ngx;
     if (job >= njobs) return;
     const int iy = job / a.ngx, xg = job - iy * a.ngx;
     const YmItemState &st = a.states[b];
     const int nq = st.nq;
+    const int regular = st.regular[0];
     const int i0 = chunk * a.chunk;
-    const int i1 = min(nq, i0 + a.chunk);
     const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
     const int32_t *cy = cx + a.dim_stride;
+    const int cyv = cy[iy], cx0 = cx[0];
     const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
-    const int32_t *__restrict__ offs = a.offsets + ((size_t)b * a.nt_stride + k) * a.max_n;
+    const int32_t *__restrict__ offs = a.offsets + ((size_t)b * a.nt_stride + k) * a.off_stride;
     uint32_t *out = a.partial + (size_t)b * a.partial_stride +
                     (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
 
-    if (st.regular[0]) {
-        const uint32_t lane_off = (uint32_t)(cy[iy] * a.g.pitch + cx[0] + xg * G * SX);
+    if (regular) {
+        const uint32_t lane_off = (uint32_t)(cyv * a.g.pitch + cx0 + xg * G * SX);
         uint32_t acc[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; j++) acc[j] = 0u;
-#pragma unroll 8
-        for (int i = i0; i < i1; i++) {
-            uint4 w;
-            __builtin_memcpy(&w, grid + (uint32_t)(lane_off + (uint32_t)offs[i]), 16);
-            if (SX == 2) {
-                acc[0] += w.x & 0x00FF00FFu; acc[1] += w.y & 0x00FF00FFu;
-                acc[2] += w.z & 0x00FF00FFu; acc[3] += w.w & 0x00FF00FFu;
-            } else {
-                acc[0] += w.x & 0x00FF00FFu; acc[1] += (w.x >> 8) & 0x00FF00FFu;
-                acc[2] += w.y & 0x00FF00FFu; acc[3] += (w.y >> 8) & 0x00FF00FFu;
-                acc[4] += w.z & 0x00FF00FFu; acc[5] += (w.z >> 8) & 0x00FF00FFu;
-                acc[6] += w.w & 0x00FF00FFu; acc[7] += (w.w >> 8) & 0x00FF00FFu;
+        for (int i = i0; i < i0 + a.chunk; i += U) {
+            uint4 w[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], grid + (uint32_t)(lane_off + (uint32_t)offs[i + u]), 16);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t m = (i + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
+                if (SX == 2) {
+                    acc[0] += w[u].x & m; acc[1] += w[u].y & m; acc[2] += w[u].z & m; acc[3] += w[u].w & m;
+                } else {
+                    acc[0] += w[u].x & m; acc[1] += (w[u].x >> 8) & m;
+                    acc[2] += w[u].y & m; acc[3] += (w[u].y >> 8) & m;
+                    acc[4] += w[u].z & m; acc[5] += (w[u].z >> 8) & m;
+                    acc[6] += w[u].w & m; acc[7] += (w[u].w >> 8) & m;
+                }
             }
         }
         uint32_t r[G];
@@ -452,14 +565,16 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
         }
 #pragma unroll
         for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+        YM_STAMP(a, 9);
     } else {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+        const int i1 = min(nq, i0 + a.chunk);
         for (int j = 0; j < G; j++) {
             const int ix = xg * G + j;
             unsigned sum = 0;
             if (ix < a.lat.nx) {
-                const int base = cy[iy] * a.g.pitch + cx[ix];
+                const int base = cyv * a.g.pitch + cx[ix];
                 for (int i = i0; i < i1; i++) {
                     const unsigned idx = (unsigned)(base + offs[i]);
                     sum += idx < limit ? grid[idx] : 0u;
@@ -482,7 +597,10 @@ struct ScoreArgs {
     size_t sums_stride;
     double *resp;         // [B][nt][ny][nx]
     double *blockmax;     // [B][n_blocks]
+    unsigned long long *probs; // [B][ny*nx] bit patterns of non-negative doubles, zeroed by prepare_kernel
+    size_t probs_stride;
     int32_t n_chunks, nx_pad, n_blocks;
+    unsigned long long *stamps;
 };
 
 __device__ __forceinline__ double hyp_response(const YmGeom &g, int penalize, unsigned sum, int nq, double sq_dist,
@@ -512,12 +630,14 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     const int nx = a.lat.nx, ny = a.lat.ny, nt = a.lat.nt, nxy = nx * ny;
     const int h = blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
     double r = -1.0;
+    YM_STAMP(a, 10);
     if (h < nxy * nt) {
         const int k = h / nxy, c = h - k * nxy;
         const int iy = c / nx, ix = c - iy * nx;
         const uint32_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
         const size_t cstride = (size_t)nt * ny * a.nx_pad;
         unsigned sum = 0;
+#pragma unroll 8
         for (int c2 = 0; c2 < a.n_chunks; c2++) sum += p[(size_t)c2 * cstride];
         const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
         const double ct = st.center[2];
@@ -525,9 +645,13 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
         r = hyp_response(a.g, a.lat.penalize, sum, st.nq, x * x + y * y, angle, ct);
         a.sums[(size_t)b * a.sums_stride + h] = sum;
         a.resp[(size_t)b * a.sums_stride + h] = r;
+        // search-space probability grid: max over theta per (x, y).  Responses are >= 0, so the
+        // u64 order of the bit patterns is the numeric order and an integer atomic max is exact.
+        if (r > 0.0) atomicMax(&a.probs[(size_t)b * a.probs_stride + c], (unsigned long long)__double_as_longlong(r));
     }
     const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
     if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + blockIdx.x] = m;
+    YM_STAMP(a, 11);
 }
 
 // ================================================================== K6 finish
@@ -542,8 +666,8 @@ struct FinishArgs {
     YmItemState *host_out;    // pinned host memory, written directly (nullable)
     const double *resp;       // coarse responses [B][nt][ny][nx]
     size_t sums_stride;
-    const double *blockmax;
-    double *probs;            // [B][ny*nx] scratch: max over theta per (x, y)  (m_pSearchSpaceProbs)
+    const double *blockmax;   // [B][n_blocks] maxima of YM_SCORE_THREADS consecutive responses
+    const double *probs;      // [B][ny*nx] max over theta per (x, y)  (m_pSearchSpaceProbs)
     size_t probs_stride;
     const uint8_t *grid;
     size_t grid_stride;
@@ -551,18 +675,54 @@ struct FinishArgs {
     int32_t *foffsets;        // [B][nt_f][max_n] fine lookup table (scratch)
     uint32_t *fsums;          // [B][nt_f*ny_f*nx_f] fine sums (kept for parity tests)
     size_t fsums_stride;
+    unsigned long long *stamps;
 };
+
+// sum N doubles across the block in one round (2 barriers); result in every thread
+template <int N>
+__device__ __forceinline__ void block_sum_vec(double (&v)[N], double *scratch /* >= 16*N */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = wave_reduce(v[j], OpAddD());
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int j = 0; j < N; j++) scratch[w * N + j] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double r = 0.0;
+        for (int i = 0; i < nw; i++) r += scratch[i * N + j];
+        v[j] = r;
+    }
+}
+
+// tie-set mean of CorrelateScan: accumulate one hypothesis
+__device__ __forceinline__ void tie_accumulate(double (&acc)[5], const YmLattice &L, int h, double cxw, double cyw,
+                                               double start_angle) {
+    const int nxy = L.nx * L.ny;
+    const int k = h / nxy, c = h - k * nxy, iy = c / L.nx, ix = c - iy * L.nx;
+    const double x = -L.off_x + ix * L.step_x, y = -L.off_y + iy * L.step_y;
+    const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
+    acc[0] += cxw + x; acc[1] += cyw + y;
+    acc[2] += cos(hd); acc[3] += sin(hd);
+    acc[4] += 1.0;
+}
 
 // grid (B), 1024 threads: everything after the coarse responses, one block per item.
 __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a) {
     constexpr int NT = YM_FINISH_THREADS;
-    __shared__ double scratch[16];
-    __shared__ int iscratch[16];
+    __shared__ double scratch[16 * 5];
     __shared__ unsigned s_fsum[YM_MAX_FINE_HYP];
     __shared__ double s_fresp[YM_MAX_FINE_HYP];
     __shared__ int s_cx[64], s_cy[64];
-    __shared__ unsigned s_asum[1024];
+    __shared__ unsigned s_asum[YM_MAX_FINE_NT];
+    __shared__ double s_cos[YM_MAX_FINE_NT], s_sin[YM_MAX_FINE_NT];
+    __shared__ int s_list[NT];
+    __shared__ int s_nlist;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    YM_STAMP(a, 12);
     YmItemState &st = a.states[b];
     const int nq = st.nq;
     if (nq == 0) {
@@ -580,6 +740,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
     }
     const uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
     const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+    const double off_x = st.off_x, off_y = st.off_y;
     double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     double mean[3] = {0, 0, 0};
     int status = 0;
@@ -588,71 +749,74 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
     // ------------------------------------------------------------- coarse tail
     {
         const YmLattice &L = a.lc;
-        const int nx = L.nx, ny = L.ny, nt = L.nt, nxy = nx * ny, nh = nxy * nt;
+        const int nx = L.nx, nxy = nx * L.ny, nh = nxy * L.nt;
         const double cxw = st.pose[0], cyw = st.pose[1], ct = st.pose[2];
         const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
         const double *resp = a.resp + (size_t)b * a.sums_stride;
-        double *probs = a.probs + (size_t)b * a.probs_stride;
+        const double *bm = a.blockmax + (size_t)b * a.n_blocks;
+        if (tid == 0) s_nlist = 0;
         double lb = -1.0;
-        for (int i = tid; i < a.n_blocks; i += NT) { const double v = a.blockmax[(size_t)b * a.n_blocks + i]; lb = v > lb ? v : lb; }
+        for (int i = tid; i < a.n_blocks; i += NT) { const double v = bm[i]; lb = v > lb ? v : lb; }
         best = block_reduce(lb, OpMaxD(), -1.0, scratch);
-        // mean of all hypotheses with DoubleEqual(response, best)
-        double ax = 0, ay = 0, tx = 0, ty = 0;
-        int cnt = 0;
-        for (int h = tid; h < nh; h += NT) {
-            const double r = resp[h];
-            if (kt_double_equal(r, best)) {
-                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
-                const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-                const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
-                ax += cxw + x; ay += cyw + y;
-                tx += cos(hd); ty += sin(hd);
-                cnt++;
+        YM_STAMP(a, 24);
+        // score blocks that can hold a hypothesis with DoubleEqual(response, best)
+        int overflow = 0;
+        for (int i = tid; i < a.n_blocks; i += NT)
+            if (bm[i] >= best - YM_KT_TOLERANCE) {
+                const int at = atomicAdd(&s_nlist, 1);
+                if (at < NT) s_list[at] = i; else overflow = 1;
             }
+        overflow = __syncthreads_or(overflow);
+        YM_STAMP(a, 25);
+        double acc[5] = {0, 0, 0, 0, 0};
+        if (!overflow) {
+            const int nlist = s_nlist;
+            for (int w = tid; w < nlist * YM_SCORE_THREADS; w += NT) {
+                const int h = s_list[w / YM_SCORE_THREADS] * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
+                if (h < nh && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
+            }
+        } else {
+            for (int h = tid; h < nh; h += NT)
+                if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
         }
-        // per-(x,y) maximum over theta: the search-space probability grid
-        for (int c = tid; c < nxy; c += NT) {
-            double cm = 0.0; // the grid starts cleared
-            for (int k = 0; k < nt; k++) { const double r = resp[(size_t)k * nxy + c]; cm = r > cm ? r : cm; }
-            probs[c] = cm;
-        }
-        ax = block_reduce(ax, OpAddD(), 0.0, scratch);
-        ay = block_reduce(ay, OpAddD(), 0.0, scratch);
-        tx = block_reduce(tx, OpAddD(), 0.0, scratch);
-        ty = block_reduce(ty, OpAddD(), 0.0, scratch);
-        cnt = block_reduce(cnt, OpAddI(), 0, iscratch);
-        if (cnt > 0) {
-            ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
-            mean[0] = ax; mean[1] = ay; mean[2] = atan2(ty, tx);
+        YM_STAMP(a, 26);
+        block_sum_vec<5>(acc, scratch);
+        YM_STAMP(a, 27);
+        if (acc[4] > 0.0) {
+            const double cnt = acc[4]; // exact small integer, same value as Karto's int count
+            mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
+            mean[2] = atan2(acc[3] / cnt, acc[2] / cnt);
         } else {
             status = -5; // "Unable to find best position"
         }
-        // ComputePositionalCovariance
-        double norm = 0, axx = 0, axy = 0, ayy = 0;
+        YM_STAMP(a, 28);
+        // ComputePositionalCovariance over the per-(x,y) maxima
+        double sums[4] = {0, 0, 0, 0};
         const double dx = mean[0] - cxw, dy = mean[1] - cyw;
         if (!(best < YM_KT_TOLERANCE)) {
+            const double *probs = a.probs + (size_t)b * a.probs_stride;
             for (int c = tid; c < nxy; c += NT) {
                 const int iy = c / nx, ix = c - iy * nx;
                 const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
                 const double response = probs[c];
                 if (response >= (best - 0.1)) {
-                    norm += response;
-                    axx += ((x - dx) * (x - dx)) * response;
-                    axy += ((x - dx) * (y - dy) * response);
-                    ayy += ((y - dy) * (y - dy)) * response;
+                    sums[0] += response;
+                    sums[1] += ((x - dx) * (x - dx)) * response;
+                    sums[2] += ((x - dx) * (y - dy) * response);
+                    sums[3] += ((y - dy) * (y - dy)) * response;
                 }
             }
         }
-        norm = block_reduce(norm, OpAddD(), 0.0, scratch);
-        axx = block_reduce(axx, OpAddD(), 0.0, scratch);
-        axy = block_reduce(axy, OpAddD(), 0.0, scratch);
-        ayy = block_reduce(ayy, OpAddD(), 0.0, scratch);
+        YM_STAMP(a, 29);
+        block_sum_vec<4>(sums, scratch);
+        YM_STAMP(a, 30);
         if (best < YM_KT_TOLERANCE) {
             cov[0] = YM_MAX_VARIANCE; cov[4] = YM_MAX_VARIANCE;
             cov[8] = 4 * (L.angle_res * L.angle_res);
         } else {
+            const double norm = sums[0];
             if (norm > YM_KT_TOLERANCE) {
-                double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
+                double vxx = sums[1] / norm, vxy = sums[2] / norm, vyy = sums[3] / norm;
                 const double vthth = 4 * (L.angle_res * L.angle_res);
                 const double min_xx = 0.1 * (L.step_x * L.step_x);
                 const double min_yy = 0.1 * (L.step_y * L.step_y);
@@ -668,6 +832,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
     }
     const double coarse_response = best > 1.0 ? 1.0 : best;
     double response = coarse_response;
+    YM_STAMP(a, 13);
 
     // ------------------------------------------------------------- fine pass (CorrelateScan, doingFineMatch)
     if (a.refine) {
@@ -677,34 +842,78 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
         const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
         int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
         const double2 *ql = a.qlocal + (size_t)b * a.max_n;
-        // lookup table around the coarse mean heading
-        for (int w = tid; w < nt * nq; w += NT) {
-            const int k = w / nq, i = w - k * nq;
-            const double angle = start_angle + k * L.angle_res;
-            foff[(size_t)k * a.max_n + i] = lookup_offset(ql[i], cos(angle), sin(angle), st.off_x, st.off_y, a.g.scale, a.g.pitch);
+        if (tid < nt) { // one fp64 sin/cos per angle, shared through LDS
+            const double angle = start_angle + tid * L.angle_res;
+            s_cos[tid] = cos(angle);
+            s_sin[tid] = sin(angle);
         }
-        for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(cxw, start_x, i, L.step_x, st.off_x, a.g);
-        for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, st.off_y, a.g);
+        for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(cxw, start_x, i, L.step_x, off_x, a.g);
+        for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g);
         for (int h = tid; h < nh; h += NT) s_fsum[h] = 0u;
         __syncthreads();
-        // gather-reduce: work item = (hypothesis, beam segment)
-        const int nseg = max(1, min(NT / max(nh, 1), (nq + 31) / 32));
-        const int seg = (nq + nseg - 1) / nseg;
-        for (int w = tid; w < nh * nseg; w += NT) {
-            const int h = w % nh, s = w / nh;
-            const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
-            const int base = s_cy[iy] * a.g.pitch + s_cx[ix];
-            const int32_t *offs = foff + (size_t)k * a.max_n;
-            const int e = min(nq, (s + 1) * seg);
-            unsigned sum = 0;
-#pragma unroll 8
-            for (int i = s * seg; i < e; i++) {
-                const unsigned idx = (unsigned)(base + offs[i]);
-                sum += idx < limit ? grid[idx] : 0u;
-            }
-            atomicAdd(&s_fsum[h], sum);
+        YM_STAMP(a, 14);
+        // lookup table around the coarse mean heading (all threads, one (angle, beam) pair each)
+        for (int w = tid; w < nt * nq; w += NT) {
+            const int k = w / nq, i = w - k * nq;
+            foff[(size_t)k * a.max_n + i] = lookup_offset(ql[i], s_cos[k], s_sin[k], off_x, off_y, a.g.scale, a.g.pitch);
         }
         __syncthreads();
+        const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
+                            s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
+        // thread groups of GS lanes share one angle; lanes stride over the beams
+        const int GS = 64 * max(1, (NT / 64) / nt);
+        if (block3) {
+            // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its
+            // beam as three 4-byte words.
+            const uint32_t base0 = (uint32_t)(s_cy[0] * a.g.pitch + s_cx[0]);
+            for (int k = tid / GS; k < nt; k += NT / GS) {
+                const int32_t *offs = foff + (size_t)k * a.max_n;
+                unsigned acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = tid % GS; i < nq; i += 4 * GS) {
+                    uint32_t w[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int ii = i + u * GS;
+                        const uint32_t idx = base0 + (uint32_t)(ii < nq ? offs[ii] : 0);
+#pragma unroll
+                        for (int r = 0; r < 3; r++) __builtin_memcpy(&w[u][r], grid + (uint32_t)(idx + r * a.g.pitch), 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t m = (i + u * GS) < nq ? 0xffu : 0u;
+#pragma unroll
+                        for (int r = 0; r < 3; r++) {
+                            acc[3 * r] += w[u][r] & m; acc[3 * r + 1] += (w[u][r] >> 8) & m; acc[3 * r + 2] += (w[u][r] >> 16) & m;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 9; j++) acc[j] = wave_reduce(acc[j], OpAddU());
+                if (lane == 0)
+#pragma unroll
+                    for (int j = 0; j < 9; j++) atomicAdd(&s_fsum[k * 9 + j], acc[j]);
+            }
+        } else {
+            // generic gather-reduce: work item = (hypothesis, beam segment)
+            const int nseg = max(1, min(NT / max(nh, 1), (nq + 31) / 32));
+            const int seg = (nq + nseg - 1) / nseg;
+            for (int w = tid; w < nh * nseg; w += NT) {
+                const int h = w % nh, s = w / nh;
+                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+                const int base = s_cy[iy] * a.g.pitch + s_cx[ix];
+                const int32_t *offs = foff + (size_t)k * a.max_n;
+                const int e = min(nq, (s + 1) * seg);
+                unsigned sum = 0;
+#pragma unroll 8
+                for (int i = s * seg; i < e; i++) {
+                    const unsigned idx = (unsigned)(base + offs[i]);
+                    sum += idx < limit ? grid[idx] : 0u;
+                }
+                atomicAdd(&s_fsum[h], sum);
+            }
+        }
+        __syncthreads();
+        YM_STAMP(a, 15);
         double lb = -1.0;
         uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride;
         for (int h = tid; h < nh; h += NT) {
@@ -716,68 +925,59 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
             lb = r > lb ? r : lb;
         }
         best = block_reduce(lb, OpMaxD(), -1.0, scratch);
-        double ax = 0, ay = 0, tx = 0, ty = 0;
-        int cnt = 0;
-        for (int h = tid; h < nh; h += NT) {
-            if (kt_double_equal(s_fresp[h], best)) {
-                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
-                const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-                const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
-                ax += cxw + x; ay += cyw + y;
-                tx += cos(hd); ty += sin(hd);
-                cnt++;
-            }
-        }
-        ax = block_reduce(ax, OpAddD(), 0.0, scratch);
-        ay = block_reduce(ay, OpAddD(), 0.0, scratch);
-        tx = block_reduce(tx, OpAddD(), 0.0, scratch);
-        ty = block_reduce(ty, OpAddD(), 0.0, scratch);
-        cnt = block_reduce(cnt, OpAddI(), 0, iscratch);
-        if (cnt > 0) {
-            ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
-            mean[0] = ax; mean[1] = ay; mean[2] = atan2(ty, tx);
+        double acc[5] = {0, 0, 0, 0, 0};
+        for (int h = tid; h < nh; h += NT)
+            if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
+        block_sum_vec<5>(acc, scratch);
+        if (acc[4] > 0.0) {
+            const double cnt = acc[4];
+            mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
+            mean[2] = atan2(acc[3] / cnt, acc[2] / cnt);
         } else {
             status = -5;
         }
+        YM_STAMP(a, 16);
         // ComputeAngularCovariance: re-score every fine angle at the cell of the mean pose
         const double best_angle = kt_normalize_angle_difference(mean[2], ct);
-        const int gx = world_to_grid(mean[0], st.off_x, a.g.scale) + a.g.border - a.g.win_origin;
-        const int gy = world_to_grid(mean[1], st.off_y, a.g.scale) + a.g.border - a.g.win_origin;
+        const int gx = world_to_grid(mean[0], off_x, a.g.scale) + a.g.border - a.g.win_origin;
+        const int gy = world_to_grid(mean[1], off_y, a.g.scale) + a.g.border - a.g.win_origin;
         const int base = gy * a.g.pitch + gx;
         for (int k = tid; k < nt; k += NT) s_asum[k] = 0u;
         __syncthreads();
-        const int nseg2 = max(1, min(NT / max(nt, 1), (nq + 31) / 32));
-        const int seg2 = (nq + nseg2 - 1) / nseg2;
-        for (int w = tid; w < nt * nseg2; w += NT) {
-            const int k = w % nt, s = w / nt;
+        for (int k = tid / GS; k < nt; k += NT / GS) {
             const int32_t *offs = foff + (size_t)k * a.max_n;
-            const int e = min(nq, (s + 1) * seg2);
             unsigned sum = 0;
-#pragma unroll 8
-            for (int i = s * seg2; i < e; i++) {
-                const unsigned idx = (unsigned)(base + offs[i]);
-                sum += idx < limit ? grid[idx] : 0u;
+            for (int i = tid % GS; i < nq; i += 4 * GS) {
+                unsigned v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = i + u * GS;
+                    const unsigned idx = (unsigned)(base + (ii < nq ? offs[ii] : 0));
+                    v[u] = (ii < nq && idx < limit) ? grid[idx] : 0u;
+                }
+                sum += v[0] + v[1] + v[2] + v[3];
             }
-            atomicAdd(&s_asum[k], sum);
+            sum = wave_reduce(sum, OpAddU());
+            if (lane == 0) atomicAdd(&s_asum[k], sum);
         }
         __syncthreads();
-        double norm = 0.0, acc = 0.0;
+        double norm = 0.0, accv = 0.0;
         for (int k = 0; k < nt; k++) {
             const double angle = start_angle + k * L.angle_res;
             double r = (double)s_asum[k];
             r /= (double)(nq * YM_OCCUPIED);
             if (r >= (best - 0.1)) {
                 norm += r;
-                acc += ((angle - best_angle) * (angle - best_angle)) * r;
+                accv += ((angle - best_angle) * (angle - best_angle)) * r;
             }
         }
         if (norm > YM_KT_TOLERANCE) {
-            if (acc < YM_KT_TOLERANCE) acc = L.angle_res * L.angle_res;
-            acc /= norm;
+            if (accv < YM_KT_TOLERANCE) accv = L.angle_res * L.angle_res;
+            accv /= norm;
         } else {
-            acc = 1000 * (L.angle_res * L.angle_res);
+            accv = 1000 * (L.angle_res * L.angle_res);
         }
-        cov[8] = acc;
+        cov[8] = accv;
         response = best > 1.0 ? 1.0 : best;
     }
     if (tid == 0) {
@@ -788,6 +988,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
         st.status = status;
         if (a.host_out) a.host_out[b] = st;
     }
+    YM_STAMP(a, 17);
 }
 
 }  // namespace ym

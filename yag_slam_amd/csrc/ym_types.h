@@ -9,7 +9,9 @@
 #define YM_KT_PI 3.14159265358979323846
 #define YM_KT_2PI 6.28318530717958647692
 #define YM_CELL_NONE INT32_MIN
-#define YM_MAX_BEAMS 8192          // per scan; bounds the LDS staging of one scan
+#define YM_MAX_BEAMS 6000          // per scan; bounds the LDS staging of one scan (25 B per reading)
+#define YM_MAX_COARSE_NT 256         // coarse angles per pass (incl. response expansion)
+#define YM_MAX_FINE_NT 256           // fine angles
 #define YM_MAX_KERNEL_HALF 20      // sigma <= 10*res  ->  half = Round(2*sigma/res) <= 20
 
 // Grid geometry of one matcher configuration + the device window chosen for one call.

@@ -166,6 +166,11 @@ class ScanMatcher(object):
                                                    C.byref(n)))
         return buf[:n.value].copy()
 
+    def debug_stamps(self, enable=True):
+        buf = (C.c_uint64 * 32)()
+        _capi.check(self._lib.ym_debug_stamps(self._m, int(bool(enable)), buf, 32))
+        return list(buf)
+
     def profile(self, on=True):
         _capi.check(self._lib.ym_profile_enable(self._m, int(bool(on))))
 
