@@ -41,8 +41,8 @@ m.match_scan(nq, nb, True, True)
 m.match_scan(nq, nb, True, True)
 st = m.debug_stamps(False)
 t0 = st[0]
-names = ["prep:start","prep:points","prep:trig","prep:offsets","rast:start","rast:scan","rast:rowpass","rast:end",
-         "corr:start","corr:end","score:start","score:end","fin:start","fin:coarse","fin:foff","fin:fgather","fin:fties","fin:end"]
-names += ["", "", "base:points", "base:nxt", "base:chain", "base:cells", "ct:best", "ct:list", "ct:ties", "ct:tiesum", "ct:mean", "ct:covloop", "ct:covsum"]
+names = ["prep:start","prep:points","prep:trig","","rast:start","rast:scan","rast:rowpass","rast:end",
+         "corr:start","corr:end","score:start","score:end","fine:start","fine:coarse","fine:cells","fine:end",
+         "final:start","final:fties","prep:qend","final:end","base:points","base:nxt","base:chain","base:cells"]
 for n, v in zip(names, st):
     if n: print("%-14s %8.2f us" % (n, (v - t0) / 100.0))

@@ -153,7 +153,7 @@ struct ym_matcher {
     DevBuf<double2> qlocal;
     DevBuf<int2> cells;
     DevBuf<uint8_t> grid;
-    DevBuf<int32_t> offsets;   // coarse lookup tables
+    DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
     DevBuf<uint32_t> partial;  // per beam-chunk partial sums of the coarse lattice
@@ -385,7 +385,6 @@ int launch_call(ym_matcher *m, Slot &slot) {
     int chunk = (max_n + n_chunks - 1) / n_chunks;
     chunk = (chunk + 15) / 16 * 16;
     n_chunks = (max_n + chunk - 1) / chunk;
-    const int off_stride = n_chunks * chunk; // lookup rows are zero-padded to whole chunks
 
     const int nt_stride = lc.nt;
     const int dim_stride = std::max(lc.nx, lc.ny);
@@ -399,7 +398,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
-    if ((rc = m->offsets.ensure((size_t)B * nt_stride * off_stride))) return rc;
+    if ((rc = m->ctrig.ensure((size_t)B * nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
     if ((rc = m->partial.ensure((size_t)B * partial_stride + 16))) return rc;
@@ -443,9 +442,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
     {
         ym::PrepareArgs a;
         a.scans = d_scans; a.items = d_items; a.g = g; a.lat = lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
-        a.cells = m->cells.p; a.offsets = m->offsets.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
+        a.cells = m->cells.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
         a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.stamps = stamps;
-        a.off_stride = off_stride;
         a.use_inline = (B == 1 && nscans <= YM_INLINE_SCANS) ? 1 : 0;
         a.pad0 = 0;
         std::memset(&a.inl, 0, sizeof a.inl);
@@ -468,10 +466,9 @@ int launch_call(ym_matcher *m, Slot &slot) {
     // ---- K4 coarse correlate
     {
         ym::CorrArgs a;
-        a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.offsets = m->offsets.p;
-        a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = partial_stride;
+        a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.ctrig = m->ctrig.p;
+        a.qlocal = m->qlocal.p; a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = partial_stride;
         a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.chunk = chunk; a.n_chunks = n_chunks;
-        a.off_stride = off_stride;
         a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 grid_dim(job_blocks, lc.nt * n_chunks, B);
@@ -490,7 +487,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.probs = reinterpret_cast<unsigned long long *>(m->probs.p); a.probs_stride = (size_t)lc.nx * lc.ny;
         hipLaunchKernelGGL(ym::score_kernel, dim3(score_blocks, B), dim3(YM_SCORE_THREADS), 0, st, a);
     }
-    // ---- K6 finish (coarse tail + fine pass), results land in pinned host memory
+    // ---- K6a fine (coarse arg-max/mean + 3x3 fine lattice, one block per fine angle) and
+    // ---- K6b final (covariances, fine arg-max/mean); results land in pinned host memory
     {
         ym::FinishArgs a;
         a.g = g; a.lc = lc; a.lf = lf; a.refine = call.refine; a.max_n = max_n; a.nt_stride = lf.nt;
@@ -500,7 +498,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = grid_stride;
         a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
         a.fsums_stride = sums_f; a.stamps = stamps;
-        hipLaunchKernelGGL(ym::finish_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
+        hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
+        hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, ev_call))) return rc;
@@ -694,7 +693,7 @@ void ym_destroy(ym_matcher *m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->grid.release();
-    m->offsets.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
+    m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
     m->tmp_ranges_host.release(); m->stamps.release();
     for (Slot &s : m->slots) {

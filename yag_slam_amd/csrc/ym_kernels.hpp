@@ -43,8 +43,14 @@ __device__ inline double kt_normalize_angle_difference(double minuend, double su
     while (minuend - subtrahend > YM_KT_PI) minuend -= YM_KT_2PI;
     return minuend;
 }
+// (int)math::Round(v): half away from zero.  trunc(|v| + 0.5) with the sign restored is the same
+// integer as floor(v + 0.5) / ceil(v - 0.5) for every |v| < 2^31 and needs no floor/ceil pair.
+__device__ __forceinline__ int kt_round_int(double v) {
+    const int r = (int)(fabs(v) + 0.5);
+    return v < 0.0 ? -r : r;
+}
 __device__ __forceinline__ int world_to_grid(double w, double off, double scale) {
-    return (int)kt_round((w - off) * scale);
+    return kt_round_int((w - off) * scale);
 }
 
 // ------------------------------------------------------------------ block helpers
@@ -173,11 +179,10 @@ struct PrepareArgs {
     YmItemState *states;
     double2 *qlocal;         // [B][max_n]
     int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
-    int32_t *offsets;        // [B][nt_stride][max_n] coarse lookup table
+    double2 *ctrig;          // [B][nt_stride] (cos, sin) of every coarse angle
     int32_t *hypcell;        // [B][2][dim_stride]
     double *probs;           // [B][ny*nx] cleared here, filled by score_kernel
     int32_t max_n, max_base, nt_stride, dim_stride;
-    int32_t off_stride;      // entries per angle in `offsets` (>= max_n, multiple of the correlate unroll)
     unsigned long long *stamps;
 };
 
@@ -186,7 +191,6 @@ struct PrepareArgs {
 __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int wave_counts[YM_PREP_THREADS / 64];
-    __shared__ double s_cos[YM_MAX_COARSE_NT], s_sin[YM_MAX_COARSE_NT];
     constexpr int NT = YM_PREP_THREADS;
     YM_STAMP(a, 0);
     const int tid = threadIdx.x;
@@ -194,7 +198,11 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     const YmItem it = a.use_inline ? a.inl.item : a.items[b];
     const bool is_query = blockIdx.x == 0;
     const int slot = (int)blockIdx.x - 1;
-    if (!is_query && slot >= it.base_count) return;
+    if (!is_query && slot >= it.base_count) { // unused chain slot: no points
+        int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
+        for (int i = threadIdx.x; i < a.max_n; i += YM_PREP_THREADS) cells[i] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+        return;
+    }
     const int si = is_query ? it.query : it.base_begin + slot;
     const YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
     const YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
@@ -262,27 +270,14 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
                 l = make_double2(cr * dx + (0.0 - sn) * dy, sn * dx + cr * dy);
             }
             ql[i] = l;
-            sx[i] = l.x; // keep the local points in LDS for the lookup table below
-            sy[i] = l.y;
         }
-        __syncthreads();
-        // coarse lookup table (GridIndexLookup::ComputeOffsets), centre heading = query heading
-        const double start_angle = sr.pose[2] - a.lat.angle_off;
-        int32_t *offs = a.offsets + (size_t)b * a.nt_stride * a.off_stride;
-        if (tid < a.lat.nt) { // one fp64 sin/cos per angle, shared through LDS
-            const double angle = start_angle + tid * a.lat.angle_res;
-            s_cos[tid] = cos(angle);
-            s_sin[tid] = sin(angle);
+        // one fp64 sin/cos per coarse angle (GridIndexLookup::ComputeOffsets); the cell offsets
+        // themselves are computed by the correlate blocks that consume them
+        if (tid < a.lat.nt) {
+            const double angle = (sr.pose[2] - a.lat.angle_off) + tid * a.lat.angle_res;
+            a.ctrig[(size_t)b * a.nt_stride + tid] = make_double2(cos(angle), sin(angle));
         }
-        __syncthreads();
         YM_STAMP(a, 2);
-        // entries past the last point are 0 so that the correlate kernel may load them unmasked
-        for (int w = tid; w < a.lat.nt * a.off_stride; w += NT) {
-            const int k = w / a.off_stride, i = w - k * a.off_stride;
-            offs[(size_t)k * a.off_stride + i] =
-                i < np ? lookup_offset(make_double2(sx[i], sy[i]), s_cos[k], s_sin[k], off_x, off_y, a.g.scale, a.g.pitch) : 0;
-        }
-        YM_STAMP(a, 3);
         for (int i = tid; i < a.lat.nx * a.lat.ny; i += NT) a.probs[(size_t)b * a.lat.nx * a.lat.ny + i] = 0.0;
         // coarse hypothesis cells + regularity flag
         int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
@@ -290,13 +285,15 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
         for (int i = tid; i < a.lat.nx; i += NT) cx[i] = hyp_cell(sr.pose[0], -a.lat.off_x, i, a.lat.step_x, off_x, a.g);
         for (int i = tid; i < a.lat.ny; i += NT) cy[i] = hyp_cell(sr.pose[1], -a.lat.off_y, i, a.lat.step_y, off_y, a.g);
         __syncthreads();
-        if (tid == 0) {
-            const int stx = (int)kt_round(a.lat.step_x * a.g.scale), sty = (int)kt_round(a.lat.step_y * a.g.scale);
-            int reg = 1;
-            for (int i = 1; i < a.lat.nx; i++) reg &= (cx[i] == cx[0] + i * stx);
-            for (int i = 1; i < a.lat.ny; i++) reg &= (cy[i] == cy[0] + i * sty);
-            a.states[b].regular[0] = reg;
+        {
+            const int stx = kt_round_int(a.lat.step_x * a.g.scale), sty = kt_round_int(a.lat.step_y * a.g.scale);
+            int ok = 1;
+            for (int i = tid; i < a.lat.nx; i += NT) ok &= (cx[i] == cx[0] + i * stx);
+            for (int i = tid; i < a.lat.ny; i += NT) ok &= (cy[i] == cy[0] + i * sty);
+            ok = __syncthreads_and(ok);
+            if (tid == 0) a.states[b].regular[0] = ok;
         }
+        YM_STAMP(a, 18);
         return;
     }
 
@@ -380,9 +377,9 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
 }
 
 // ================================================================== K2 raster
-#define YM_TILE_W 128
-#define YM_TILE_H 64
-#define YM_RASTER_THREADS 1024
+#define YM_TILE_W 64
+#define YM_TILE_H 32
+#define YM_RASTER_THREADS 256
 struct RasterArgs {
     const int2 *cells;
     const YmItemState *states;
@@ -394,7 +391,7 @@ struct RasterArgs {
     unsigned long long *stamps;
 };
 
-// grid (tiles_x, tiles_y, B), 1024 threads.  Each block owns one 128x64 tile of the window and
+// grid (tiles_x, tiles_y, B), 256 threads.  Each block owns one 64x32 tile of the window and
 // writes every byte of it exactly once (so no separate clear pass exists).  Karto's SmearPoint
 // max-stamps a (2h+1)^2 kernel at every occupied cell; the kernel value depends only on the squared
 // cell distance and never grows with it (checked on the host when the matcher is created), so a
@@ -403,7 +400,8 @@ struct RasterArgs {
 //   column pass m(y, x) = min over |dy| <= h of dy^2 + g(y+dy, x)^2        (8 cells per lane)
 __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a) {
     constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF, NT = YM_RASTER_THREADS;
-    constexpr int RW = 4;  // 64-bit words per bitmap row: TW + 2*HM = 168 bits, + 1 word so a funnel read never leaves the row
+    constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
+    constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
     __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
     __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
     __shared__ unsigned char lut[2 * HM * HM + 8];
@@ -416,11 +414,11 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
     for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
     __syncthreads();
-    const int total = a.states[b].base_count * a.max_n;
+    const int total = a.max_base * a.max_n; // unused slots hold NONE
     const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = tid; i < total; i += NT) {
         const int2 c = cells[i];
         const int lx = c.x - (tx0 - h), ly = c.y - (ty0 - h);
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     YM_STAMP(a, 5);
     uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
     // thread -> 8 consecutive cells of one tile row
-    const int y = tid >> 4, x8 = (tid & 15) * 8;
+    const int y = tid / LPR, x8 = (tid % LPR) * 8;
     const bool row_ok = (ty0 + y) < a.g.win_w;
     uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
     if (!any) {
@@ -485,12 +483,13 @@ struct CorrArgs {
     YmLattice lat;
     const uint8_t *grid;
     size_t grid_stride;
-    const int32_t *offsets;
+    const double2 *ctrig;   // [B][nt_stride] (cos, sin) per coarse angle
+    const double2 *qlocal;  // [B][max_n] query points in the sensor frame
     const int32_t *hypcell;
     const YmItemState *states;
     uint32_t *partial;     // [B][n_chunks][nt][ny][nx_pad]
     size_t partial_stride; // per item
-    int32_t max_n, nt_stride, dim_stride, off_stride;
+    int32_t max_n, nt_stride, dim_stride;
     int32_t chunk;         // beams per chunk (multiple of 16, <= 512 keeps the 16-bit lanes from overflowing)
     int32_t n_chunks;
     int32_t ngx;           // x groups per row = ceil(nx / G)
@@ -503,8 +502,10 @@ struct CorrArgs {
 // steps 2 cells (coarse search), 16 when it steps 1.  For every beam of its chunk the lane loads
 // the 16 grid bytes that hold those hypotheses' cells (row segment start + wave-uniform beam
 // offset) and accumulates them in 16-bit lanes.  No cross-lane reduction; partial sums per beam
-// chunk are added up by score_kernel.  The loads of a chunk are issued 16 beams at a time without
-// waiting for the point count: table entries past the last beam are 0 and are masked by a scalar.
+// chunk are added up by score_kernel.  Each block first builds the cell offsets of its own beam
+// chunk in LDS (GridIndexLookup::ComputeOffsets for one angle: rotate the sensor-frame point,
+// WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are issued 16 beams at a
+// time; entries past the last beam are 0 and are masked by a scalar.
 // grid (ceil(ny*ngx / 256), nt * n_chunks, B).
 template <int SX>
 __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
@@ -514,19 +515,29 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     const int b = blockIdx.z;
     const int k = blockIdx.y % a.lat.nt, chunk = blockIdx.y / a.lat.nt;
     const int job = blockIdx.x * YM_CORR_THREADS + threadIdx.x;
+    __shared__ int offs[512];
     YM_STAMP(a, 8);
     const int njobs = a.lat.ny * a.ngx;
-    if (job >= njobs) return;
-    const int iy = job / a.ngx, xg = job - iy * a.ngx;
     const YmItemState &st = a.states[b];
     const int nq = st.nq;
     const int regular = st.regular[0];
     const int i0 = chunk * a.chunk;
+    {
+        const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
+        const double off_x = st.off_x, off_y = st.off_y;
+        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        for (int c = threadIdx.x; c < a.chunk; c += YM_CORR_THREADS) {
+            const int i = i0 + c;
+            offs[c] = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) : 0;
+        }
+    }
+    __syncthreads();
+    if (job >= njobs) return;
+    const int iy = job / a.ngx, xg = job - iy * a.ngx;
     const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
     const int32_t *cy = cx + a.dim_stride;
     const int cyv = cy[iy], cx0 = cx[0];
     const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
-    const int32_t *__restrict__ offs = a.offsets + ((size_t)b * a.nt_stride + k) * a.off_stride;
     uint32_t *out = a.partial + (size_t)b * a.partial_stride +
                     (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
 
@@ -535,13 +546,13 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
         uint32_t acc[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; j++) acc[j] = 0u;
-        for (int i = i0; i < i0 + a.chunk; i += U) {
+        for (int c = 0; c < a.chunk; c += U) {
             uint4 w[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], grid + (uint32_t)(lane_off + (uint32_t)offs[i + u]), 16);
+            for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], grid + (uint32_t)(lane_off + (uint32_t)offs[c + u]), 16);
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t m = (i + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
+                const uint32_t m = (i0 + c + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
                 if (SX == 2) {
                     acc[0] += w[u].x & m; acc[1] += w[u].y & m; acc[2] += w[u].z & m; acc[3] += w[u].w & m;
                 } else {
@@ -569,13 +580,13 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     } else {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
-        const int i1 = min(nq, i0 + a.chunk);
+        const int n_here = min(nq - i0, a.chunk);
         for (int j = 0; j < G; j++) {
             const int ix = xg * G + j;
             unsigned sum = 0;
             if (ix < a.lat.nx) {
                 const int base = cyv * a.g.pitch + cx[ix];
-                for (int i = i0; i < i1; i++) {
+                for (int i = 0; i < n_here; i++) {
                     const unsigned idx = (unsigned)(base + offs[i]);
                     sum += idx < limit ? grid[idx] : 0u;
                 }
@@ -709,20 +720,161 @@ __device__ __forceinline__ void tie_accumulate(double (&acc)[5], const YmLattice
     acc[4] += 1.0;
 }
 
-// grid (B), 1024 threads: everything after the coarse responses, one block per item.
-__global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a) {
-    constexpr int NT = YM_FINISH_THREADS;
+// Coarse tail of CorrelateScan for one item: best response, mean of all hypotheses with
+// DoubleEqual(response, best).  Runs redundantly in every block that needs the coarse mean.
+// Returns best (unclamped); mean[] and *status valid in every thread.
+template <int NT>
+__device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const double *resp, const double *bm,
+                                                       int n_blocks, const double pose[3], double mean[3], int *status,
+                                                       double *scratch /* >= 80 */, int *s_list /* NT */, int *s_nlist) {
+    const int tid = threadIdx.x;
+    const int nh = L.nx * L.ny * L.nt;
+    const double start_angle = pose[2] - L.angle_off;
+    if (tid == 0) *s_nlist = 0;
+    double lb = -1.0;
+    for (int i = tid; i < n_blocks; i += NT) { const double v = bm[i]; lb = v > lb ? v : lb; }
+    const double best = block_reduce(lb, OpMaxD(), -1.0, scratch);
+    // score blocks that can hold a hypothesis with DoubleEqual(response, best)
+    int overflow = 0;
+    for (int i = tid; i < n_blocks; i += NT)
+        if (bm[i] >= best - YM_KT_TOLERANCE) {
+            const int at = atomicAdd(s_nlist, 1);
+            if (at < NT) s_list[at] = i; else overflow = 1;
+        }
+    overflow = __syncthreads_or(overflow);
+    double acc[5] = {0, 0, 0, 0, 0};
+    if (!overflow) {
+        const int nlist = *s_nlist;
+        for (int w = tid; w < nlist * YM_SCORE_THREADS; w += NT) {
+            const int h = s_list[w / YM_SCORE_THREADS] * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
+            if (h < nh && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+        }
+    } else {
+        for (int h = tid; h < nh; h += NT)
+            if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+    }
+    block_sum_vec<5>(acc, scratch);
+    if (acc[4] > 0.0) {
+        const double cnt = acc[4]; // exact small integer, same value as Karto's int count
+        mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
+        mean[2] = atan2(acc[3] / cnt, acc[2] / cnt);
+    } else {
+        mean[0] = mean[1] = mean[2] = 0.0;
+        *status = -5; // "Unable to find best position"
+    }
+    return best;
+}
+
+// ---- K6a fine: grid (max(nt_f,1), B), 256 threads.  Block k scores the 3x3 fine lattice for fine angle k.
+#define YM_FINE_THREADS 256
+__global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
+    constexpr int NT = YM_FINE_THREADS;
     __shared__ double scratch[16 * 5];
-    __shared__ unsigned s_fsum[YM_MAX_FINE_HYP];
-    __shared__ double s_fresp[YM_MAX_FINE_HYP];
-    __shared__ int s_cx[64], s_cy[64];
-    __shared__ unsigned s_asum[YM_MAX_FINE_NT];
-    __shared__ double s_cos[YM_MAX_FINE_NT], s_sin[YM_MAX_FINE_NT];
     __shared__ int s_list[NT];
     __shared__ int s_nlist;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ double s_cs[2];
+    __shared__ int s_cx[64], s_cy[64];
+    __shared__ unsigned s_sum[YM_MAX_FINE_HYP];
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     YM_STAMP(a, 12);
+    YmItemState &st = a.states[b];
+    const int nq = st.nq;
+    if (nq == 0) return;
+    const double pose[3] = {st.pose[0], st.pose[1], st.pose[2]};
+    const double off_x = st.off_x, off_y = st.off_y;
+    double mean[3];
+    int status = 0;
+    const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride,
+                                                 a.blockmax + (size_t)b * a.n_blocks, a.n_blocks, pose, mean, &status,
+                                                 scratch, s_list, &s_nlist);
+    if (k == 0 && tid == 0) { // hand the coarse result to final_kernel
+        st.center[0] = mean[0]; st.center[1] = mean[1]; st.center[2] = mean[2];
+        st.coarse_response = best; // unclamped
+        st.status = status;
+    }
+    YM_STAMP(a, 13);
+    if (!a.refine) return;
+
+    const YmLattice &L = a.lf;
+    const int nx = L.nx, ny = L.ny, nxy = nx * ny;
+    const double start_x = -L.off_x, start_y = -L.off_y;
+    if (tid == 0) {
+        const double angle = (mean[2] - L.angle_off) + k * L.angle_res;
+        s_cs[0] = cos(angle);
+        s_cs[1] = sin(angle);
+    }
+    for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(mean[0], start_x, i, L.step_x, off_x, a.g);
+    for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(mean[1], start_y, i, L.step_y, off_y, a.g);
+    for (int h = tid; h < nxy; h += NT) s_sum[h] = 0u;
+    __syncthreads();
+    YM_STAMP(a, 14);
+    const double cosine = s_cs[0], sine = s_cs[1];
+    const uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
+    const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+    int32_t *foff = a.foffsets + ((size_t)b * a.nt_stride + k) * a.max_n;
+    const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+    const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
+                        s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
+    if (block3) {
+        // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its beam
+        // as three 4-byte words.
+        const uint32_t base0 = (uint32_t)(s_cy[0] * a.g.pitch + s_cx[0]);
+        unsigned acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < nq; i += 4 * NT) {
+            uint32_t w[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ii = i + u * NT;
+                int off = 0;
+                if (ii < nq) {
+                    off = lookup_offset(ql[ii], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+                    foff[ii] = off;
+                }
+                const uint32_t idx = base0 + (uint32_t)off;
+#pragma unroll
+                for (int r = 0; r < 3; r++) __builtin_memcpy(&w[u][r], grid + (uint32_t)(idx + r * a.g.pitch), 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t m = (i + u * NT) < nq ? 0xffu : 0u;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    acc[3 * r] += w[u][r] & m; acc[3 * r + 1] += (w[u][r] >> 8) & m; acc[3 * r + 2] += (w[u][r] >> 16) & m;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[j] = wave_reduce(acc[j], OpAddU());
+        if (lane == 0)
+#pragma unroll
+            for (int j = 0; j < 9; j++) atomicAdd(&s_sum[j], acc[j]);
+    } else {
+        // generic lattice: per beam, every (iy, ix) cell
+        for (int i = tid; i < nq; i += NT) {
+            const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+            foff[i] = off;
+            for (int c = 0; c < nxy; c++) {
+                const int iy = c / nx, ix = c - iy * nx;
+                const unsigned idx = (unsigned)(s_cy[iy] * a.g.pitch + s_cx[ix] + off);
+                if (idx < limit) atomicAdd(&s_sum[c], (unsigned)grid[idx]);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride + (size_t)k * nxy;
+    for (int h = tid; h < nxy; h += NT) fs[h] = s_sum[h];
+    YM_STAMP(a, 15);
+}
+
+// ---- K6b final: grid (B), 1024 threads: positional covariance, fine arg-max / mean, angular covariance.
+__global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) {
+    constexpr int NT = YM_FINISH_THREADS;
+    __shared__ double scratch[16 * 5];
+    __shared__ double s_fresp[YM_MAX_FINE_HYP];
+    __shared__ unsigned s_asum[YM_MAX_FINE_NT];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63;
+    YM_STAMP(a, 16);
     YmItemState &st = a.states[b];
     const int nq = st.nq;
     if (nq == 0) {
@@ -742,55 +894,16 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
     const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
     const double off_x = st.off_x, off_y = st.off_y;
     double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    double mean[3] = {0, 0, 0};
-    int status = 0;
-    double best;
+    double mean[3] = {st.center[0], st.center[1], st.center[2]}; // coarse mean (fine_kernel, block 0)
+    double best = st.coarse_response;                             // coarse best, unclamped
+    int status = st.status;
 
-    // ------------------------------------------------------------- coarse tail
+    // ------------------------------------------------------------- ComputePositionalCovariance
     {
         const YmLattice &L = a.lc;
-        const int nx = L.nx, nxy = nx * L.ny, nh = nxy * L.nt;
-        const double cxw = st.pose[0], cyw = st.pose[1], ct = st.pose[2];
-        const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
-        const double *resp = a.resp + (size_t)b * a.sums_stride;
-        const double *bm = a.blockmax + (size_t)b * a.n_blocks;
-        if (tid == 0) s_nlist = 0;
-        double lb = -1.0;
-        for (int i = tid; i < a.n_blocks; i += NT) { const double v = bm[i]; lb = v > lb ? v : lb; }
-        best = block_reduce(lb, OpMaxD(), -1.0, scratch);
-        YM_STAMP(a, 24);
-        // score blocks that can hold a hypothesis with DoubleEqual(response, best)
-        int overflow = 0;
-        for (int i = tid; i < a.n_blocks; i += NT)
-            if (bm[i] >= best - YM_KT_TOLERANCE) {
-                const int at = atomicAdd(&s_nlist, 1);
-                if (at < NT) s_list[at] = i; else overflow = 1;
-            }
-        overflow = __syncthreads_or(overflow);
-        YM_STAMP(a, 25);
-        double acc[5] = {0, 0, 0, 0, 0};
-        if (!overflow) {
-            const int nlist = s_nlist;
-            for (int w = tid; w < nlist * YM_SCORE_THREADS; w += NT) {
-                const int h = s_list[w / YM_SCORE_THREADS] * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
-                if (h < nh && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
-            }
-        } else {
-            for (int h = tid; h < nh; h += NT)
-                if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
-        }
-        YM_STAMP(a, 26);
-        block_sum_vec<5>(acc, scratch);
-        YM_STAMP(a, 27);
-        if (acc[4] > 0.0) {
-            const double cnt = acc[4]; // exact small integer, same value as Karto's int count
-            mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
-            mean[2] = atan2(acc[3] / cnt, acc[2] / cnt);
-        } else {
-            status = -5; // "Unable to find best position"
-        }
-        YM_STAMP(a, 28);
-        // ComputePositionalCovariance over the per-(x,y) maxima
+        const int nx = L.nx, nxy = nx * L.ny;
+        const double cxw = st.pose[0], cyw = st.pose[1];
+        const double start_x = -L.off_x, start_y = -L.off_y;
         double sums[4] = {0, 0, 0, 0};
         const double dx = mean[0] - cxw, dy = mean[1] - cyw;
         if (!(best < YM_KT_TOLERANCE)) {
@@ -807,9 +920,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
                 }
             }
         }
-        YM_STAMP(a, 29);
         block_sum_vec<4>(sums, scratch);
-        YM_STAMP(a, 30);
         if (best < YM_KT_TOLERANCE) {
             cov[0] = YM_MAX_VARIANCE; cov[4] = YM_MAX_VARIANCE;
             cov[8] = 4 * (L.angle_res * L.angle_res);
@@ -832,98 +943,23 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
     }
     const double coarse_response = best > 1.0 ? 1.0 : best;
     double response = coarse_response;
-    YM_STAMP(a, 13);
 
-    // ------------------------------------------------------------- fine pass (CorrelateScan, doingFineMatch)
+    // ------------------------------------------------------------- fine tail (CorrelateScan, doingFineMatch)
     if (a.refine) {
         const YmLattice &L = a.lf;
         const int nx = L.nx, ny = L.ny, nt = L.nt, nxy = nx * ny, nh = nxy * nt;
         const double cxw = mean[0], cyw = mean[1], ct = mean[2];
         const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
-        int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
-        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
-        if (tid < nt) { // one fp64 sin/cos per angle, shared through LDS
-            const double angle = start_angle + tid * L.angle_res;
-            s_cos[tid] = cos(angle);
-            s_sin[tid] = sin(angle);
-        }
-        for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(cxw, start_x, i, L.step_x, off_x, a.g);
-        for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g);
-        for (int h = tid; h < nh; h += NT) s_fsum[h] = 0u;
-        __syncthreads();
-        YM_STAMP(a, 14);
-        // lookup table around the coarse mean heading (all threads, one (angle, beam) pair each)
-        for (int w = tid; w < nt * nq; w += NT) {
-            const int k = w / nq, i = w - k * nq;
-            foff[(size_t)k * a.max_n + i] = lookup_offset(ql[i], s_cos[k], s_sin[k], off_x, off_y, a.g.scale, a.g.pitch);
-        }
-        __syncthreads();
-        const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
-                            s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
-        // thread groups of GS lanes share one angle; lanes stride over the beams
-        const int GS = 64 * max(1, (NT / 64) / nt);
-        if (block3) {
-            // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its
-            // beam as three 4-byte words.
-            const uint32_t base0 = (uint32_t)(s_cy[0] * a.g.pitch + s_cx[0]);
-            for (int k = tid / GS; k < nt; k += NT / GS) {
-                const int32_t *offs = foff + (size_t)k * a.max_n;
-                unsigned acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = tid % GS; i < nq; i += 4 * GS) {
-                    uint32_t w[4][3];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int ii = i + u * GS;
-                        const uint32_t idx = base0 + (uint32_t)(ii < nq ? offs[ii] : 0);
-#pragma unroll
-                        for (int r = 0; r < 3; r++) __builtin_memcpy(&w[u][r], grid + (uint32_t)(idx + r * a.g.pitch), 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t m = (i + u * GS) < nq ? 0xffu : 0u;
-#pragma unroll
-                        for (int r = 0; r < 3; r++) {
-                            acc[3 * r] += w[u][r] & m; acc[3 * r + 1] += (w[u][r] >> 8) & m; acc[3 * r + 2] += (w[u][r] >> 16) & m;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 9; j++) acc[j] = wave_reduce(acc[j], OpAddU());
-                if (lane == 0)
-#pragma unroll
-                    for (int j = 0; j < 9; j++) atomicAdd(&s_fsum[k * 9 + j], acc[j]);
-            }
-        } else {
-            // generic gather-reduce: work item = (hypothesis, beam segment)
-            const int nseg = max(1, min(NT / max(nh, 1), (nq + 31) / 32));
-            const int seg = (nq + nseg - 1) / nseg;
-            for (int w = tid; w < nh * nseg; w += NT) {
-                const int h = w % nh, s = w / nh;
-                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
-                const int base = s_cy[iy] * a.g.pitch + s_cx[ix];
-                const int32_t *offs = foff + (size_t)k * a.max_n;
-                const int e = min(nq, (s + 1) * seg);
-                unsigned sum = 0;
-#pragma unroll 8
-                for (int i = s * seg; i < e; i++) {
-                    const unsigned idx = (unsigned)(base + offs[i]);
-                    sum += idx < limit ? grid[idx] : 0u;
-                }
-                atomicAdd(&s_fsum[h], sum);
-            }
-        }
-        __syncthreads();
-        YM_STAMP(a, 15);
+        const uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride;
         double lb = -1.0;
-        uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride;
         for (int h = tid; h < nh; h += NT) {
             const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
             const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-            const double r = hyp_response(a.g, L.penalize, s_fsum[h], nq, x * x + y * y, start_angle + k * L.angle_res, ct);
+            const double r = hyp_response(a.g, L.penalize, fs[h], nq, x * x + y * y, start_angle + k * L.angle_res, ct);
             s_fresp[h] = r;
-            fs[h] = s_fsum[h];
             lb = r > lb ? r : lb;
         }
+        for (int k = tid; k < nt; k += NT) s_asum[k] = 0u;
         best = block_reduce(lb, OpMaxD(), -1.0, scratch);
         double acc[5] = {0, 0, 0, 0, 0};
         for (int h = tid; h < nh; h += NT)
@@ -936,14 +972,14 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
         } else {
             status = -5;
         }
-        YM_STAMP(a, 16);
+        YM_STAMP(a, 17);
         // ComputeAngularCovariance: re-score every fine angle at the cell of the mean pose
         const double best_angle = kt_normalize_angle_difference(mean[2], ct);
         const int gx = world_to_grid(mean[0], off_x, a.g.scale) + a.g.border - a.g.win_origin;
         const int gy = world_to_grid(mean[1], off_y, a.g.scale) + a.g.border - a.g.win_origin;
         const int base = gy * a.g.pitch + gx;
-        for (int k = tid; k < nt; k += NT) s_asum[k] = 0u;
-        __syncthreads();
+        const int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
+        const int GS = 64 * max(1, (NT / 64) / nt); // lanes that share one angle
         for (int k = tid / GS; k < nt; k += NT / GS) {
             const int32_t *offs = foff + (size_t)k * a.max_n;
             unsigned sum = 0;
@@ -988,7 +1024,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void finish_kernel(FinishArgs a)
         st.status = status;
         if (a.host_out) a.host_out[b] = st;
     }
-    YM_STAMP(a, 17);
+    YM_STAMP(a, 19);
 }
 
 }  // namespace ym
