@@ -13,7 +13,7 @@
  *   ym_match_scans                Wrapper.match_scan(query._scan, [b._scan ...], penalty, do_fine)
  *                                 /root/reference/yag_slam/scan_matching.py:40-42, /root/reference/test.py:38
  *   ym_match                      same call, for callers that hold plain range arrays (no resident scan)
- *   ym_match_batch                the serial chain loop of GraphSlam.try_to_close_loop
+ *   ym_match_batch, ym_batch_*    the serial chain loop of GraphSlam.try_to_close_loop
  *                                 /root/reference/yag_slam/graph_slam.py:217-236 (one query, many chains)
  *   ym_result                     the returned object's .response / .covariance / .best_pose
  *                                 /root/reference/yag_slam/scan_matching.py:42, /root/reference/test.py:39-41
@@ -132,15 +132,24 @@ int ym_wait(ym_matcher *m, int slot, ym_result *out);
 
 /* One query against n_chains candidate chains; chain c = scans[chain_offsets[c] .. chain_offsets[c+1]).
  * per_chain (nullable) receives every chain's result; best/best_chain (nullable) the arg-max over
- * response, ties to the lowest chain index.  If dev_key_out (nullable, DEVICE pointer to 4 x int64)
- * is given, the packed sortable key {response bits, ~global chain id} and the winner's pose bits are
- * also left on the device for an RCCL max-reduce across ranks (chain ids offset by chain_id_base). */
+ * response, ties to the lowest chain index. */
 int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans,
                    const int32_t *chain_offsets, int n_chains, int penalize, int refine,
                    ym_result *per_chain, ym_result *best, int32_t *best_chain);
-int ym_match_batch_async(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans,
-                         const int32_t *chain_offsets, int n_chains, int penalize, int refine,
-                         int64_t chain_id_base, void *dev_key_out);
+
+/* The same as a reusable object + pipelined run.  A batch only remembers WHICH scans form the chains;
+ * poses are read from the scans at every run.  If dev_best_out (nullable, DEVICE pointer to 8
+ * doubles) is given, {response, chain_id_base + best chain, x, y, heading, cov_xx, cov_yy, cov_tt} of
+ * the best chain is also left on the device, stream-ordered, as the payload of a cross-rank
+ * arg-max (RCCL all-gather of one such record per rank). */
+typedef struct ym_batch ym_batch;
+ym_batch *ym_batch_create(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans,
+                          const int32_t *chain_offsets, int n_chains);
+void ym_batch_destroy(ym_batch *b);
+int ym_batch_size(const ym_batch *b);
+int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refine, int slot,
+                       int64_t chain_id_base, void *dev_best_out);
+int ym_batch_wait(ym_matcher *m, int slot, ym_result *per_chain, ym_result *best, int32_t *best_chain);
 
 /* ---- introspection for parity tests (state of the LAST completed synchronous match) ---- */
 typedef struct ym_grid_info {

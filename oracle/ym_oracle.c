@@ -455,13 +455,13 @@ static double k_correlate(orc_ctx *c, const double center[3], double off_x, doub
     int bad_index = 0;
 
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(g->threads) schedule(static) if (g->threads > 1)
+#pragma omp parallel for collapse(2) num_threads(g->threads) schedule(static) if (g->threads > 1)
 #endif
     for (int iy = 0; iy < ny; iy++) {
-        double y = start_y + iy * step_y;
-        double new_y = center[1] + y;
-        double sq_y = y * y;
         for (int ix = 0; ix < nx; ix++) {
+            double y = start_y + iy * step_y;
+            double new_y = center[1] + y;
+            double sq_y = y * y;
             double x = start_x + ix * step_x;
             double new_x = center[0] + x;
             double sq_x = x * x;

@@ -17,7 +17,8 @@ EXPORTS = (
     "ym_version", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
     "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scan_get_pose",
     "ym_scan_size", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_async_slots",
-    "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_match_batch_async", "ym_debug_grid_info",
+    "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
+    "ym_batch_run_async", "ym_batch_wait", "ym_debug_grid_info",
     "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_stamps",
     "ym_profile_enable",
     "ym_profile_read",
@@ -131,7 +132,13 @@ def lib():
     L.ym_wait.argtypes = [vp, C.c_int, C.POINTER(YmResult)]
     L.ym_match_batch.argtypes = [vp, vp, C.POINTER(vp), ip, C.c_int, C.c_int, C.c_int, C.POINTER(YmResult),
                                  C.POINTER(YmResult), ip]
-    L.ym_match_batch_async.argtypes = [vp, vp, C.POINTER(vp), ip, C.c_int, C.c_int, C.c_int, C.c_int64, vp]
+    L.ym_batch_create.restype = vp
+    L.ym_batch_create.argtypes = [vp, vp, C.POINTER(vp), ip, C.c_int]
+    L.ym_batch_destroy.argtypes = [vp]
+    L.ym_batch_destroy.restype = None
+    L.ym_batch_size.argtypes = [vp]
+    L.ym_batch_run_async.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]
+    L.ym_batch_wait.argtypes = [vp, C.c_int, C.POINTER(YmResult), C.POINTER(YmResult), ip]
     L.ym_debug_grid_info.argtypes = [vp, C.c_int, C.POINTER(YmGridInfo)]
     L.ym_debug_grid.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int64]
     L.ym_debug_sums.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int64]

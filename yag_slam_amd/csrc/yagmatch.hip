@@ -121,6 +121,7 @@ struct Slot {
     YmLattice coarse{}, fine{};
     int n_items = 0;
     int64_t chain_id_base = 0;
+    void *dev_best_out = nullptr; // optional device buffer (8 doubles) for the cross-rank arg-max
 };
 
 struct ProfEvents {
@@ -141,6 +142,12 @@ struct ym_scan {
     double max_valid_karto, max_valid_yagpy;
 };
 
+struct ym_batch {
+    const ym_scan *query;
+    std::vector<const ym_scan *> scans;
+    std::vector<int32_t> offsets;
+};
+
 struct ym_matcher {
     ym_config cfg;
     int device;
@@ -152,6 +159,7 @@ struct ym_matcher {
     DevBuf<YmItemState> states;
     DevBuf<double2> qlocal;
     DevBuf<int2> cells;
+    DevBuf<int4> bbox;
     DevBuf<uint8_t> grid;
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
@@ -397,6 +405,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if ((rc = m->states.ensure(B))) return rc;
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
+    if ((rc = m->bbox.ensure((size_t)B * max_base * ((max_n + 63) / 64)))) return rc;
     if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
@@ -442,7 +451,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     {
         ym::PrepareArgs a;
         a.scans = d_scans; a.items = d_items; a.g = g; a.lat = lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
-        a.cells = m->cells.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
+        a.cells = m->cells.p; a.bbox = m->bbox.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
         a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.stamps = stamps;
         a.use_inline = (B == 1 && nscans <= YM_INLINE_SCANS) ? 1 : 0;
         a.pad0 = 0;
@@ -457,7 +466,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     // ---- K2 raster
     {
         ym::RasterArgs a;
-        a.cells = m->cells.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
+        a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
         a.grid_stride = grid_stride; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
         if ((rc = prof_begin(m, 1, &ev_k))) return rc;
         hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
@@ -501,6 +510,9 @@ int launch_call(ym_matcher *m, Slot &slot) {
         hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
         hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
+    if (slot.dev_best_out)
+        hipLaunchKernelGGL(ym::argbest_kernel, dim3(1), dim3(256), 0, st, m->states.p, B, (long long)slot.chain_id_base,
+                           reinterpret_cast<double *>(slot.dev_best_out));
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, ev_call))) return rc;
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
@@ -692,7 +704,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->grid.release();
+    m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
     m->tmp_ranges_host.release(); m->stamps.release();
@@ -864,43 +876,83 @@ int ym_wait(ym_matcher *m, int slot_idx, ym_result *out) {
     return YM_OK;
 }
 
-int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
-                   int n_chains, int penalize, int refine, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
-    if (!m || !query || !chain_offsets) return set_err(YM_ERR_INVALID, "null argument");
-    if (n_chains <= 0) return set_err(YM_ERR_INVALID, "n_chains must be > 0");
+ym_batch *ym_batch_create(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
+                          int n_chains) {
+    if (!m || !query || !chain_offsets) { set_err(YM_ERR_INVALID, "null argument"); return nullptr; }
+    if (n_chains <= 0) { set_err(YM_ERR_INVALID, "n_chains must be > 0"); return nullptr; }
     const int n_scans = chain_offsets[n_chains];
-    if (n_scans < 0 || (n_scans > 0 && !scans)) return set_err(YM_ERR_INVALID, "bad scan list");
-    Call call;
+    if (chain_offsets[0] != 0 || n_scans < 0 || (n_scans > 0 && !scans)) { set_err(YM_ERR_INVALID, "bad scan list"); return nullptr; }
+    for (int c = 0; c < n_chains; c++)
+        if (chain_offsets[c + 1] < chain_offsets[c]) { set_err(YM_ERR_INVALID, "chain_offsets must be non-decreasing"); return nullptr; }
+    if (query->device != m->device) { set_err(YM_ERR_INVALID, "query scan lives on another device"); return nullptr; }
+    for (int i = 0; i < n_scans; i++)
+        if (!scans[i] || scans[i]->device != m->device) { set_err(YM_ERR_INVALID, "scan %d is null or lives on another device", i); return nullptr; }
+    ym_batch *b = new ym_batch();
+    b->query = query;
+    b->scans.assign(scans, scans + n_scans);
+    b->offsets.assign(chain_offsets, chain_offsets + n_chains + 1);
+    return b;
+}
+
+void ym_batch_destroy(ym_batch *b) { delete b; }
+
+int ym_batch_size(const ym_batch *b) { return b ? (int)b->offsets.size() - 1 : YM_ERR_INVALID; }
+
+int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refine, int slot_idx, int64_t chain_id_base,
+                       void *dev_best_out) {
+    if (!m || !b) return set_err(YM_ERR_INVALID, "null argument");
+    if (slot_idx < 0 || slot_idx >= kAsyncSlots) return set_err(YM_ERR_INVALID, "slot %d out of range", slot_idx);
+    Slot &slot = m->slots[slot_idx];
+    if (slot.in_flight) return set_err(YM_ERR_BUSY, "slot %d still holds an uncollected call", slot_idx);
+    const int n_chains = (int)b->offsets.size() - 1, n_scans = (int)b->scans.size();
+    Call &call = slot.call;
     call.scans.resize(1 + (size_t)n_scans);
-    int rc = scan_to_call(query, m->cfg.semantics, &call.scans[0]);
+    int rc = scan_to_call(b->query, m->cfg.semantics, &call.scans[0]);
     if (rc) return rc;
     for (int i = 0; i < n_scans; i++)
-        if ((rc = scan_to_call(scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
+        if ((rc = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
     call.items.resize(n_chains);
-    for (int c = 0; c < n_chains; c++) {
-        if (chain_offsets[c + 1] < chain_offsets[c]) return set_err(YM_ERR_INVALID, "chain_offsets must be non-decreasing");
-        call.items[c] = CallItem{0, 1 + chain_offsets[c], chain_offsets[c + 1] - chain_offsets[c]};
-    }
+    for (int c = 0; c < n_chains; c++) call.items[c] = CallItem{0, 1 + b->offsets[c], b->offsets[c + 1] - b->offsets[c]};
     call.penalize = penalize ? 1 : 0;
     call.refine = refine ? 1 : 0;
     call.coarse_angle_off = m->cfg.coarse_search_angle_offset;
-    Slot &slot = m->slots[kAsyncSlots];
-    slot.call = call;
-    if ((rc = launch_call(m, slot))) return rc;
-    std::vector<ym_result> res(n_chains);
-    if ((rc = finish_call(m, slot, res.data()))) return rc;
+    slot.chain_id_base = chain_id_base;
+    slot.dev_best_out = dev_best_out;
+    rc = launch_call(m, slot);
+    slot.dev_best_out = nullptr; // a response-expansion re-run must not overwrite the caller's buffer
+    return rc;
+}
+
+int ym_batch_wait(ym_matcher *m, int slot_idx, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    if (slot_idx < 0 || slot_idx >= kAsyncSlots) return set_err(YM_ERR_INVALID, "slot %d out of range", slot_idx);
+    Slot &slot = m->slots[slot_idx];
+    std::vector<ym_result> res(std::max(1, slot.n_items));
+    int rc = finish_call(m, slot, res.data());
+    if (rc) return rc;
+    const int n = slot.n_items;
     int bi = 0;
-    for (int c = 1; c < n_chains; c++)
+    for (int c = 1; c < n; c++)
         if (res[c].response > res[bi].response) bi = c;
-    if (per_chain) std::memcpy(per_chain, res.data(), sizeof(ym_result) * n_chains);
+    if (per_chain) std::memcpy(per_chain, res.data(), sizeof(ym_result) * n);
     if (best) *best = res[bi];
     if (best_chain) *best_chain = bi;
     return YM_OK;
 }
 
-int ym_match_batch_async(ym_matcher *, const ym_scan *, const ym_scan *const *, const int32_t *, int, int, int, int64_t,
-                         void *) {
-    return set_err(YM_ERR_UNSUPPORTED, "ym_match_batch_async is not implemented in this build yet");
+int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
+                   int n_chains, int penalize, int refine, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
+    ym_batch *b = ym_batch_create(m, query, scans, chain_offsets, n_chains);
+    if (!b) return YM_ERR_INVALID;
+    // use the last async slot that is free
+    int slot_idx = -1;
+    for (int i = kAsyncSlots - 1; i >= 0; i--)
+        if (!m->slots[i].in_flight) { slot_idx = i; break; }
+    int rc = slot_idx < 0 ? set_err(YM_ERR_BUSY, "all async slots are in flight")
+                          : ym_batch_run_async(m, b, penalize, refine, slot_idx, 0, nullptr);
+    if (rc == YM_OK) rc = ym_batch_wait(m, slot_idx, per_chain, best, best_chain);
+    ym_batch_destroy(b);
+    return rc;
 }
 
 // ---- debug getters

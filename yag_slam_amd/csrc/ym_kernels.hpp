@@ -130,6 +130,8 @@ struct OpMaxD { __device__ double operator()(double a, double b) const { return 
 struct OpAddD { __device__ double operator()(double a, double b) const { return a + b; } };
 struct OpAddU { __device__ unsigned operator()(unsigned a, unsigned b) const { return a + b; } };
 struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
+struct OpMinI { __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
 
 // development aid: block (0,0,0) thread 0 records the 100 MHz wall clock at phase boundaries
 #define YM_STAMP(args, idx)                                                                       \
@@ -179,6 +181,7 @@ struct PrepareArgs {
     YmItemState *states;
     double2 *qlocal;         // [B][max_n]
     int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
+    int4 *bbox;              // [B][max_base][ceil(max_n/64)] window bounding box of 64 consecutive cells
     double2 *ctrig;          // [B][nt_stride] (cos, sin) of every coarse angle
     int32_t *hypcell;        // [B][2][dim_stride]
     double *probs;           // [B][ny*nx] cleared here, filled by score_kernel
@@ -198,9 +201,10 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     const YmItem it = a.use_inline ? a.inl.item : a.items[b];
     const bool is_query = blockIdx.x == 0;
     const int slot = (int)blockIdx.x - 1;
-    if (!is_query && slot >= it.base_count) { // unused chain slot: no points
-        int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
-        for (int i = threadIdx.x; i < a.max_n; i += YM_PREP_THREADS) cells[i] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    const int n_cchunks = (a.max_n + 63) / 64;
+    if (!is_query && slot >= it.base_count) { // unused chain slot: no points, empty boxes
+        int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
+        for (int i = threadIdx.x; i < n_cchunks; i += YM_PREP_THREADS) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
         return;
     }
     const int si = is_query ? it.query : it.base_begin + slot;
@@ -341,7 +345,9 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     __syncthreads();
     YM_STAMP_B1(a, 22);
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
-    for (int i = tid; i < a.max_n; i += NT) {
+    int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
+    for (int i0 = 0; i0 < n_cchunks * 64; i0 += NT) {
+        const int i = i0 + tid; // a wave covers one 64-cell chunk
         int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
         if (i < np) {
             bool keep = false;
@@ -371,7 +377,13 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
                     c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
             }
         }
-        cells[i] = c;
+        if (i < a.max_n) cells[i] = c;
+        // bounding box of the chunk's rasterised cells: the raster kernel reads a chunk only when
+        // this box touches its tile
+        const bool has = c.x != YM_CELL_NONE;
+        const int x0 = wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = wave_reduce(has ? c.y : INT32_MAX, OpMinI());
+        const int x1 = wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+        if ((tid & 63) == 0 && i / 64 < n_cchunks) bbox[i / 64] = make_int4(x0, y0, x1, y1);
     }
     YM_STAMP_B1(a, 23);
 }
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
 #define YM_RASTER_THREADS 256
 struct RasterArgs {
     const int2 *cells;
+    const int4 *bbox;     // [B][max_base][ceil(max_n/64)]
     const YmItemState *states;
     YmGeom g;
     uint8_t *grid;        // [B][win_w rows][pitch]
@@ -414,17 +427,37 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
     for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
     __syncthreads();
-    const int total = a.max_base * a.max_n; // unused slots hold NONE
+    // candidate chunks: 64 consecutive cells of one base scan whose bounding box touches tile + halo
+    const int n_cchunks = (a.max_n + 63) / 64;
+    const int n_boxes = a.max_base * n_cchunks;
+    const int4 *bbox = a.bbox + (size_t)b * n_boxes;
     const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
+    const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
     int any = 0;
-#pragma unroll 8
-    for (int i = tid; i < total; i += NT) {
-        const int2 c = cells[i];
-        const int lx = c.x - (tx0 - h), ly = c.y - (ty0 - h);
-        if (c.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
-            atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
-            any = 1;
+    for (int c0 = 0; c0 < n_boxes; c0 += NT) {
+        const int c = c0 + tid;
+        bool hit = false;
+        if (c < n_boxes) {
+            const int4 bb = bbox[c];
+            hit = bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y;
+        }
+        // every wave walks the hits of its own 64 boxes; lanes then cover the chunk's 64 cells
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int chunk = c0 + (tid & ~63) + bit;          // wave-uniform
+            const int slot = chunk / n_cchunks, ci = chunk - slot * n_cchunks;
+            const int i = ci * 64 + (tid & 63);
+            if (i < a.max_n) {
+                const int2 cc = cells[(size_t)slot * a.max_n + i];
+                const int lx = cc.x - lo_x, ly = cc.y - lo_y;
+                if (cc.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+                    atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
+                    any = 1;
+                }
+            }
         }
     }
     any = __syncthreads_or(any);
@@ -766,7 +799,7 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
 }
 
 // ---- K6a fine: grid (max(nt_f,1), B), 256 threads.  Block k scores the 3x3 fine lattice for fine angle k.
-#define YM_FINE_THREADS 256
+#define YM_FINE_THREADS 512
 __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     constexpr int NT = YM_FINE_THREADS;
     __shared__ double scratch[16 * 5];
@@ -979,22 +1012,27 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         const int gy = world_to_grid(mean[1], off_y, a.g.scale) + a.g.border - a.g.win_origin;
         const int base = gy * a.g.pitch + gx;
         const int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
-        const int GS = 64 * max(1, (NT / 64) / nt); // lanes that share one angle
-        for (int k = tid / GS; k < nt; k += NT / GS) {
-            const int32_t *offs = foff + (size_t)k * a.max_n;
-            unsigned sum = 0;
-            for (int i = tid % GS; i < nq; i += 4 * GS) {
-                unsigned v[4];
+        __syncthreads(); // s_asum cleared above
+        // work item = (angle, beam); beams padded to whole waves so that a wave shares one angle
+        const int nq_pad = (nq + 63) & ~63;
+        const int total = nt * nq_pad;
+        for (int w0 = 0; w0 < total; w0 += 8 * NT) {
+            int kk[8];
+            unsigned idx[8], v[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int ii = i + u * GS;
-                    const unsigned idx = (unsigned)(base + (ii < nq ? offs[ii] : 0));
-                    v[u] = (ii < nq && idx < limit) ? grid[idx] : 0u;
-                }
-                sum += v[0] + v[1] + v[2] + v[3];
+            for (int u = 0; u < 8; u++) {
+                const int w = w0 + u * NT + tid;
+                kk[u] = w < total ? w / nq_pad : -1; // wave-uniform
+                const int i = w - kk[u] * nq_pad;
+                idx[u] = (kk[u] >= 0 && i < nq) ? (unsigned)(base + foff[(size_t)kk[u] * a.max_n + i]) : limit;
             }
-            sum = wave_reduce(sum, OpAddU());
-            if (lane == 0) atomicAdd(&s_asum[k], sum);
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = idx[u] < limit ? grid[idx[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned sum = wave_reduce(v[u], OpAddU());
+                if (lane == 0 && kk[u] >= 0) atomicAdd(&s_asum[kk[u]], sum);
+            }
         }
         __syncthreads();
         double norm = 0.0, accv = 0.0;
@@ -1025,6 +1063,37 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         if (a.host_out) a.host_out[b] = st;
     }
     YM_STAMP(a, 19);
+}
+
+// ================================================================== K7 arg-best over the items of a call
+// One block.  out[0..8) = {response, global chain id, x, y, heading, cov_xx, cov_yy, cov_tt} of the
+// item with the highest response (ties: lowest index) -- the payload of the cross-rank arg-max.
+__global__ __launch_bounds__(256) void argbest_kernel(const YmItemState *states, int n_items, long long id_base,
+                                                      double *out) {
+    __shared__ double s_r[4];
+    __shared__ int s_i[4];
+    double br = -1.0;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_items; i += 256) {
+        const double r = states[i].response;
+        if (r > br || (r == br && i < bi)) { br = r; bi = i; }
+    }
+    // wave arg-max (value, then lowest index), then across the 4 waves
+    const double wr = wave_reduce(br, OpMaxD());
+    const int wi = wave_reduce(br == wr ? bi : 0x7fffffff, OpMinI());
+    if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6] = wr; s_i[threadIdx.x >> 6] = wi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = s_r[0];
+        int idx = s_i[0];
+        for (int w = 1; w < 4; w++)
+            if (s_r[w] > r || (s_r[w] == r && s_i[w] < idx)) { r = s_r[w]; idx = s_i[w]; }
+        if (idx == 0x7fffffff || idx >= n_items) idx = 0;
+        const YmItemState &st = states[idx];
+        out[0] = st.response; out[1] = (double)(id_base + idx);
+        out[2] = st.mean[0]; out[3] = st.mean[1]; out[4] = st.mean[2];
+        out[5] = st.cov[0]; out[6] = st.cov[4]; out[7] = st.cov[8];
+    }
 }
 
 }  // namespace ym

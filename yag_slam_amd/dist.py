@@ -1,0 +1,68 @@
+"""Loop-closure batches across the GPUs of one node (one process per GPU, torch.distributed).
+
+The reference closes loops by matching one query scan against candidate chains one after another
+(/root/reference/yag_slam/graph_slam.py:217-254).  Chains are independent problems, so they shard
+across ranks with no data-path exchange; the only collective is one RCCL all-gather of a 64-byte
+"best of my shard" record per rank (backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests),
+followed by a deterministic local arg-max (highest response, ties to the lowest global chain id).
+"""
+import numpy as np
+
+RECORD = 8  # doubles: response, global chain id, x, y, heading, cov_xx, cov_yy, cov_tt
+
+
+def shard_range(n_chains, rank, world):
+    """Contiguous block of chain indices [lo, hi) owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(int(n_chains), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pick_best(records):
+    """records: (world, RECORD) array-like -> winning row index (max response, then min chain id).
+    Rows with a negative chain id (empty shard) never win."""
+    r = np.asarray(records, dtype=np.float64).reshape(-1, RECORD)
+    best = -1
+    for i in range(r.shape[0]):
+        if r[i, 1] < 0:
+            continue
+        if best < 0 or r[i, 0] > r[best, 0] or (r[i, 0] == r[best, 0] and r[i, 1] < r[best, 1]):
+            best = i
+    return best
+
+
+def all_gather_best(local_record, group=None):
+    """local_record: torch tensor (RECORD,) float64 on the rank's device (cuda for nccl, cpu for gloo).
+    Returns (winner_record_tensor, gathered (world, RECORD) tensor)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world, RECORD), dtype=torch.float64, device=local_record.device)
+    dist.all_gather_into_tensor(out, local_record.contiguous(), group=group)
+    resp, cid = out[:, 0], out[:, 1]
+    valid = cid >= 0
+    # lexicographic arg-max on the device: response descending, then chain id ascending
+    top = torch.where(valid, resp, torch.full_like(resp, -1.0)).max()
+    cand = torch.where(valid & (resp == top), cid, torch.full_like(cid, float("inf")))
+    win = torch.argmin(cand)
+    return out[win], out
+
+
+class ShardedLoopMatcher(object):
+    """Each rank owns a ScanMatcher on its GPU and a contiguous shard of the candidate chains."""
+
+    def __init__(self, matcher, query, chains, rank, world):
+        self.matcher = matcher
+        self.rank, self.world = rank, world
+        self.lo, self.hi = shard_range(len(chains), rank, world)
+        self.batch = matcher.make_batch(query, chains[self.lo:self.hi]) if self.hi > self.lo else None
+
+    def run_async(self, record, penalty=False, do_fine=False, slot=0):
+        """Enqueue the local shard; `record` (torch float64[RECORD] on this GPU) receives the shard's best."""
+        if self.batch is None:
+            record.fill_(-1.0)
+            return
+        self.batch.run_async(penalty, do_fine, slot, chain_id_base=self.lo, dev_best_out=record.data_ptr())
+
+    def reduce(self, record, group=None):
+        return all_gather_best(record, group)

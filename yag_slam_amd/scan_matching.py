@@ -124,6 +124,10 @@ class ScanMatcher(object):
                                              per, C.byref(best), C.byref(bi)))
         return [_result(r) for r in per], int(bi.value)
 
+    def make_batch(self, query, chains):
+        """Reusable (query, chains) batch for the pipelined loop-closure path."""
+        return MatchBatch(self, query, chains)
+
     def _require_native(self, scan):
         h = self._native(scan)
         if h is None:
@@ -144,6 +148,10 @@ class ScanMatcher(object):
 
     def synchronize(self):
         _capi.check(self._lib.ym_synchronize(self._m))
+
+    def set_stream(self, stream_handle):
+        """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None = own."""
+        _capi.check(self._lib.ym_set_stream(self._m, C.c_void_p(stream_handle) if stream_handle else None))
 
     # ---- introspection for the parity tests --------------------------------------------------
     def debug_grid(self, item=0):
@@ -178,6 +186,54 @@ class ScanMatcher(object):
         ms, n = C.c_double(), C.c_int64()
         _capi.check(self._lib.ym_profile_read(self._m, which, C.byref(ms), C.byref(n), int(bool(reset))))
         return ms.value, n.value
+
+
+class MatchBatch(object):
+    """One query against many candidate chains, resident on the device, runnable many times.
+
+    Replaces the serial `for chain in chains: loop_matcher.match_scan(scan, chain, False, False)` of
+    /root/reference/yag_slam/graph_slam.py:217-220 by one enqueue per batch."""
+
+    def __init__(self, matcher, query, chains):
+        self.m = matcher
+        self.query = query
+        self.chains = [list(c) for c in chains]
+        flat, offs = [], [0]
+        for ch in self.chains:
+            flat.extend(ch)
+            offs.append(len(flat))
+        self._flat = flat
+        hq = matcher._require_native(query)
+        hs = (C.c_void_p * max(1, len(flat)))(*[matcher._require_native(s) for s in flat])
+        co = (C.c_int32 * len(offs))(*offs)
+        self._h = matcher._lib.ym_batch_create(matcher._m, hq, hs, co, len(self.chains))
+        if not self._h:
+            raise _capi.YmError(-1, _capi.last_error())
+        self.n = len(self.chains)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                self.m._lib.ym_batch_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def push_poses(self):
+        """Write the scans' current corrected poses through to their device twins."""
+        for s in [self.query] + self._flat:
+            self.m._native(s)
+
+    def run_async(self, penalty=False, do_fine=False, slot=0, chain_id_base=0, dev_best_out=None):
+        _capi.check(self.m._lib.ym_batch_run_async(self.m._m, self._h, int(bool(penalty)), int(bool(do_fine)), int(slot),
+                                                   int(chain_id_base), C.c_void_p(dev_best_out) if dev_best_out else None))
+
+    def wait(self, slot=0, per_chain=True):
+        per = (_capi.YmResult * self.n)() if per_chain else None
+        best = _capi.YmResult()
+        bi = C.c_int32(-1)
+        _capi.check(self.m._lib.ym_batch_wait(self.m._m, int(slot), per, C.byref(best), C.byref(bi)))
+        return ([_result(r) for r in per] if per_chain else None), _result(best), int(bi.value)
 
 
 # names the reference exports (scan_matching.py:32,224)
