@@ -95,6 +95,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline leg: no spinning OpenMP workers
     from yag_slam_amd import dist as ymdist
     from yag_slam_amd.scan_matching import ScanMatcher
 
@@ -105,7 +106,7 @@ def main():
     batch = m.make_batch(query, chains)
     nslots = 32
     records = torch.zeros((nslots, ymdist.RECORD), dtype=torch.float64, device="cuda")
-    gathered = torch.zeros((world, ymdist.RECORD), dtype=torch.float64, device="cuda")
+    gathered = torch.zeros(world * ymdist.RECORD, dtype=torch.float64, device="cuda")
 
     def step(i):
         s = i % nslots

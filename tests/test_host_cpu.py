@@ -1,0 +1,124 @@
+"""CPU-only checks: the C ABI library loads and exports every symbol include/yagmatch.h declares,
+host-side logic (config surface, poses, scan model, sharding) behaves like the reference's."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.util import REPO
+
+
+def test_library_exports_every_declared_symbol():
+    from yag_slam_amd import _capi
+    L = _capi.lib()
+    hdr = open(os.path.join(REPO, "include", "yagmatch.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ym_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(L, name), "libyagmatch.so lacks %s" % name
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    assert L.ym_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    import ctypes as C
+    from yag_slam_amd import _capi
+    assert C.sizeof(_capi.YmConfig) == 11 * 8 + 2 * 4
+    assert C.sizeof(_capi.YmScanDesc) == 8 + 8 + 6 * 8 + 3 * 8
+    assert C.sizeof(_capi.YmResult) == 8 + 24 + 72 + 8 + 8 + 12 + 12 + 4 * 4
+    assert C.sizeof(_capi.YmGridInfo) == 12 * 4 + 16
+
+
+def test_no_device_fails_loudly():
+    from yag_slam_amd import _capi
+    from yag_slam_amd.scan_matching import ScanMatcher
+    if _capi.lib().ym_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_capi.YmError, match="no HIP device"):
+        ScanMatcher()
+
+
+def test_config_surface_matches_reference_defaults():
+    from yag_slam_amd import config
+    assert config.default_config["search_size"] == 0.5 and config.default_config["resolution"] == 0.01
+    assert config.default_config_loop["search_size"] == 4.0 and config.default_config_loop["resolution"] == 0.05
+    assert set(config.default_config) == set(config.CONFIG_KEYS) and len(config.CONFIG_KEYS) == 11
+    c = config.make_config({"resolution": 0.02})
+    assert c.resolution == 0.02 and c.smear_deviation == 0.05 and c.minimum_distance_penalty == 0.5
+    assert config.make_config(c.as_dict()).as_dict() == c.as_dict()  # round-trips like serde.py:88-92
+    with pytest.raises(AssertionError, match="Smear deviation"):
+        config.make_config({"resolution": 0.01, "smear_deviation": 0.2})
+    s = __import__("yag_slam_amd._capi", fromlist=["x"]).config_struct(c, "karto")
+    assert s.resolution == 0.02 and s.use_response_expansion == 1 and s.semantics == 0
+
+
+def test_transform_composes_like_an_odometry_prior():
+    from yag_slam_amd.transform import Transform
+    last_odom = Transform.from_position_euler(1.0, 2.0, 0, 0, 0, 0.3)
+    new_odom = Transform.from_position_euler(1.5, 2.2, 0, 0, 0, 0.5)
+    last_corr = Transform.from_position_euler(10.0, -3.0, 0, 0, 0, 1.3)
+    prior = last_corr + (new_odom - last_odom)  # graph_slam.py:320-322
+    # the relative motion is preserved in the corrected frame
+    d = prior - last_corr
+    e = new_odom - last_odom
+    assert abs(d.x - e.x) < 1e-12 and abs(d.y - e.y) < 1e-12 and abs(d.euler[-1] - e.euler[-1]) < 1e-12
+    assert abs(prior.euler[-1] - 1.5) < 1e-12
+    ident = last_odom - last_odom
+    assert abs(ident.x) < 1e-12 and abs(ident.y) < 1e-12 and abs(ident.euler[-1]) < 1e-12
+
+
+def test_scan_model_without_gpu():
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.transform import Transform
+    z = np.load(os.path.join(REPO, "tests", "golden", "points_dirty.npz"))
+    s = LocalizedRangeScan(z["ranges"], float(z["min_angle"]), 0.0, float(z["angle_increment"]), 0.05, 30.0,
+                           float(z["range_threshold"]), *z["pose"])
+    px, py = s.points()  # same rule as the reference's _get_point_readings (helpers.py:58-68)
+    np.testing.assert_allclose(px, z["px"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(py, z["py"], rtol=0, atol=1e-12)
+    s.corrected_pose = Transform.from_position_euler(1.0, 2.0, 0, 0, 0, 0.5)
+    assert s.corrected_pose.x == 1.0 and s.odom_pose.x == float(z["pose"][0])
+    c = s.copy()
+    assert c.corrected_pose.euler[-1] == 0.5 and c.ranges is not s.ranges and c.num == 0
+    s.num = 7
+    assert s.num == 7
+    lx, ly = s.points_local()
+    assert len(lx) == len(px)
+
+
+def test_shard_ranges_cover_all_chains():
+    from yag_slam_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 9, 4096, 4099):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pick_best_is_deterministic():
+    from yag_slam_amd.dist import pick_best, RECORD
+    r = np.zeros((4, RECORD))
+    r[:, 0] = [0.5, 0.9, 0.9, 0.2]
+    r[:, 1] = [0, 700, 300, 5]
+    assert pick_best(r) == 2          # tie on response -> lowest chain id
+    r[2, 1] = -1                      # empty shard never wins
+    assert pick_best(r) == 1
+
+
+def test_synthetic_scene_is_reproducible():
+    from yag_slam_amd import synth
+    a, b = synth.Scene(), synth.Scene()
+    assert np.array_equal(a.segs, b.segs) and len(a.boxes) == 6
+    r1 = a.scan_ranges((3.0, 3.0, 0.0), 3)
+    r2 = b.scan_ranges((3.0, 3.0, 0.0), 3)
+    assert np.array_equal(r1, r2) and r1.shape == (synth.N_BEAMS,)
+    assert 0.5 < r1.min() and r1.max() < 10.0
+    d = a.scan_ranges((3.0, 3.0, 0.0), 3, dirty=True)
+    assert np.isnan(d).sum() == 10 and (d > synth.MAX_RANGE).sum() == 10
+    truth, prior = synth.loop_trajectory(50)
+    assert truth.shape == (50, 3) and np.all(np.hypot(*(truth[1:, :2] - truth[:-1, :2]).T) < 0.12)

@@ -37,8 +37,9 @@ def all_gather_best(local_record, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world, RECORD), dtype=torch.float64, device=local_record.device)
-    dist.all_gather_into_tensor(out, local_record.contiguous(), group=group)
+    flat = torch.empty(world * RECORD, dtype=torch.float64, device=local_record.device)
+    dist.all_gather_into_tensor(flat, local_record.contiguous().view(-1), group=group)
+    out = flat.view(world, RECORD)
     resp, cid = out[:, 0], out[:, 1]
     valid = cid >= 0
     # lexicographic arg-max on the device: response descending, then chain id ascending
