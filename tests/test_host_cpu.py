@@ -121,4 +121,4 @@ def test_synthetic_scene_is_reproducible():
     d = a.scan_ranges((3.0, 3.0, 0.0), 3, dirty=True)
     assert np.isnan(d).sum() == 10 and (d > synth.MAX_RANGE).sum() == 10
     truth, prior = synth.loop_trajectory(50)
-    assert truth.shape == (50, 3) and np.all(np.hypot(*(truth[1:, :2] - truth[:-1, :2]).T) < 0.12)
+    assert truth.shape == (50, 3) and np.all(np.hypot(*(truth[1:, :2] - truth[:-1, :2]).T) < 0.15)
