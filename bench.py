@@ -207,7 +207,7 @@ def main():
                 "sample": "%d cfg2 matches (coarse+fine, penalty) in %.1f s, oracle/ym_oracle.c karto semantics, "
                           "-O3 -march=native, 1 thread" % (cb["single"]["matches"], cb["single"]["seconds"]),
                 "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
-                              "sample": "%d matches in %.1f s, OpenMP over the coarse lattice, host has %d cores" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1) % ("", "")},
+                              "sample": "%d matches in %.1f s, OpenMP over the coarse lattice, host has %d cores" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
             }
         print(json.dumps(line))
     if dist is not None:
