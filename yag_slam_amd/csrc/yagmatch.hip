@@ -161,6 +161,7 @@ struct ym_matcher {
     DevBuf<int2> cells;
     DevBuf<int4> bbox;
     DevBuf<uint8_t> grid;
+    DevBuf<uint8_t> planes;    // even/odd column planes of every window
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
@@ -380,13 +381,19 @@ int launch_call(ym_matcher *m, Slot &slot) {
     // ---- coarse correlate decomposition
     const int sx = (int)kt_round_h(lc.step_x * g.scale);
     if (sx != 1 && sx != 2) return set_err(YM_ERR_UNSUPPORTED, "coarse lattice step of %d cells", sx);
-    const int G = 16 / sx;
+    const int G = 16;
     const int ngx = (lc.nx + G - 1) / G;
     const int nx_pad = ngx * G;
     const int njobs = lc.ny * ngx;
-    const int job_blocks = (njobs + YM_CORR_THREADS - 1) / YM_CORR_THREADS;
+    // (measured on MI355X: sharing a block between adjacent angles does not help -- the kernel is bound by
+    //  L1 tag lookups per lane, not by line reuse -- so one angle per block)
+    const int tpb = 1;
+    const int jobs_pb = YM_CORR_THREADS / tpb;
+    const int job_blocks = (njobs + jobs_pb - 1) / jobs_pb;
+    const int ktiles = (lc.nt + tpb - 1) / tpb;
     // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams
     const double waves_one_chunk = (double)((njobs + 63) / 64) * lc.nt * B;
+    (void)ktiles;
     int n_chunks = (int)std::ceil(2048.0 / std::max(1.0, waves_one_chunk));
     n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
     n_chunks = std::max(n_chunks, (max_n + 511) / 512);
@@ -407,6 +414,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * ((max_n + 63) / 64)))) return rc;
     if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
+    if ((rc = m->planes.ensure((size_t)B * grid_stride))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
@@ -467,7 +475,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     {
         ym::RasterArgs a;
         a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
-        a.grid_stride = grid_stride; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
+        a.grid_stride = grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
         if ((rc = prof_begin(m, 1, &ev_k))) return rc;
         hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
@@ -475,12 +483,12 @@ int launch_call(ym_matcher *m, Slot &slot) {
     // ---- K4 coarse correlate
     {
         ym::CorrArgs a;
-        a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.ctrig = m->ctrig.p;
+        a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.planes = m->planes.p; a.ctrig = m->ctrig.p;
         a.qlocal = m->qlocal.p; a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = partial_stride;
         a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.chunk = chunk; a.n_chunks = n_chunks;
-        a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps;
+        a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps; a.tpb = tpb;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
-        const dim3 grid_dim(job_blocks, lc.nt * n_chunks, B);
+        const dim3 grid_dim(job_blocks, ktiles * n_chunks, B);
         if (sx == 2) hipLaunchKernelGGL(ym::correlate_kernel<2>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
         else hipLaunchKernelGGL(ym::correlate_kernel<1>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
@@ -704,7 +712,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release();
+    m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
     m->tmp_ranges_host.release(); m->stamps.release();

@@ -399,6 +399,7 @@ struct RasterArgs {
     YmGeom g;
     uint8_t *grid;        // [B][win_w rows][pitch]
     size_t grid_stride;   // bytes per item
+    uint8_t *planes;      // [B][2][win_w rows][pitch/2]: plane p holds columns 2*x+p of the window
     const uint8_t *lut;   // smear kernel value by squared cell distance: lut[dx*dx + dy*dy], 2*h*h + 1 entries
     int32_t max_n, max_base;
     unsigned long long *stamps;
@@ -467,8 +468,14 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     const int y = tid / LPR, x8 = (tid % LPR) * 8;
     const bool row_ok = (ty0 + y) < a.g.win_w;
     uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
+    const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
+    uint8_t *pl = a.planes + (size_t)b * a.grid_stride + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
     if (!any) {
-        if (row_ok) *dst = make_uint2(0u, 0u);
+        if (row_ok) {
+            *dst = make_uint2(0u, 0u);
+            *reinterpret_cast<uint32_t *>(pl) = 0u;
+            *reinterpret_cast<uint32_t *>(pl + plane_bytes) = 0u;
+        }
         return;
     }
     // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
@@ -505,7 +512,12 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
         const unsigned v = mn[q] <= max_d2 ? lut[mn[q]] : 0u;
         packed[q >> 2] |= v << (8 * (q & 3));
     }
-    if (row_ok) *dst = make_uint2(packed[0], packed[1]);
+    if (row_ok) {
+        *dst = make_uint2(packed[0], packed[1]);
+        // even / odd columns of the same 8 cells (v_perm_b32 byte gathers)
+        *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(packed[1], packed[0], 0x06040200u);
+        *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(packed[1], packed[0], 0x07050301u);
+    }
     YM_STAMP(a, 7);
 }
 
@@ -516,6 +528,7 @@ struct CorrArgs {
     YmLattice lat;
     const uint8_t *grid;
     size_t grid_stride;
+    const uint8_t *planes;  // even/odd column planes of the window (coarse step = 2 cells)
     const double2 *ctrig;   // [B][nt_stride] (cos, sin) per coarse angle
     const double2 *qlocal;  // [B][max_n] query points in the sensor frame
     const int32_t *hypcell;
@@ -525,93 +538,103 @@ struct CorrArgs {
     int32_t max_n, nt_stride, dim_stride;
     int32_t chunk;         // beams per chunk (multiple of 16, <= 512 keeps the 16-bit lanes from overflowing)
     int32_t n_chunks;
+    int32_t tpb;           // adjacent angles per block (1, 2 or 4)
     int32_t ngx;           // x groups per row = ceil(nx / G)
     int32_t nx_pad;        // ngx * G
     int32_t sx;            // cell stride between x-adjacent hypotheses (1 or 2)
     unsigned long long *stamps;
 };
 
-// Lane job = G x-adjacent hypotheses of one lattice row for one angle: G = 8 when the lattice
-// steps 2 cells (coarse search), 16 when it steps 1.  For every beam of its chunk the lane loads
-// the 16 grid bytes that hold those hypotheses' cells (row segment start + wave-uniform beam
-// offset) and accumulates them in 16-bit lanes.  No cross-lane reduction; partial sums per beam
-// chunk are added up by score_kernel.  Each block first builds the cell offsets of its own beam
-// chunk in LDS (GridIndexLookup::ComputeOffsets for one angle: rotate the sensor-frame point,
-// WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are issued 16 beams at a
-// time; entries past the last beam are 0 and are masked by a scalar.
+// Lane job = 16 x-adjacent hypotheses of one lattice row for one angle.  The coarse search steps
+// 2 cells (SX = 2), so its hypotheses' cells for one beam are every other byte of a row: they are
+// contiguous in the even- or odd-column plane the raster kernel also writes (which plane is a
+// per-beam, wave-uniform choice: parity of hypothesis column + beam offset).  For every beam of
+// its chunk a lane loads the 16 plane bytes of its 16 hypotheses (row start + wave-uniform beam
+// offset) and accumulates them in 16-bit lanes: no cross-lane reduction, no wasted bytes.
+// Partial sums per beam chunk are added up by score_kernel.  Each block first builds the offsets
+// of its own beam chunk in LDS (GridIndexLookup::ComputeOffsets for one angle: rotate the
+// sensor-frame point, WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are
+// issued 16 beams at a time; entries past the last beam are 0 and are masked by a scalar.
 // grid (ceil(ny*ngx / 256), nt * n_chunks, B).
 template <int SX>
 __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
-    constexpr int G = 16 / SX;      // hypotheses per lane
-    constexpr int NACC = 4 * (SX == 1 ? 2 : 1);
+    constexpr int G = 16;           // hypotheses per lane
     constexpr int U = 16;           // beams in flight per lane
     const int b = blockIdx.z;
-    const int k = blockIdx.y % a.lat.nt, chunk = blockIdx.y / a.lat.nt;
-    const int job = blockIdx.x * YM_CORR_THREADS + threadIdx.x;
-    __shared__ int offs[512];
+    // a block covers jobs_pb lane jobs of each of tpb adjacent angles for one beam chunk: waves of
+    // one block read overlapping grid patches (adjacent angles shift the patch by a few cells)
+    const int tpb = a.tpb, jobs_pb = YM_CORR_THREADS / tpb;
+    const int ktiles = (a.lat.nt + tpb - 1) / tpb;
+    const int k = (blockIdx.y % ktiles) * tpb + threadIdx.x / jobs_pb, chunk = blockIdx.y / ktiles;
+    const int job = blockIdx.x * jobs_pb + threadIdx.x % jobs_pb;
+    __shared__ int offs_all[4][512];
+    int *offs = offs_all[threadIdx.x / jobs_pb];
     YM_STAMP(a, 8);
     const int njobs = a.lat.ny * a.ngx;
+    const bool k_ok = k < a.lat.nt;
     const YmItemState &st = a.states[b];
     const int nq = st.nq;
     const int regular = st.regular[0];
     const int i0 = chunk * a.chunk;
-    {
+    const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    const int32_t *cy = cx + a.dim_stride;
+    const int cx0 = cx[0];
+    const int half_pitch = a.g.pitch / 2;
+    const int plane_bytes = half_pitch * a.g.win_w;
+    if (k_ok) {
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
         const double2 *ql = a.qlocal + (size_t)b * a.max_n;
-        for (int c = threadIdx.x; c < a.chunk; c += YM_CORR_THREADS) {
+        for (int c = threadIdx.x % jobs_pb; c < a.chunk; c += jobs_pb) {
             const int i = i0 + c;
-            offs[c] = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) : 0;
+            int o = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) : 0;
+            if (SX == 2 && regular) {
+                // window-linear index of hypothesis column 0 for this beam -> (plane, index in plane)
+                const int l = o + cx0;
+                o = (l >> 1) + (l & 1) * plane_bytes;
+            }
+            offs[c] = o;
         }
     }
     __syncthreads();
-    if (job >= njobs) return;
+    if (job >= njobs || !k_ok) return;
     const int iy = job / a.ngx, xg = job - iy * a.ngx;
-    const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
-    const int32_t *cy = cx + a.dim_stride;
-    const int cyv = cy[iy], cx0 = cx[0];
-    const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+    const int cyv = cy[iy];
     uint32_t *out = a.partial + (size_t)b * a.partial_stride +
                     (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
 
     if (regular) {
-        const uint32_t lane_off = (uint32_t)(cyv * a.g.pitch + cx0 + xg * G * SX);
-        uint32_t acc[NACC];
+        const uint8_t *__restrict__ src = SX == 2 ? a.planes + (size_t)b * a.grid_stride : a.grid + (size_t)b * a.grid_stride;
+        const uint32_t lane_off = SX == 2 ? (uint32_t)(cyv * half_pitch + xg * G)
+                                          : (uint32_t)(cyv * a.g.pitch + cx0 + xg * G);
+        uint32_t acc[8];
 #pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = 0u;
+        for (int j = 0; j < 8; j++) acc[j] = 0u;
         for (int c = 0; c < a.chunk; c += U) {
             uint4 w[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], grid + (uint32_t)(lane_off + (uint32_t)offs[c + u]), 16);
+            for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], src + (uint32_t)(lane_off + (uint32_t)offs[c + u]), 16);
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t m = (i0 + c + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
-                if (SX == 2) {
-                    acc[0] += w[u].x & m; acc[1] += w[u].y & m; acc[2] += w[u].z & m; acc[3] += w[u].w & m;
-                } else {
-                    acc[0] += w[u].x & m; acc[1] += (w[u].x >> 8) & m;
-                    acc[2] += w[u].y & m; acc[3] += (w[u].y >> 8) & m;
-                    acc[4] += w[u].z & m; acc[5] += (w[u].z >> 8) & m;
-                    acc[6] += w[u].w & m; acc[7] += (w[u].w >> 8) & m;
-                }
+                acc[0] += w[u].x & m; acc[1] += (w[u].x >> 8) & m;
+                acc[2] += w[u].y & m; acc[3] += (w[u].y >> 8) & m;
+                acc[4] += w[u].z & m; acc[5] += (w[u].z >> 8) & m;
+                acc[6] += w[u].w & m; acc[7] += (w[u].w >> 8) & m;
             }
         }
         uint32_t r[G];
-        if (SX == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { r[2 * j] = acc[j] & 0xFFFFu; r[2 * j + 1] = acc[j] >> 16; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
-                r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
-            }
+        for (int j = 0; j < 4; j++) {
+            r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
+            r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
         }
 #pragma unroll
         for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
         YM_STAMP(a, 9);
     } else {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
+        const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
         const int n_here = min(nq - i0, a.chunk);
         for (int j = 0; j < G; j++) {
