@@ -175,3 +175,57 @@ def test_async_pipeline_matches_sync():
     for s in range(8):
         r = m.wait(s)
         assert r.response == ref.response and r.covariance == ref.covariance
+
+
+# ------------------------------------------------------------------------------------------------
+# "yagpy" semantics on the device against the golden vectors produced by the REFERENCE's own
+# Python matcher (tests/golden/make_golden.py): same inputs, the reference's outputs.
+GOLDEN_CASES = ["small_pen0_fine1", "small_pen1_fine1", "small_pen1_fine0", "small_dirty_rot", "testpy_flat",
+                "cfg2_pen1_fine1", "cfg2_pen0_fine1", "cfg2_pen1_fine0"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_yagpy_device_matches_reference_goldens(name):
+    from tests.util import load_case
+    from yag_slam_amd.scan_matching import ScanMatcher
+    c = load_case(name)
+    z = c["z"]
+    m = ScanMatcher(c["cfg"], semantics="yagpy")
+    r = m.match_scan(c["query"], c["base"], c["penalty"], c["do_fine"])
+    # correlation grid: the device window against the same rectangle of the reference's grid,
+    # in the integer form the reference scores with, int(100 * cell)  (helpers.py:142-145)
+    G = int(z["grid_size"])
+    g, info = m.debug_grid()
+    assert info.storage_w == G
+    full = np.zeros((G, G), dtype=np.uint8)
+    full[z["grid_nz_y"], z["grid_nz_x"]] = (100 * z["grid_nz_val"]).astype(np.int64)
+    sub = full[info.origin_y:info.origin_y + info.height, info.origin_x:info.origin_x + info.width]
+    assert np.array_equal(g, sub), "grid window differs in %d cells" % int((g != sub).sum())
+    if "coarse_sums" in z.files:  # integer work: bit-exact against the reference's own scoring function
+        s0 = m.debug_sums(0, dims=r.meta["coarse_dims"])
+        assert s0.shape == z["coarse_sums"].shape
+        assert np.array_equal(s0.astype(np.int64), z["coarse_sums"])
+    assert abs(r.response - float(z["response"])) <= 1e-12
+    bp = r.best_pose
+    np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], z["best_pose"], rtol=0, atol=1e-9)
+    cov, got = z["covariance"], np.array(r.covariance)
+    if np.all(np.isfinite(cov)):
+        np.testing.assert_allclose(got, cov, rtol=1e-9, atol=1e-15)
+    else:  # zero response: the reference divides by zero; same NaN/inf pattern expected
+        assert np.array_equal(np.isfinite(got), np.isfinite(cov)) and np.array_equal(np.isnan(got), np.isnan(cov))
+
+
+def test_yagpy_device_matches_oracle_both_passes():
+    from oracle import oracle as orc
+    from tests.util import load_case
+    from yag_slam_amd.scan_matching import ScanMatcher
+    c = load_case("small_dirty_rot")
+    o = orc.Oracle(c["cfg"], "yagpy")
+    ro = o.match_scan(c["query"], c["base"], True, True)
+    m = ScanMatcher(c["cfg"], semantics="yagpy")
+    r = m.match_scan(c["query"], c["base"], True, True)
+    assert r.meta["coarse_dims"] == ro["coarse_dims"] and r.meta["fine_dims"] == ro["fine_dims"]
+    assert r.meta["hypotheses"] == ro["hypotheses"]
+    assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]), o.sums(0))
+    assert np.array_equal(m.debug_sums(1, dims=r.meta["fine_dims"]), o.sums(1))
+    assert abs(r.response - ro["response"]) <= 1e-12

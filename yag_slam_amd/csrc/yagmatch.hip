@@ -170,6 +170,8 @@ struct ym_matcher {
     DevBuf<double> resp;
     DevBuf<double> blockmax;
     DevBuf<double> probs;
+    DevBuf<double> yaxes;      // yagpy: xvals, yvals, tvals per item
+    DevBuf<double2> yrot;      // yagpy: points rotated per angle
     DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
     bool stamps_on = false;
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
@@ -200,10 +202,39 @@ int build_geometry(ym_matcher *m) {
     if (!(c.coarse_angle_resolution > 0) || !(c.fine_search_angle_resolution > 0) ||
         !(c.coarse_search_angle_offset > 0))
         return set_err(YM_ERR_INVALID, "angle offsets/resolutions must be > 0");
-    if (c.semantics != YM_SEM_KARTO)
-        return set_err(YM_ERR_UNSUPPORTED, "semantics %d is not built into this library yet", c.semantics);
+    if (c.semantics != YM_SEM_KARTO && c.semantics != YM_SEM_YAGPY)
+        return set_err(YM_ERR_INVALID, "unknown semantics %d", c.semantics);
     YmGeom &g = m->geom;
     std::memset(&g, 0, sizeof g);
+    if (c.semantics == YM_SEM_YAGPY) {
+        // Scan2DMatcherPy.match_scan (/root/reference/yag_slam/scan_matching.py:183-190) and
+        // calculate_kernel (/root/reference/yag_slam/helpers.py:86-97)
+        g.res = c.resolution;
+        g.scale = 1.0 / c.resolution;
+        const int G = (int)(c.search_size / c.resolution + 1 + 2 * c.range_threshold / c.resolution);
+        if (G <= 0) return set_err(YM_ERR_INVALID, "bad grid size %d", G);
+        g.side = 0;
+        g.roi_w = G;
+        g.border = 0;
+        g.storage_w = G;
+        const int ks = (int)(4 * std::rint(c.smear_deviation / c.resolution) + 1);
+        g.half_kernel = ks / 2;
+        if (g.half_kernel > YM_MAX_KERNEL_HALF || g.half_kernel < 1)
+            return set_err(YM_ERR_INVALID, "kernel half size %d out of range", g.half_kernel);
+        g.semantics = c.semantics;
+        g.zone_count = 1; // the Python path re-stamps occupied cells: order-independent
+        const int h = g.half_kernel;
+        m->kernel.assign((size_t)ks * ks, 0);
+        for (int i_ = 0; i_ < ks; i_++)
+            for (int j_ = 0; j_ < ks; j_++) {
+                const int i = i_ - h, j = j_ - h;
+                const double a = i * c.resolution, b = j * c.resolution;
+                const double sqdist = a * a + b * b;
+                const double v = std::exp(-0.5 * sqdist / (c.smear_deviation * c.smear_deviation));
+                m->kernel[(size_t)i_ * ks + j_] = (uint8_t)(int)(100 * v); // score: int(100 * cell), helpers.py:142-145
+            }
+        return YM_OK;
+    }
     // ScanMatcher::Create + CorrelationGrid::CreateGrid
     g.scale = 1.0 / c.resolution;
     g.res = 1.0 / g.scale;
@@ -351,23 +382,33 @@ int launch_call(ym_matcher *m, Slot &slot) {
     for (const CallScan &s : call.scans) max_n = std::max(max_n, s.n);
     if (max_n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", max_n, YM_MAX_BEAMS);
 
+    const bool yag = g.semantics == YM_SEM_YAGPY;
     // ---- lattices (ScanMatcher::MatchScan)
-    const double coarse_off = 0.5 * (g.side - 1) * g.res;
+    const double coarse_off = yag ? 0.5 * m->cfg.search_size : 0.5 * (g.side - 1) * g.res;
     const double coarse_step = 2 * g.res;
-    YmLattice lc = make_lattice(g, coarse_off, coarse_step, call.coarse_angle_off, m->cfg.coarse_angle_resolution, 0,
-                                call.penalize);
-    YmLattice lf = make_lattice(g, coarse_step * 0.5, g.res, 0.5 * m->cfg.coarse_angle_resolution,
-                                m->cfg.fine_search_angle_resolution, 1, call.penalize);
+    YmLattice lc, lf;
+    if (yag) { // lattices are built on the device from np.arange; the Karto tables stay empty
+        std::memset(&lc, 0, sizeof lc);
+        std::memset(&lf, 0, sizeof lf);
+        lc.step_x = lc.step_y = coarse_step;
+        lc.angle_res = m->cfg.coarse_angle_resolution;
+        lf.fine = 1;
+    } else {
+        lc = make_lattice(g, coarse_off, coarse_step, call.coarse_angle_off, m->cfg.coarse_angle_resolution, 0,
+                          call.penalize);
+        lf = make_lattice(g, coarse_step * 0.5, g.res, 0.5 * m->cfg.coarse_angle_resolution,
+                          m->cfg.fine_search_angle_resolution, 1, call.penalize);
+    }
     slot.coarse = lc;
     slot.fine = lf;
 
     // ---- device window: the central part of Karto's storage the query endpoints can reach
     const int centre = g.border + (g.roi_w - 1) / 2;
-    const double reach = rq + coarse_off + g.res;
-    int wh = (int)std::ceil(reach * g.scale) + 3;
+    const double reach = rq + coarse_off + (yag ? 3 : 1) * g.res; // yagpy's fine pass reaches 2 cells past the coarse box
+    int wh = (int)std::ceil(reach / g.res) + 3;
     wh = std::min(wh, centre);
     g.win_origin = centre - wh;
-    g.win_w = 2 * wh + 1;
+    g.win_w = std::min(2 * wh + 1 + (yag ? 1 : 0), g.storage_w - g.win_origin); // even yagpy grids have no centre cell
     const int tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
     const int tiles_y = (g.win_w + YM_TILE_H - 1) / YM_TILE_H;
     g.pitch = tiles_x * YM_TILE_W + 64;
@@ -379,8 +420,14 @@ int launch_call(ym_matcher *m, Slot &slot) {
         return set_err(YM_ERR_UNSUPPORTED, "%d coarse angles exceed the built-in limit of %d", lc.nt, YM_MAX_COARSE_NT);
 
     // ---- coarse correlate decomposition
-    const int sx = (int)kt_round_h(lc.step_x * g.scale);
+    const int sx = yag ? 2 : (int)kt_round_h(lc.step_x * g.scale);
     if (sx != 1 && sx != 2) return set_err(YM_ERR_UNSUPPORTED, "coarse lattice step of %d cells", sx);
+    // yagpy lattice bounds (np.arange lengths are fixed on the device; these only size the buffers)
+    const int ymaxd = yag ? std::max(8, (int)std::ceil(m->cfg.search_size / coarse_step) + 2) : 0;
+    const int ymaxt = yag ? std::max(13, (int)std::ceil(m->cfg.coarse_search_angle_offset / m->cfg.coarse_angle_resolution) + 2) : 0;
+    if (yag && (ymaxd > YM_YAG_MAX_DIM || ymaxt > YM_YAG_MAX_NT))
+        return set_err(YM_ERR_UNSUPPORTED, "yagpy lattice %d x %d x %d exceeds the built-in limit", ymaxd, ymaxd, ymaxt);
+    const size_t yvol = (size_t)ymaxt * ymaxd * ymaxd;
     const int G = 16;
     const int ngx = (lc.nx + G - 1) / G;
     const int nx_pad = ngx * G;
@@ -419,8 +466,12 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
     if ((rc = m->partial.ensure((size_t)B * partial_stride + 16))) return rc;
-    if ((rc = m->sums.ensure((size_t)B * (sums_c + sums_f)))) return rc;
-    if ((rc = m->resp.ensure((size_t)B * sums_c))) return rc;
+    if ((rc = m->sums.ensure((size_t)B * std::max(sums_c + sums_f, 2 * yvol)))) return rc;
+    if ((rc = m->resp.ensure((size_t)B * std::max(sums_c, yvol)))) return rc;
+    if (yag) {
+        if ((rc = m->yaxes.ensure((size_t)B * 3 * YM_YAG_MAX_DIM))) return rc;
+        if ((rc = m->yrot.ensure((size_t)B * ymaxt * max_n))) return rc;
+    }
     if ((rc = m->blockmax.ensure((size_t)B * score_blocks))) return rc;
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
 
@@ -480,6 +531,32 @@ int launch_call(ym_matcher *m, Slot &slot) {
         hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
     }
+    if (yag) {
+        // ---- the Python matcher's two find_best_pose passes (scan_matching.py:204-214)
+        m->sums_pass_offset[0] = 0;
+        m->sums_pass_offset[1] = (size_t)B * yvol;
+        for (int pass = 0; pass < (call.refine ? 2 : 1); pass++) {
+            ym::YagArgs a;
+            std::memset(&a, 0, sizeof a);
+            a.g = g; a.pass = pass; a.penalize = call.penalize; a.refine = call.refine;
+            a.last = (pass == 1 || !call.refine) ? 1 : 0;
+            if (pass == 0) {
+                a.search_xy = m->cfg.search_size * 0.5; a.step_xy = g.res * 2;
+                a.search_t = m->cfg.coarse_search_angle_offset * 0.5; a.step_t = m->cfg.coarse_angle_resolution;
+            } else {
+                a.search_xy = g.res * 2; a.step_xy = g.res; a.search_t = 0.0349 * 0.5; a.step_t = 0.00349;
+            }
+            a.coarse_angle_res = m->cfg.coarse_angle_resolution;
+            a.states = m->states.p; a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
+            a.qlocal = m->qlocal.p; a.axes = m->yaxes.p; a.rot = m->yrot.p;
+            a.sums = m->sums.p + m->sums_pass_offset[pass]; a.out = m->resp.p;
+            a.grid = m->grid.p; a.grid_stride = grid_stride; a.vol_stride = yvol;
+            a.max_n = max_n; a.maxd = ymaxd; a.maxt = ymaxt;
+            hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(ymaxt, B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(ym::yag_score_kernel, dim3((ymaxd * ymaxd + 255) / 256, ymaxt, B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(B), dim3(1024), 0, st, a);
+        }
+    } else {
     // ---- K4 coarse correlate
     {
         ym::CorrArgs a;
@@ -518,6 +595,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
         hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
         hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
+    } // karto
     if (slot.dev_best_out)
         hipLaunchKernelGGL(ym::argbest_kernel, dim3(1), dim3(256), 0, st, m->states.p, B, (long long)slot.chain_id_base,
                            reinterpret_cast<double *>(slot.dev_best_out));
@@ -534,7 +612,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     m->last_B = B; m->last_max_n = max_n; m->last_max_base = max_base;
     m->last_nt_stride = nt_stride; m->last_dim_stride = dim_stride;
     m->last_grid_stride = grid_stride;
-    m->last_sums_stride[0] = sums_c; m->last_sums_stride[1] = call.refine ? sums_f : 0;
+    m->last_sums_stride[0] = yag ? yvol : sums_c; m->last_sums_stride[1] = call.refine ? (yag ? yvol : sums_f) : 0;
     m->last_valid = true;
     return YM_OK;
 }
@@ -552,7 +630,11 @@ void state_to_result(const ym_matcher *m, const Slot &slot, const YmItemState &s
         r->fine_dims[0] = slot.fine.nx; r->fine_dims[1] = slot.fine.ny; r->fine_dims[2] = slot.fine.nt;
         hyp += (int64_t)slot.fine.nx * slot.fine.ny * slot.fine.nt;
     }
-    if (s.nq == 0) { // MatchScan returns before any correlation
+    if (m->cfg.semantics == YM_SEM_YAGPY) {
+        for (int i = 0; i < 3; i++) { r->coarse_dims[i] = s.ydims[0][i]; r->fine_dims[i] = slot.call.refine ? s.ydims[1][i] : 0; }
+        hyp = (int64_t)s.ydims[0][0] * s.ydims[0][1] * s.ydims[0][2];
+        if (slot.call.refine) hyp += (int64_t)s.ydims[1][0] * s.ydims[1][1] * s.ydims[1][2];
+    } else if (s.nq == 0) { // MatchScan returns before any correlation
         hyp = 0;
         std::memset(r->coarse_dims, 0, sizeof r->coarse_dims);
         std::memset(r->fine_dims, 0, sizeof r->fine_dims);
@@ -575,7 +657,9 @@ int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */)
     std::vector<int64_t> prior(B, 0);
     for (int i = 0; i < B; i++) {
         state_to_result(m, slot, hs[i], 0, 0, &out[i]);
-        if (m->cfg.use_response_expansion && kt_double_equal_h(hs[i].coarse_response, 0.0)) redo.push_back(i);
+        if (m->cfg.semantics == YM_SEM_KARTO && m->cfg.use_response_expansion &&
+            kt_double_equal_h(hs[i].coarse_response, 0.0))
+            redo.push_back(i);
     }
     // up to three retries, +20 degrees each (ScanMatcher::MatchScan).  A retry re-runs the whole
     // pipeline for the affected items with the wider coarse angle range (rare path).
@@ -715,7 +799,7 @@ void ym_destroy(ym_matcher *m) {
     m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
-    m->tmp_ranges_host.release(); m->stamps.release();
+    m->tmp_ranges_host.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
     for (Slot &s : m->slots) {
         s.desc.release();
         s.result.release();
@@ -996,10 +1080,12 @@ int ym_debug_sums(ym_matcher *m, int item, int pass, uint32_t *out, int64_t out_
     if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
     const size_t n = m->last_sums_stride[pass];
     if (n == 0) return set_err(YM_ERR_INVALID, "pass %d did not run", pass);
-    if ((size_t)out_count < n) return set_err(YM_ERR_INVALID, "sums buffer too small: need %zu entries", n);
+    const size_t ncopy = std::min(n, (size_t)out_count); // a pass's volume is stored dense from the start of its slot
+    if (m->cfg.semantics == YM_SEM_KARTO && (size_t)out_count < n)
+        return set_err(YM_ERR_INVALID, "sums buffer too small: need %zu entries", n);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    HIP_TRY(hipMemcpy(out, m->sums.p + m->sums_pass_offset[pass] + (size_t)item * n, n * sizeof(uint32_t),
+    HIP_TRY(hipMemcpy(out, m->sums.p + m->sums_pass_offset[pass] + (size_t)item * n, ncopy * sizeof(uint32_t),
                       hipMemcpyDeviceToHost));
     return YM_OK;
 }

@@ -12,6 +12,8 @@
 #define YM_MAX_BEAMS 6000          // per scan; bounds the LDS staging of one scan (25 B per reading)
 #define YM_MAX_COARSE_NT 256         // coarse angles per pass (incl. response expansion)
 #define YM_MAX_FINE_NT 256           // fine angles
+#define YM_YAG_MAX_DIM 512            // yagpy lattice points per axis (np.arange lengths)
+#define YM_YAG_MAX_NT 256
 #define YM_MAX_KERNEL_HALF 20      // sigma <= 10*res  ->  half = Round(2*sigma/res) <= 20
 
 // Grid geometry of one matcher configuration + the device window chosen for one call.
@@ -78,4 +80,8 @@ struct YmItemState {
     int32_t regular[2];   // per pass: hypothesis cells form an exact lattice (fast path legal)
     int32_t base_count;   // chain length of this item (copied from the call descriptor)
     int32_t pad;
+    // "yagpy" semantics only: per pass lattice sizes and find_best_pose's return tuple
+    int32_t ydims[2][3];  // nx, ny, nt
+    int32_t ypad[2];
+    double ybest[2][8];   // response, x, y, t, xx, yy, xy, th
 };
