@@ -229,3 +229,16 @@ def test_yagpy_device_matches_oracle_both_passes():
     assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]), o.sums(0))
     assert np.array_equal(m.debug_sums(1, dims=r.meta["fine_dims"]), o.sums(1))
     assert abs(r.response - ro["response"]) <= 1e-12
+
+
+def test_order_dependent_smear_boundary():
+    # smear_deviation = 10 * resolution: the four neighbours of an occupied cell are 100 as well, so
+    # Karto's "value already set" skip makes the raster depend on point order
+    from tests.util import load_case
+    c = load_case("small_pen1_fine1")
+    cfg = dict(c["cfg"], search_size=0.32, resolution=0.005, smear_deviation=0.05)
+    from oracle import oracle as orc
+    assert (orc.kernel_karto(0.005, 0.05) == 100).sum() == 5
+    compare(cfg, c["query"], c["base"], True, True)
+    q, base = cfg2_scans(range_threshold=12.0)
+    compare(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0), q, base[:4], True, True)

@@ -154,6 +154,7 @@ struct ym_matcher {
     hipStream_t own_stream, stream;
     YmGeom geom;                 // config part filled at create; window part per call
     std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)
+    int z2max = 0;               // largest squared cell distance whose kernel value is 100
     DevBuf<uint8_t> ktab;
     // workspace
     DevBuf<YmItemState> states;
@@ -294,6 +295,10 @@ int upload_lut(ym_matcher *m) {
             e = v;
         }
     int prev = 255;
+    m->z2max = 0;
+    for (int i = 0; i < n; i++)
+        if (lut[i] == YM_OCCUPIED) m->z2max = i;
+    if (m->z2max > 2) return set_err(YM_ERR_UNSUPPORTED, "smear kernel holds 100 out to squared distance %d", m->z2max);
     std::vector<uint8_t> q(n + 8, 0);
     for (int i = 0; i < n; i++) {
         if (lut[i] < 0) { q[i] = (uint8_t)prev; continue; } // unreachable distance: never looked up
@@ -366,11 +371,6 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if (B <= 0) return set_err(YM_ERR_INVALID, "empty call");
     HIP_TRY(hipSetDevice(m->device));
     YmGeom g = m->geom;
-    if (g.zone_count > 1)
-        return set_err(YM_ERR_UNSUPPORTED,
-                       "smear_deviation/resolution = %g makes Karto's AddScan order-dependent (kernel has %d taps "
-                       "equal to 100); not supported by this build",
-                       m->cfg.smear_deviation / m->cfg.resolution, g.zone_count);
 
     // ---- sizes
     int max_n = 1, max_base = 1;
@@ -521,6 +521,18 @@ int launch_call(ym_matcher *m, Slot &slot) {
         }
         const size_t lds = YM_PREP_LDS_BYTES(max_n);
         hipLaunchKernelGGL(ym::prepare_kernel, dim3(max_base + 1, B), dim3(YM_PREP_THREADS), lds, st, a);
+    }
+    // ---- K1b select: Karto's order-dependent "value already set" rule (only when the kernel has 100-valued taps off-centre)
+    if (g.zone_count > 1) {
+        const size_t pts = (size_t)max_base * max_n;
+        int log2cap = 10;
+        while (((size_t)1 << log2cap) < 2 * pts) log2cap++;
+        if (log2cap > 15 || g.storage_w >= 32768)
+            return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 16384 readings are not supported",
+                           m->cfg.smear_deviation / m->cfg.resolution);
+        ym::SelectArgs a;
+        a.cells = m->cells.p; a.max_n = max_n; a.max_base = max_base; a.z2max = m->z2max; a.log2cap = log2cap;
+        hipLaunchKernelGGL(ym::select_kernel, dim3(B), dim3(64), sizeof(unsigned) << log2cap, st, a);
     }
     // ---- K2 raster
     {
@@ -781,6 +793,7 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     }
     m->stream = m->own_stream;
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot raise the dynamic LDS limit of prepare_kernel");

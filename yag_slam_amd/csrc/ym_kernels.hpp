@@ -388,6 +388,75 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     YM_STAMP_B1(a, 23);
 }
 
+// ================================================================== K1b select (only when the smear kernel has taps == 100 off-centre)
+// Karto's AddScan skips a point whose cell already holds 100 ("value already set").  With
+// smear_deviation >= 9.99 * resolution the four neighbours of an occupied cell are stamped 100 as
+// well, so whether a point is rasterised depends on the points before it: a point is EFFECTIVE iff
+// no earlier effective point lies within squared cell distance z2max (the radius of the kernel's
+// 100-valued disc).  This kernel replays that greedy rule in Karto's order (base scans in order,
+// beams in order) and erases the non-effective points from `cells`; the raster kernel then stamps
+// exactly the effective set.  One wave per item: 64 points per step are checked in parallel against
+// an LDS hash set of earlier effective cells, conflicts inside the step are resolved lane by lane.
+struct SelectArgs {
+    int2 *cells;          // [B][max_base][max_n]
+    int32_t max_n, max_base;
+    int32_t z2max;        // largest squared distance whose kernel value is 100
+    int32_t log2cap;      // hash capacity = 1 << log2cap entries (dynamic LDS)
+};
+
+__device__ __forceinline__ unsigned select_key(int x, int y) {
+    return ((unsigned)(y + 32768) << 16) | ((unsigned)(x + 32768) & 0xffffu);
+}
+
+__global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
+    extern __shared__ unsigned table[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const unsigned cap = 1u << a.log2cap, maskcap = cap - 1u;
+    for (unsigned i = lane; i < cap; i += 64) table[i] = 0u;
+    __syncthreads();
+    int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
+    const int total = a.max_base * a.max_n;
+    const int R = a.z2max >= 1 ? 1 : 0; // z2max <= 2 is guaranteed by smear <= 10 * resolution
+    for (int e0 = 0; e0 < total; e0 += 64) {
+        const int e = e0 + lane;
+        int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+        if (e < total) c = cells[e];
+        bool cand = c.x != YM_CELL_NONE, skipped = false;
+        if (cand) { // an earlier effective point within the 100-disc?
+            for (int dy = -R; dy <= R && !skipped; dy++)
+                for (int dx = -R; dx <= R && !skipped; dx++) {
+                    if (dx * dx + dy * dy > a.z2max) continue;
+                    const unsigned key = select_key(c.x + dx, c.y + dy);
+                    unsigned hsh = (key * 2654435761u) >> (32 - a.log2cap);
+                    for (;;) {
+                        const unsigned t = table[hsh];
+                        if (t == 0u) break;
+                        if (t == key) { skipped = true; break; }
+                        hsh = (hsh + 1u) & maskcap;
+                    }
+                }
+            if (skipped) cand = false;
+        }
+        unsigned long long m = __ballot(cand);
+        while (m) { // lowest remaining candidate is effective; it knocks out later ones in its disc
+            const int L = __ffsll((long long)m) - 1;
+            const int lx = __builtin_amdgcn_readlane(c.x, L), ly = __builtin_amdgcn_readlane(c.y, L);
+            if (lane == L) {
+                const unsigned key = select_key(c.x, c.y);
+                unsigned hsh = (key * 2654435761u) >> (32 - a.log2cap);
+                while (table[hsh] != 0u) hsh = (hsh + 1u) & maskcap;
+                table[hsh] = key;
+                cand = false;
+            } else if (cand) {
+                const int dx = c.x - lx, dy = c.y - ly;
+                if (dx * dx + dy * dy <= a.z2max) { cand = false; skipped = true; }
+            }
+            m = __ballot(cand);
+        }
+        if (skipped) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    }
+}
+
 // ================================================================== K2 raster
 #define YM_TILE_W 64
 #define YM_TILE_H 32
