@@ -242,3 +242,12 @@ def test_order_dependent_smear_boundary():
     compare(cfg, c["query"], c["base"], True, True)
     q, base = cfg2_scans(range_threshold=12.0)
     compare(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0), q, base[:4], True, True)
+
+
+def test_stress_config_full_lattice():
+    # BASELINE configs[4]: search_size=2.0 resolution=0.005 coarse_angle_offset=0.785 (201x201x46 + 99
+    # hypotheses); every one of the 1.86 M integer sums is compared with the oracle
+    q, base = cfg2_scans()
+    cfg = dict(search_size=2.0, resolution=0.005, coarse_search_angle_offset=0.785)
+    r, ro = compare(cfg, q, base, True, True, check_grid=True)
+    assert r.meta["coarse_dims"] == (201, 201, 46) and r.meta["hypotheses"] == 1858545

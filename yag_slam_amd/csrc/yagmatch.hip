@@ -532,7 +532,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
                            m->cfg.smear_deviation / m->cfg.resolution);
         ym::SelectArgs a;
         a.cells = m->cells.p; a.max_n = max_n; a.max_base = max_base; a.z2max = m->z2max; a.log2cap = log2cap;
-        hipLaunchKernelGGL(ym::select_kernel, dim3(B), dim3(64), sizeof(unsigned) << log2cap, st, a);
+        if (m->z2max <= 1) hipLaunchKernelGGL(ym::select_kernel<5>, dim3(B), dim3(64), sizeof(unsigned) << log2cap, st, a);
+        else hipLaunchKernelGGL(ym::select_kernel<9>, dim3(B), dim3(64), sizeof(unsigned) << log2cap, st, a);
     }
     // ---- K2 raster
     {
@@ -793,7 +794,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     }
     m->stream = m->own_stream;
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot raise the dynamic LDS limit of prepare_kernel");

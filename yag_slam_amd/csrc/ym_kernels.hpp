@@ -408,52 +408,105 @@ __device__ __forceinline__ unsigned select_key(int x, int y) {
     return ((unsigned)(y + 32768) << 16) | ((unsigned)(x + 32768) & 0xffffu);
 }
 
+// Probe an open-addressing table (empty = 0) for the NB cells of a disc around (x, y), all first
+// probes in flight together.  Returns a bit per neighbour that was found; slot_out receives the slot.
+template <int NB>
+__device__ __forceinline__ unsigned select_probe(const unsigned *table, unsigned maskcap, int shift, int x, int y,
+                                                 unsigned (&slot_out)[NB]) {
+    // neighbour order: centre first, then the 4-neighbourhood, then the diagonals
+    constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
+    constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
+    unsigned key[NB], hsh[NB], t[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        key[n] = select_key(x + DX[n], y + DY[n]);
+        hsh[n] = (key[n] * 2654435761u) >> shift;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; n++) t[n] = table[hsh[n]];
+    unsigned found = 0u, pending = 0u;
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        if (t[n] == key[n]) found |= 1u << n;
+        else if (t[n] != 0u) pending |= 1u << n;
+    }
+    while (pending) { // collisions: keep probing linearly (rare)
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+            if (pending & (1u << n)) {
+                hsh[n] = (hsh[n] + 1u) & maskcap;
+                const unsigned v = table[hsh[n]];
+                if (v == key[n]) { found |= 1u << n; pending &= ~(1u << n); }
+                else if (v == 0u) pending &= ~(1u << n);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; n++) slot_out[n] = hsh[n];
+    return found;
+}
+
+// NB = 5 for z2max = 1 (plus-shaped disc), 9 for z2max = 2
+template <int NB>
 __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
-    extern __shared__ unsigned table[];
+    extern __shared__ unsigned table[];          // effective cells of all earlier steps
+    __shared__ unsigned step_key[256];           // cells of this step's candidates ...
+    __shared__ unsigned step_cnt[256];           // ... and how many candidates sit on each
     const int b = blockIdx.x, lane = threadIdx.x;
     const unsigned cap = 1u << a.log2cap, maskcap = cap - 1u;
     for (unsigned i = lane; i < cap; i += 64) table[i] = 0u;
-    __syncthreads();
     int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     const int total = a.max_base * a.max_n;
-    const int R = a.z2max >= 1 ? 1 : 0; // z2max <= 2 is guaranteed by smear <= 10 * resolution
+    int2 c_next = lane < total ? cells[lane] : make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    unsigned slots[NB];
     for (int e0 = 0; e0 < total; e0 += 64) {
         const int e = e0 + lane;
-        int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
-        if (e < total) c = cells[e];
+        const int2 c = c_next;
+        c_next = (e + 64) < total ? cells[e + 64] : make_int2(YM_CELL_NONE, YM_CELL_NONE); // prefetch
+        for (int i = lane; i < 256; i += 64) { step_key[i] = 0u; step_cnt[i] = 0u; }
         bool cand = c.x != YM_CELL_NONE, skipped = false;
-        if (cand) { // an earlier effective point within the 100-disc?
-            for (int dy = -R; dy <= R && !skipped; dy++)
-                for (int dx = -R; dx <= R && !skipped; dx++) {
-                    if (dx * dx + dy * dy > a.z2max) continue;
-                    const unsigned key = select_key(c.x + dx, c.y + dy);
-                    unsigned hsh = (key * 2654435761u) >> (32 - a.log2cap);
-                    for (;;) {
-                        const unsigned t = table[hsh];
-                        if (t == 0u) break;
-                        if (t == key) { skipped = true; break; }
-                        hsh = (hsh + 1u) & maskcap;
-                    }
-                }
-            if (skipped) cand = false;
+        // (1) an earlier effective point within the 100-disc?
+        if (cand && select_probe<NB>(table, maskcap, 32 - a.log2cap, c.x, c.y, slots) != 0u) { cand = false; skipped = true; }
+        // (2) which candidates of this step have another candidate of the step in their disc?
+        if (cand) {
+            const unsigned key = select_key(c.x, c.y);
+            unsigned hsh = (key * 2654435761u) >> 24;
+            for (;;) {
+                const unsigned prev = atomicCAS(&step_key[hsh], 0u, key);
+                if (prev == 0u || prev == key) break;
+                hsh = (hsh + 1u) & 255u;
+            }
+            atomicAdd(&step_cnt[hsh], 1u);
         }
-        unsigned long long m = __ballot(cand);
-        while (m) { // lowest remaining candidate is effective; it knocks out later ones in its disc
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave: LDS ops are in order
+        bool conflict = false;
+        if (cand) {
+            const unsigned found = select_probe<NB>(step_key, 255u, 24, c.x, c.y, slots);
+            conflict = (found & ~1u) != 0u || step_cnt[slots[0]] > 1u; // a neighbour cell, or company on my own cell
+        }
+        // (3) conflict-free candidates are effective; the others are resolved in order:
+        // the lowest remaining one is effective and knocks out later candidates in its disc
+        bool effective = cand && !conflict;
+        bool open = cand && conflict;
+        unsigned long long m = __ballot(open);
+        while (m) {
             const int L = __ffsll((long long)m) - 1;
             const int lx = __builtin_amdgcn_readlane(c.x, L), ly = __builtin_amdgcn_readlane(c.y, L);
             if (lane == L) {
-                const unsigned key = select_key(c.x, c.y);
-                unsigned hsh = (key * 2654435761u) >> (32 - a.log2cap);
-                while (table[hsh] != 0u) hsh = (hsh + 1u) & maskcap;
-                table[hsh] = key;
-                cand = false;
-            } else if (cand) {
+                effective = true;
+                open = false;
+            } else if (open) {
                 const int dx = c.x - lx, dy = c.y - ly;
-                if (dx * dx + dy * dy <= a.z2max) { cand = false; skipped = true; }
+                if (dx * dx + dy * dy <= a.z2max) { open = false; skipped = true; }
             }
-            m = __ballot(cand);
+            m = __ballot(open);
+        }
+        if (effective) { // distinct cells by construction: claim a free slot with a CAS
+            const unsigned key = select_key(c.x, c.y);
+            unsigned hsh = (key * 2654435761u) >> (32 - a.log2cap);
+            while (atomicCAS(&table[hsh], 0u, key) != 0u) hsh = (hsh + 1u) & maskcap;
         }
         if (skipped) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+        __builtin_amdgcn_s_waitcnt(0xC07F); // inserts land before the next step's lookups
     }
 }
 
