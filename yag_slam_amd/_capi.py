@@ -19,7 +19,7 @@ EXPORTS = (
     "ym_scan_size", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
     "ym_batch_run_async", "ym_batch_wait", "ym_debug_grid_info",
-    "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_stamps",
+    "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_option", "ym_debug_stamps",
     "ym_profile_enable",
     "ym_profile_read",
 )
@@ -144,6 +144,7 @@ def lib():
     L.ym_debug_sums.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int64]
     L.ym_debug_query_local.argtypes = [vp, C.c_int, dp, C.c_int32, ip]
     L.ym_debug_cells.argtypes = [vp, C.c_int, ip, C.c_int64, ip]
+    L.ym_debug_option.argtypes = [vp, C.c_int, C.c_int]
     L.ym_debug_stamps.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.c_int32]
     L.ym_profile_enable.argtypes = [vp, C.c_int]
     L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]

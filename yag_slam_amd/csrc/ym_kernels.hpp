@@ -774,6 +774,169 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     }
 }
 
+// ---- LDS-staged variant of the coarse correlate (SX = 2).
+// One wave per block.  The wave walks its beam chunk in sub-chunks of 32 beams; for each sub-chunk it
+// copies the rectangle of the two column planes that its 64 lane jobs can touch (bounding box of the
+// 32 beam offsets + the hypothesis rectangle of the wave) into LDS with aligned 16-byte loads, and
+// then serves every (beam, lane job) gather from LDS: two aligned ds_read_b128 + a wave-uniform byte
+// funnel shift (v_alignbyte_b32) instead of one byte-unaligned global load.  The vector L1 charges
+// ~1.9 tag lookups per lane for the unaligned global form (profiles/r01_b_correlate_counters.md); the
+// staged form needs ~8x fewer global lane-accesses.  A sub-chunk whose rectangle does not fit the
+// LDS budget (range discontinuity inside the 32 beams) falls back to direct global loads.
+#define YM_LDS_SUB 32
+#define YM_LDS_BYTES (24 * 1024)
+__device__ __forceinline__ int2 lookup_cell(double2 p, double cosine, double sine, double off_x, double off_y, double scale) {
+    const double ox = cosine * p.x - sine * p.y;
+    const double oy = sine * p.x + cosine * p.y;
+    return make_int2(world_to_grid(ox + off_x, off_x, scale), world_to_grid(oy + off_y, off_y, scale));
+}
+
+__global__ __launch_bounds__(64) void correlate_lds_kernel(CorrArgs a) {
+    constexpr int G = 16;
+    __shared__ __attribute__((aligned(16))) unsigned char region[YM_LDS_BYTES];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.z;
+    const int k = blockIdx.y % a.lat.nt, chunk = blockIdx.y / a.lat.nt;
+    const int njobs = a.lat.ny * a.ngx;
+    const int j_first = blockIdx.x * 64, j_last = min(njobs, j_first + 64) - 1;
+    const bool active = j_first + lane <= j_last;
+    const int job = min(j_first + lane, j_last); // idle lanes shadow the last job (valid addresses, result dropped)
+    const int iy = job / a.ngx, xg = job - iy * a.ngx;
+    const YmItemState &st = a.states[b];
+    const int nq = st.nq;
+    const int i0 = chunk * a.chunk;
+    const int32_t *cxp = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    const int cx0 = cxp[0], cy0 = cxp[a.dim_stride];
+    const int half_pitch = a.g.pitch / 2;
+    const int plane_bytes = half_pitch * a.g.win_w;
+    const uint8_t *__restrict__ planes = a.planes + (size_t)b * a.grid_stride;
+    const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
+    const double off_x = st.off_x, off_y = st.off_y;
+    const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+    // hypothesis rectangle of this wave (wave-uniform)
+    const int iy_min = j_first / a.ngx, iy_max = j_last / a.ngx;
+    const int xg_min = iy_min == iy_max ? j_first % a.ngx : 0, xg_max = iy_min == iy_max ? j_last % a.ngx : a.ngx - 1;
+    if (!st.regular[0]) {
+        // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
+        if (!active) return;
+        const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+        const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+        const int32_t *cyp = cxp + a.dim_stride;
+        uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+                        (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
+        const int i1 = min(nq, i0 + a.chunk);
+        for (int j = 0; j < G; j++) {
+            const int ix = xg * G + j;
+            unsigned sum = 0;
+            if (ix < a.lat.nx) {
+                const int base = cyp[iy] * a.g.pitch + cxp[ix];
+                for (int i = i0; i < i1; i++) {
+                    const int2 c = lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale);
+                    const unsigned idx = (unsigned)(base + c.x + c.y * a.g.pitch);
+                    sum += idx < limit ? grid[idx] : 0u;
+                }
+            }
+            out[j] = sum;
+        }
+        return;
+    }
+    uint32_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0u;
+
+    for (int s0 = 0; s0 < a.chunk; s0 += YM_LDS_SUB) {
+        const int nvalid = min(min(YM_LDS_SUB, a.chunk - s0), nq - (i0 + s0)); // wave-uniform
+        if (nvalid <= 0) break;
+        // cell offsets of the sub-chunk's beams: lane l and l+32 both hold beam l
+        const int bi = lane & (YM_LDS_SUB - 1);
+        const bool bvalid = bi < nvalid;
+        int2 cell = make_int2(0, 0);
+        if (bvalid) cell = lookup_cell(ql[i0 + s0 + bi], cs.x, cs.y, off_x, off_y, a.g.scale);
+        const int gx_min = wave_reduce(bvalid ? cell.x : INT32_MAX, OpMinI()), gx_max = wave_reduce(bvalid ? cell.x : INT32_MIN, OpMaxI());
+        const int gy_min = wave_reduce(bvalid ? cell.y : INT32_MAX, OpMinI()), gy_max = wave_reduce(bvalid ? cell.y : INT32_MIN, OpMaxI());
+        // rectangle of plane bytes the wave can touch for these beams
+        const int X0 = cx0 + gx_min + 2 * G * xg_min, X1 = cx0 + gx_max + 2 * G * xg_max + 2 * (G - 1);
+        const int Y0 = cy0 + 2 * iy_min + gy_min, Y1 = cy0 + 2 * iy_max + gy_max;
+        const int Xp0 = (X0 >> 1) & ~15;
+        int spr = ((((X1 >> 1) - Xp0 + 1) + 15) >> 4) + 1; // 16-byte segments per row (+1: the funnel reads one block ahead)
+        spr |= 1;                                           // odd: rows 2 apart land in different 16-byte bank groups
+        const int P = spr * 16, H = Y1 - Y0 + 1;
+        const bool use_lds = 2 * H * P <= YM_LDS_BYTES;
+        if (use_lds) {
+            const int per_plane = H * spr, nseg = 2 * per_plane;
+            for (int sg0 = 0; sg0 < nseg; sg0 += 4 * 64) {
+                uint4 v[4];
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int sg = sg0 + u * 64 + lane;
+                    dst[u] = -1;
+                    if (sg < nseg) {
+                        const int pl = sg >= per_plane ? 1 : 0, rem = sg - pl * per_plane;
+                        const int row = rem / spr, col = rem - row * spr;
+                        v[u] = *reinterpret_cast<const uint4 *>(planes + (size_t)pl * plane_bytes + (size_t)(Y0 + row) * half_pitch + Xp0 + 16 * col);
+                        dst[u] = pl * H * P + row * P + 16 * col;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (dst[u] >= 0) *reinterpret_cast<uint4 *>(region + dst[u]) = v[u];
+            }
+        }
+        for (int bb = 0; bb < nvalid; bb++) {
+            const int gxb = __builtin_amdgcn_readlane(cell.x, bb), gyb = __builtin_amdgcn_readlane(cell.y, bb);
+            const int col0 = cx0 + gxb, par = col0 & 1; // wave-uniform
+            const uint32_t m = 0x00FF00FFu;
+            uint32_t x0, x1, x2, x3;
+            if (use_lds) {
+                const int a16 = (col0 >> 1) & 15;          // byte misalignment inside a 16-byte block, wave-uniform
+                const int addr = par * H * P + (cy0 + 2 * iy + gyb - Y0) * P + (((col0 >> 1) - Xp0) & ~15) + 16 * xg;
+                const uint4 w0 = *reinterpret_cast<const uint4 *>(region + addr);
+                const uint4 w1 = *reinterpret_cast<const uint4 *>(region + addr + 16);
+                const int r = a16 & 3;
+                switch (a16 >> 2) {
+                case 0:
+                    x0 = __builtin_amdgcn_alignbyte(w0.y, w0.x, r); x1 = __builtin_amdgcn_alignbyte(w0.z, w0.y, r);
+                    x2 = __builtin_amdgcn_alignbyte(w0.w, w0.z, r); x3 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r);
+                    break;
+                case 1:
+                    x0 = __builtin_amdgcn_alignbyte(w0.z, w0.y, r); x1 = __builtin_amdgcn_alignbyte(w0.w, w0.z, r);
+                    x2 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r); x3 = __builtin_amdgcn_alignbyte(w1.y, w1.x, r);
+                    break;
+                case 2:
+                    x0 = __builtin_amdgcn_alignbyte(w0.w, w0.z, r); x1 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r);
+                    x2 = __builtin_amdgcn_alignbyte(w1.y, w1.x, r); x3 = __builtin_amdgcn_alignbyte(w1.z, w1.y, r);
+                    break;
+                default:
+                    x0 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r); x1 = __builtin_amdgcn_alignbyte(w1.y, w1.x, r);
+                    x2 = __builtin_amdgcn_alignbyte(w1.z, w1.y, r); x3 = __builtin_amdgcn_alignbyte(w1.w, w1.z, r);
+                    break;
+                }
+            } else {
+                uint4 w;
+                __builtin_memcpy(&w, planes + (size_t)par * plane_bytes + (size_t)(cy0 + 2 * iy + gyb) * half_pitch + (col0 >> 1) + G * xg, 16);
+                x0 = w.x; x1 = w.y; x2 = w.z; x3 = w.w;
+            }
+            acc[0] += x0 & m; acc[1] += (x0 >> 8) & m;
+            acc[2] += x1 & m; acc[3] += (x1 >> 8) & m;
+            acc[4] += x2 & m; acc[5] += (x2 >> 8) & m;
+            acc[6] += x3 & m; acc[7] += (x3 >> 8) & m;
+        }
+    }
+    if (active) {
+        uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+                        (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
+        uint32_t r[G];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
+            r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
+        }
+#pragma unroll
+        for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+    }
+}
+
 // ================================================================== K5a score
 #define YM_SCORE_THREADS 256
 struct ScoreArgs {

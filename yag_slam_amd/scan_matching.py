@@ -174,6 +174,9 @@ class ScanMatcher(object):
                                                    C.byref(n)))
         return buf[:n.value].copy()
 
+    def debug_option(self, option, value):
+        _capi.check(self._lib.ym_debug_option(self._m, int(option), int(value)))
+
     def debug_stamps(self, enable=True):
         buf = (C.c_uint64 * 32)()
         _capi.check(self._lib.ym_debug_stamps(self._m, int(bool(enable)), buf, 32))
