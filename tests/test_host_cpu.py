@@ -122,3 +122,29 @@ def test_synthetic_scene_is_reproducible():
     assert np.isnan(d).sum() == 10 and (d > synth.MAX_RANGE).sum() == 10
     truth, prior = synth.loop_trajectory(50)
     assert truth.shape == (50, 3) and np.all(np.hypot(*(truth[1:, :2] - truth[:-1, :2]).T) < 0.15)
+
+
+def test_sequential_mapper_call_pattern():
+    # graph_slam.py:306-339: odometry prior, penalty + fine, running chain of at most 10
+    from collections import namedtuple
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.transform import Transform
+    R = namedtuple("R", "best_pose response covariance meta")
+    calls = []
+
+    class Stub:
+        def match_scan(self, q, base, pen, fine):
+            calls.append((len(base), pen, fine, q.corrected_pose.x))
+            return R(Transform(q.corrected_pose.x + 0.01, q.corrected_pose.y, 0, q.corrected_pose.euler[-1]), 1.0, None, {})
+
+    mp = SequentialMapper(Stub())
+    for i in range(14):
+        s = LocalizedRangeScan([1.0] * 5, -1, 1, 0.5, 0, 10, 5, 0, 0, 0)
+        s.odom_pose = Transform(0.1 * i, 0, 0, 0.0)
+        mp.process_scan(s)
+    assert len(calls) == 13 and all(c[1] and c[2] for c in calls)
+    assert [c[0] for c in calls] == [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10]
+    # prior = last corrected (which carries the accumulated +0.01 corrections) + odometry increment
+    assert abs(calls[-1][3] - (0.1 * 13 + 0.01 * 12)) < 1e-9
+    assert len(mp.running_scans) == 10 and mp.running_scans[-1].num == 13
