@@ -44,6 +44,16 @@ def build_inputs(batch, rank):
     return query, chains
 
 
+def traffic_bytes(batch):
+    """HBM bytes per correlate launch from the PMC pass recorded under profiles/ (FETCH_SIZE with the gfx950
+    x2 correction of MI355X_MICROARCH.md); only valid for the batch size it was measured at."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "traffic_correlate.json")))
+        return t["hbm_bytes_per_launch"] if int(t["batch"]) == int(batch) else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds=6.0):
     """The CPU oracle (karto semantics, -O3 -march=native on this host) on the same cfg2 problem."""
     from oracle import oracle as orc
@@ -91,7 +101,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: libyagmatch has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("YM_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path with one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -194,7 +204,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic_bytes(args.batch),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": corr_s * 1e6,
                 "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
