@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,8 @@ def main():
     m = ScanMatcher(None, device=local_rank)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
+    if args.correlate_variant >= 0:
+        m.debug_option(0, args.correlate_variant)
     query, chains = build_inputs(args.batch, rank)
     batch = m.make_batch(query, chains)
     nslots = 32

@@ -169,7 +169,7 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
  * out[(slot*max_n + i)*2 + {0,1}] = wx, wy  or (INT32_MIN, INT32_MIN) for filtered points */
 int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int32_t *max_n);
 
-/* development aid: option 0 = use the LDS-staged coarse correlate kernel (default 1) */
+/* development aid: option 0 = coarse correlate kernel form (0 global loads = default, 1 experimental LDS staging) */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.

@@ -175,7 +175,7 @@ struct ym_matcher {
     DevBuf<double2> yrot;      // yagpy: points rotated per angle
     DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
     bool stamps_on = false;
-    bool use_lds_correlate = false; // measured slower than the global path in its current form
+    int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
     Slot slots[kAsyncSlots + 1]; // last one serves the synchronous entry points
@@ -502,9 +502,6 @@ int launch_call(ym_matcher *m, Slot &slot) {
     }
     const YmScanRef *d_scans = reinterpret_cast<const YmScanRef *>(slot.desc.dp);
     const YmItem *d_items = reinterpret_cast<const YmItem *>(slot.desc.dp + scans_bytes);
-    // The coarse lattice of Karto is regular by construction (centre = grid centre cell + integer steps); the
-    // LDS kernel relies on it and the generic kernel re-checks on the device.
-    const bool all_regular_hint = true;
     hipStream_t st = m->stream;
     unsigned long long *stamps = m->stamps_on ? m->stamps.p : nullptr;
     hipEvent_t ev_call = nullptr, ev_k = nullptr;
@@ -583,10 +580,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps; a.tpb = tpb;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 grid_dim(job_blocks, ktiles * n_chunks, B);
-        // the LDS-staged kernel pays off while one wave's hypothesis rectangle is small (<= 2 waves per angle);
-        // big lattices (stress config) already use full cache lines through the global path
-        if (sx == 2 && m->use_lds_correlate && all_regular_hint && njobs <= 128)
-            hipLaunchKernelGGL(ym::correlate_lds_kernel, dim3((njobs + 63) / 64, lc.nt * n_chunks, B), dim3(64), 0, st, a);
+        if (sx == 2 && m->use_lds_correlate == 1 && njobs <= 128)
+            hipLaunchKernelGGL(ym::correlate_lds_kernel, dim3((njobs + 63) / 64, lc.nt * n_chunks, B), dim3(256), 0, st, a);
         else if (sx == 2) hipLaunchKernelGGL(ym::correlate_kernel<2>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
         else hipLaunchKernelGGL(ym::correlate_kernel<1>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
@@ -1142,7 +1137,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
 
 int ym_debug_option(ym_matcher *m, int option, int value) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
-    if (option == 0) m->use_lds_correlate = value != 0;
+    if (option == 0) m->use_lds_correlate = value;
     else return set_err(YM_ERR_INVALID, "unknown option %d", option);
     return YM_OK;
 }

@@ -774,27 +774,138 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     }
 }
 
-// ---- LDS-staged variant of the coarse correlate (SX = 2).
-// One wave per block.  The wave walks its beam chunk in sub-chunks of 32 beams; for each sub-chunk it
-// copies the rectangle of the two column planes that its 64 lane jobs can touch (bounding box of the
-// 32 beam offsets + the hypothesis rectangle of the wave) into LDS with aligned 16-byte loads, and
-// then serves every (beam, lane job) gather from LDS: two aligned ds_read_b128 + a wave-uniform byte
-// funnel shift (v_alignbyte_b32) instead of one byte-unaligned global load.  The vector L1 charges
-// ~1.9 tag lookups per lane for the unaligned global form (profiles/r01_b_correlate_counters.md); the
-// staged form needs ~8x fewer global lane-accesses.  A sub-chunk whose rectangle does not fit the
-// LDS budget (range discontinuity inside the 32 beams) falls back to direct global loads.
-#define YM_LDS_SUB 32
-#define YM_LDS_BYTES (24 * 1024)
 __device__ __forceinline__ int2 lookup_cell(double2 p, double cosine, double sine, double off_x, double off_y, double scale) {
     const double ox = cosine * p.x - sine * p.y;
     const double oy = sine * p.x + cosine * p.y;
     return make_int2(world_to_grid(ox + off_x, off_x, scale), world_to_grid(oy + off_y, off_y, scale));
 }
 
-__global__ __launch_bounds__(64) void correlate_lds_kernel(CorrArgs a) {
+// ---- LDS-staged coarse correlate (experimental, off by default): 4 waves per block share one staged
+// rectangle and the staging of sub-chunk s+2 is in flight (global -> registers) while sub-chunk s is gathered.
+//   block   = (item, angle, beam chunk, 64 lane jobs); wave w gathers beams w, w+4, ... of every sub-chunk
+//   stage   = both column planes of the rectangle (rows Y0..Y0+H, plane bytes Xp0..Xp0+16*spr) of a 16-beam
+//             sub-chunk, copied with aligned 16-byte loads into an LDS buffer of fixed pitch 112 B
+//   gather  = two aligned ds_read_b128 per (beam, lane job) + wave-uniform byte funnel (v_alignbyte_b32)
+//   pipeline per iteration s: issue loads of s+2 -> gather s from buffer s&1 -> store registers of s+1 into
+//             buffer (s+1)&1 -> barrier
+// A sub-chunk whose rectangle exceeds 96 rows x 7 segments is served by direct global loads instead.
+// Measured (profiles/r01_c_alignment_experiment.md): bit-exact, and exactly as fast as the global-load kernel:
+// it removes the L1 lane-access bottleneck but issues ~4x more instructions per gather (a staged byte is
+// used less than once because the rectangle spans both column planes and both row parities).
+#define YM_L2_SUB 16
+#define YM_L2_ROWS 96
+#define YM_L2_SEGS 7
+#define YM_L2_PITCH (16 * YM_L2_SEGS)
+#define YM_L2_PLANE (YM_L2_ROWS * YM_L2_PITCH)
+#define YM_L2_BUF (2 * YM_L2_PLANE)
+struct L2Rect { int Xp0, Y0, H, spr, use_lds, nvalid; };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// The staging loads are inline asm on purpose: hipcc otherwise sinks a load whose only use is a
+// conditional LDS store down to that store and waits vmcnt(0) right there, which serialises the
+// pipeline (seen in the ISA).  As asm they are issued where written; the matching waits are the
+// explicit counted s_waitcnt below (gfx9 vmcnt retires in order).
+__device__ __forceinline__ void l2_stage_load(u32x4 (&v)[6], const L2Rect &r, const uint8_t *planes, int plane_bytes,
+                                              int half_pitch) {
+    const int col = threadIdx.x & 7, row0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            // idle lanes re-read a clamped in-rectangle address: every lane issues all six loads
+            const int row = min(row0 + 32 * u, max(r.H - 1, 0));
+            const int cc = min(col, max(r.spr - 1, 0));
+            const uint8_t *p = planes + (size_t)pl * plane_bytes + (size_t)(r.Y0 + row) * half_pitch + r.Xp0 + 16 * cc;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[pl * 3 + u]) : "v"(p) : "memory");
+        }
+}
+// wait until at most N vector-memory operations are outstanding, then hand the six registers to the compiler
+#define YM_L2_WAIT(N, v)                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                     \
+                 : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5])          \
+                 :                                                                                             \
+                 : "memory")
+__device__ __forceinline__ void l2_stage_store(const u32x4 (&v)[6], const L2Rect &r, unsigned char *buf) {
+    const int col = threadIdx.x & 7, row0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int row = row0 + 32 * u;
+            if (r.use_lds && row < r.H && col < r.spr)
+                *reinterpret_cast<u32x4 *>(buf + pl * YM_L2_PLANE + row * YM_L2_PITCH + 16 * col) = v[pl * 3 + u];
+        }
+}
+
+__device__ __forceinline__ L2Rect l2_rect_of(const int *s_rect, int nsub, int s) {
+    L2Rect r;
+    r.Xp0 = r.Y0 = r.H = r.spr = r.use_lds = r.nvalid = 0;
+    if (s < nsub) {
+        const int *p = s_rect + s * 8;
+        r.Xp0 = p[0]; r.Y0 = p[1]; r.H = p[2]; r.spr = p[3]; r.use_lds = p[4]; r.nvalid = p[5];
+    }
+    return r;
+}
+struct L2Ctx { // wave/lane constants of the gather
+    const uint8_t *planes;
+    const int2 *cells;
+    int cx0, cy0, iy, xg, wave, plane_bytes, half_pitch;
+};
+// gather the beams of sub-chunk s that belong to this wave
+__device__ __forceinline__ void l2_gather(uint32_t (&acc)[8], const L2Ctx &c, int s, const L2Rect &r, const unsigned char *buf) {
     constexpr int G = 16;
-    __shared__ __attribute__((aligned(16))) unsigned char region[YM_LDS_BYTES];
-    const int lane = threadIdx.x;
+#pragma unroll
+    for (int q4 = 0; q4 < YM_L2_SUB / 4; q4++) {
+        const int bb = c.wave + 4 * q4;
+        if (bb < r.nvalid) { // wave-uniform
+            const int2 cc = c.cells[s * YM_L2_SUB + bb];
+            const int gxb = __builtin_amdgcn_readfirstlane(cc.x), gyb = __builtin_amdgcn_readfirstlane(cc.y);
+            const int col0 = c.cx0 + gxb, par = col0 & 1;
+            uint32_t x0, x1, x2, x3;
+            if (r.use_lds) {
+                const int a16 = (col0 >> 1) - r.Xp0;
+                const int addr = par * YM_L2_PLANE + (c.cy0 + 2 * c.iy + gyb - r.Y0) * YM_L2_PITCH + (a16 & ~15) + 16 * c.xg;
+                const uint4 w0 = *reinterpret_cast<const uint4 *>(buf + addr);
+                const uint4 w1 = *reinterpret_cast<const uint4 *>(buf + addr + 16);
+                const int rr = a16 & 3;
+                switch ((a16 >> 2) & 3) {
+                case 0:
+                    x0 = __builtin_amdgcn_alignbyte(w0.y, w0.x, rr); x1 = __builtin_amdgcn_alignbyte(w0.z, w0.y, rr);
+                    x2 = __builtin_amdgcn_alignbyte(w0.w, w0.z, rr); x3 = __builtin_amdgcn_alignbyte(w1.x, w0.w, rr);
+                    break;
+                case 1:
+                    x0 = __builtin_amdgcn_alignbyte(w0.z, w0.y, rr); x1 = __builtin_amdgcn_alignbyte(w0.w, w0.z, rr);
+                    x2 = __builtin_amdgcn_alignbyte(w1.x, w0.w, rr); x3 = __builtin_amdgcn_alignbyte(w1.y, w1.x, rr);
+                    break;
+                case 2:
+                    x0 = __builtin_amdgcn_alignbyte(w0.w, w0.z, rr); x1 = __builtin_amdgcn_alignbyte(w1.x, w0.w, rr);
+                    x2 = __builtin_amdgcn_alignbyte(w1.y, w1.x, rr); x3 = __builtin_amdgcn_alignbyte(w1.z, w1.y, rr);
+                    break;
+                default:
+                    x0 = __builtin_amdgcn_alignbyte(w1.x, w0.w, rr); x1 = __builtin_amdgcn_alignbyte(w1.y, w1.x, rr);
+                    x2 = __builtin_amdgcn_alignbyte(w1.z, w1.y, rr); x3 = __builtin_amdgcn_alignbyte(w1.w, w1.z, rr);
+                    break;
+                }
+            } else {
+                uint4 w;
+                __builtin_memcpy(&w, c.planes + (size_t)par * c.plane_bytes + (size_t)(c.cy0 + 2 * c.iy + gyb) * c.half_pitch + (col0 >> 1) + G * c.xg, 16);
+                x0 = w.x; x1 = w.y; x2 = w.z; x3 = w.w;
+            }
+            const uint32_t m = 0x00FF00FFu;
+            acc[0] += x0 & m; acc[1] += (x0 >> 8) & m;
+            acc[2] += x1 & m; acc[3] += (x1 >> 8) & m;
+            acc[4] += x2 & m; acc[5] += (x2 >> 8) & m;
+            acc[6] += x3 & m; acc[7] += (x3 >> 8) & m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void correlate_lds_kernel(CorrArgs a) {
+    constexpr int G = 16;
+    __shared__ __attribute__((aligned(16))) unsigned char region[2 * YM_L2_BUF];
+    __shared__ int2 s_cells[512];
+    __shared__ int s_rect[32 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int k = blockIdx.y % a.lat.nt, chunk = blockIdx.y / a.lat.nt;
     const int njobs = a.lat.ny * a.ngx;
@@ -810,130 +921,120 @@ __global__ __launch_bounds__(64) void correlate_lds_kernel(CorrArgs a) {
     const int half_pitch = a.g.pitch / 2;
     const int plane_bytes = half_pitch * a.g.win_w;
     const uint8_t *__restrict__ planes = a.planes + (size_t)b * a.grid_stride;
-    const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
-    const double off_x = st.off_x, off_y = st.off_y;
-    const double2 *ql = a.qlocal + (size_t)b * a.max_n;
-    // hypothesis rectangle of this wave (wave-uniform)
     const int iy_min = j_first / a.ngx, iy_max = j_last / a.ngx;
     const int xg_min = iy_min == iy_max ? j_first % a.ngx : 0, xg_max = iy_min == iy_max ? j_last % a.ngx : a.ngx - 1;
-    if (!st.regular[0]) {
+    const int nsub = (a.chunk + YM_L2_SUB - 1) / YM_L2_SUB;
+
+    // ---- cell offsets of the whole chunk, then one rectangle per 16-beam sub-chunk
+    {
+        const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
+        const double off_x = st.off_x, off_y = st.off_y;
+        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        for (int c = tid; c < a.chunk; c += 256) {
+            const int i = i0 + c;
+            s_cells[c] = i < nq ? lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale) : make_int2(0, 0);
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < nsub; s += 256) {
+        const int s0 = s * YM_L2_SUB;
+        const int nvalid = max(0, min(min(YM_L2_SUB, a.chunk - s0), nq - (i0 + s0)));
+        int gx0 = INT32_MAX, gx1 = INT32_MIN, gy0 = INT32_MAX, gy1 = INT32_MIN;
+        for (int j = 0; j < nvalid; j++) {
+            const int2 c = s_cells[s0 + j];
+            gx0 = min(gx0, c.x); gx1 = max(gx1, c.x); gy0 = min(gy0, c.y); gy1 = max(gy1, c.y);
+        }
+        int Xp0 = 0, Y0 = 0, H = 0, spr = 0, use_lds = 0;
+        if (nvalid > 0) {
+            const int X0 = cx0 + gx0 + 2 * G * xg_min, X1 = cx0 + gx1 + 2 * G * xg_max + 2 * (G - 1);
+            Y0 = cy0 + 2 * iy_min + gy0;
+            H = cy0 + 2 * iy_max + gy1 - Y0 + 1;
+            Xp0 = (X0 >> 1) & ~15;
+            spr = ((((X1 >> 1) - Xp0 + 1) + 15) >> 4) + 1; // +1: the funnel reads one block ahead
+            use_lds = (H <= YM_L2_ROWS && spr <= YM_L2_SEGS) ? 1 : 0;
+        }
+        int *r = s_rect + s * 8;
+        r[0] = Xp0; r[1] = Y0; r[2] = H; r[3] = spr; r[4] = use_lds; r[5] = nvalid;
+    }
+    __syncthreads();
+#define rect_of(S) l2_rect_of(s_rect, nsub, (S))
+
+    uint32_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0u;
+
+    L2Ctx ctx;
+    ctx.planes = planes; ctx.cells = s_cells; ctx.cx0 = cx0; ctx.cy0 = cy0; ctx.iy = iy; ctx.xg = xg; ctx.wave = wave;
+    ctx.plane_bytes = plane_bytes; ctx.half_pitch = half_pitch;
+    if (st.regular[0]) {
+        u32x4 va[6], vb[6]; // registers in flight: va holds even sub-chunks, vb odd ones
+        L2Rect r0 = rect_of(0), r1 = rect_of(1);
+        l2_stage_load(va, r0, planes, plane_bytes, half_pitch);
+        l2_stage_load(vb, r1, planes, plane_bytes, half_pitch);
+        YM_L2_WAIT(6, va);
+        l2_stage_store(va, r0, region);
+        __syncthreads();
+        for (int s = 0; s < nsub; s += 2) {
+            // even step: gather s from buffer 0; vb holds s+1; va is refilled with s+2
+            L2Rect rs = rect_of(s), rn = rect_of(s + 1), rnn = rect_of(s + 2);
+            if (rs.nvalid <= 0) break;
+            l2_stage_load(va, rnn, planes, plane_bytes, half_pitch);
+            l2_gather(acc, ctx, s, rs, region);
+            YM_L2_WAIT(6, vb); // the six loads of s+2 just issued may stay in flight
+            l2_stage_store(vb, rn, region + YM_L2_BUF);
+            __syncthreads();
+            // odd step: gather s+1 from buffer 1; va holds s+2; vb is refilled with s+3
+            if (rn.nvalid <= 0) break;
+            L2Rect rnnn = rect_of(s + 3);
+            l2_stage_load(vb, rnnn, planes, plane_bytes, half_pitch);
+            l2_gather(acc, ctx, s + 1, rn, region + YM_L2_BUF);
+            YM_L2_WAIT(6, va);
+            l2_stage_store(va, rnn, region);
+            __syncthreads();
+        }
+#undef rect_of
+        // ---- add the four waves' packed 16-bit sums, wave 0 writes the partials
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t *red = reinterpret_cast<uint32_t *>(region);
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[(wave * 8 + j) * 64 + lane] = acc[j];
+        __syncthreads();
+        if (wave == 0 && active) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = red[j * 64 + lane] + red[(8 + j) * 64 + lane] + red[(16 + j) * 64 + lane] + red[(24 + j) * 64 + lane];
+            uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+                            (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
+            uint32_t r[G];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
+                r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
+            }
+#pragma unroll
+            for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+        }
+    } else {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
-        if (!active) return;
+        if (wave != 0 || !active) return;
         const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
         const int32_t *cyp = cxp + a.dim_stride;
         uint32_t *out = a.partial + (size_t)b * a.partial_stride +
                         (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
-        const int i1 = min(nq, i0 + a.chunk);
+        const int n_here = min(nq - i0, a.chunk);
         for (int j = 0; j < G; j++) {
             const int ix = xg * G + j;
             unsigned sum = 0;
             if (ix < a.lat.nx) {
                 const int base = cyp[iy] * a.g.pitch + cxp[ix];
-                for (int i = i0; i < i1; i++) {
-                    const int2 c = lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale);
-                    const unsigned idx = (unsigned)(base + c.x + c.y * a.g.pitch);
+                for (int i = 0; i < n_here; i++) {
+                    const unsigned idx = (unsigned)(base + s_cells[i].x + s_cells[i].y * a.g.pitch);
                     sum += idx < limit ? grid[idx] : 0u;
                 }
             }
             out[j] = sum;
         }
-        return;
-    }
-    uint32_t acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] = 0u;
-
-    for (int s0 = 0; s0 < a.chunk; s0 += YM_LDS_SUB) {
-        const int nvalid = min(min(YM_LDS_SUB, a.chunk - s0), nq - (i0 + s0)); // wave-uniform
-        if (nvalid <= 0) break;
-        // cell offsets of the sub-chunk's beams: lane l and l+32 both hold beam l
-        const int bi = lane & (YM_LDS_SUB - 1);
-        const bool bvalid = bi < nvalid;
-        int2 cell = make_int2(0, 0);
-        if (bvalid) cell = lookup_cell(ql[i0 + s0 + bi], cs.x, cs.y, off_x, off_y, a.g.scale);
-        const int gx_min = wave_reduce(bvalid ? cell.x : INT32_MAX, OpMinI()), gx_max = wave_reduce(bvalid ? cell.x : INT32_MIN, OpMaxI());
-        const int gy_min = wave_reduce(bvalid ? cell.y : INT32_MAX, OpMinI()), gy_max = wave_reduce(bvalid ? cell.y : INT32_MIN, OpMaxI());
-        // rectangle of plane bytes the wave can touch for these beams
-        const int X0 = cx0 + gx_min + 2 * G * xg_min, X1 = cx0 + gx_max + 2 * G * xg_max + 2 * (G - 1);
-        const int Y0 = cy0 + 2 * iy_min + gy_min, Y1 = cy0 + 2 * iy_max + gy_max;
-        const int Xp0 = (X0 >> 1) & ~15;
-        int spr = ((((X1 >> 1) - Xp0 + 1) + 15) >> 4) + 1; // 16-byte segments per row (+1: the funnel reads one block ahead)
-        spr |= 1;                                           // odd: rows 2 apart land in different 16-byte bank groups
-        const int P = spr * 16, H = Y1 - Y0 + 1;
-        const bool use_lds = 2 * H * P <= YM_LDS_BYTES;
-        if (use_lds) {
-            const int per_plane = H * spr, nseg = 2 * per_plane;
-            for (int sg0 = 0; sg0 < nseg; sg0 += 4 * 64) {
-                uint4 v[4];
-                int dst[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int sg = sg0 + u * 64 + lane;
-                    dst[u] = -1;
-                    if (sg < nseg) {
-                        const int pl = sg >= per_plane ? 1 : 0, rem = sg - pl * per_plane;
-                        const int row = rem / spr, col = rem - row * spr;
-                        v[u] = *reinterpret_cast<const uint4 *>(planes + (size_t)pl * plane_bytes + (size_t)(Y0 + row) * half_pitch + Xp0 + 16 * col);
-                        dst[u] = pl * H * P + row * P + 16 * col;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (dst[u] >= 0) *reinterpret_cast<uint4 *>(region + dst[u]) = v[u];
-            }
-        }
-        for (int bb = 0; bb < nvalid; bb++) {
-            const int gxb = __builtin_amdgcn_readlane(cell.x, bb), gyb = __builtin_amdgcn_readlane(cell.y, bb);
-            const int col0 = cx0 + gxb, par = col0 & 1; // wave-uniform
-            const uint32_t m = 0x00FF00FFu;
-            uint32_t x0, x1, x2, x3;
-            if (use_lds) {
-                const int a16 = (col0 >> 1) & 15;          // byte misalignment inside a 16-byte block, wave-uniform
-                const int addr = par * H * P + (cy0 + 2 * iy + gyb - Y0) * P + (((col0 >> 1) - Xp0) & ~15) + 16 * xg;
-                const uint4 w0 = *reinterpret_cast<const uint4 *>(region + addr);
-                const uint4 w1 = *reinterpret_cast<const uint4 *>(region + addr + 16);
-                const int r = a16 & 3;
-                switch (a16 >> 2) {
-                case 0:
-                    x0 = __builtin_amdgcn_alignbyte(w0.y, w0.x, r); x1 = __builtin_amdgcn_alignbyte(w0.z, w0.y, r);
-                    x2 = __builtin_amdgcn_alignbyte(w0.w, w0.z, r); x3 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r);
-                    break;
-                case 1:
-                    x0 = __builtin_amdgcn_alignbyte(w0.z, w0.y, r); x1 = __builtin_amdgcn_alignbyte(w0.w, w0.z, r);
-                    x2 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r); x3 = __builtin_amdgcn_alignbyte(w1.y, w1.x, r);
-                    break;
-                case 2:
-                    x0 = __builtin_amdgcn_alignbyte(w0.w, w0.z, r); x1 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r);
-                    x2 = __builtin_amdgcn_alignbyte(w1.y, w1.x, r); x3 = __builtin_amdgcn_alignbyte(w1.z, w1.y, r);
-                    break;
-                default:
-                    x0 = __builtin_amdgcn_alignbyte(w1.x, w0.w, r); x1 = __builtin_amdgcn_alignbyte(w1.y, w1.x, r);
-                    x2 = __builtin_amdgcn_alignbyte(w1.z, w1.y, r); x3 = __builtin_amdgcn_alignbyte(w1.w, w1.z, r);
-                    break;
-                }
-            } else {
-                uint4 w;
-                __builtin_memcpy(&w, planes + (size_t)par * plane_bytes + (size_t)(cy0 + 2 * iy + gyb) * half_pitch + (col0 >> 1) + G * xg, 16);
-                x0 = w.x; x1 = w.y; x2 = w.z; x3 = w.w;
-            }
-            acc[0] += x0 & m; acc[1] += (x0 >> 8) & m;
-            acc[2] += x1 & m; acc[3] += (x1 >> 8) & m;
-            acc[4] += x2 & m; acc[5] += (x2 >> 8) & m;
-            acc[6] += x3 & m; acc[7] += (x3 >> 8) & m;
-        }
-    }
-    if (active) {
-        uint32_t *out = a.partial + (size_t)b * a.partial_stride +
-                        (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
-        uint32_t r[G];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
-            r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
-        }
-#pragma unroll
-        for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
     }
 }
 
