@@ -157,12 +157,15 @@ struct ym_matcher {
     int z2max = 0;               // largest squared cell distance whose kernel value is 100
     DevBuf<uint8_t> ktab;
     // workspace
+    DevBuf<unsigned char> desc_dev; // batch call descriptors (single calls travel in the kernel arguments)
     DevBuf<YmItemState> states;
     DevBuf<double2> qlocal;
     DevBuf<int2> cells;
     DevBuf<int4> bbox;
     DevBuf<uint8_t> grid;
     DevBuf<uint8_t> planes;    // even/odd column planes of every window
+    DevBuf<uint8_t> tile_zero; // per raster tile: window memory known to be zero (skips rewriting empty tiles)
+    size_t tz_sig[6] = {0, 0, 0, 0, 0, 0}; // memory/geometry the flags are valid for
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
@@ -500,9 +503,16 @@ int launch_call(ym_matcher *m, Slot &slot) {
         hi[i].base_count = call.items[i].base_count;
         hi[i].pad = 0;
     }
-    const YmScanRef *d_scans = reinterpret_cast<const YmScanRef *>(slot.desc.dp);
-    const YmItem *d_items = reinterpret_cast<const YmItem *>(slot.desc.dp + scans_bytes);
     hipStream_t st = m->stream;
+    const bool inline_desc = (B == 1 && nscans <= YM_INLINE_SCANS);
+    const YmScanRef *d_scans = nullptr;
+    const YmItem *d_items = nullptr;
+    if (!inline_desc) { // one async H2D copy; hundreds of blocks reading pinned host memory directly is slower
+        if ((rc = m->desc_dev.ensure(desc_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(m->desc_dev.p, slot.desc.p, desc_bytes, hipMemcpyHostToDevice, st));
+        d_scans = reinterpret_cast<const YmScanRef *>(m->desc_dev.p);
+        d_items = reinterpret_cast<const YmItem *>(m->desc_dev.p + scans_bytes);
+    }
     unsigned long long *stamps = m->stamps_on ? m->stamps.p : nullptr;
     hipEvent_t ev_call = nullptr, ev_k = nullptr;
     if ((rc = prof_begin(m, 2, &ev_call))) return rc;
@@ -513,7 +523,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.scans = d_scans; a.items = d_items; a.g = g; a.lat = lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
         a.cells = m->cells.p; a.bbox = m->bbox.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
         a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.stamps = stamps;
-        a.use_inline = (B == 1 && nscans <= YM_INLINE_SCANS) ? 1 : 0;
+        a.use_inline = inline_desc ? 1 : 0;
         a.pad0 = 0;
         std::memset(&a.inl, 0, sizeof a.inl);
         if (a.use_inline) { // descriptor travels in the kernel arguments: no host-memory reads on the device
@@ -538,9 +548,24 @@ int launch_call(ym_matcher *m, Slot &slot) {
     }
     // ---- K2 raster
     {
+        // the "tile is already zero" flags describe window MEMORY: they survive from call to call while the buffers and
+        // the tiling stay the same, otherwise they are cleared
+        const size_t ntiles = (size_t)B * tiles_x * tiles_y;
+        const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, grid_stride, (size_t)g.pitch, (size_t)g.win_w, ntiles};
+        const bool tz_grow = ntiles > m->tile_zero.cap;
+        if ((rc = m->tile_zero.ensure(ntiles))) return rc;
+        if (tz_grow || std::memcmp(sig, m->tz_sig, sizeof sig) != 0) {
+            // a smaller batch inside the same buffers keeps valid flags for the items it covers; anything else: reset
+            const bool shrink_only = !tz_grow && std::memcmp(sig, m->tz_sig, 5 * sizeof(size_t)) == 0 && ntiles <= m->tz_sig[5];
+            if (!shrink_only) {
+                HIP_TRY(hipMemsetAsync(m->tile_zero.p, 0, m->tile_zero.cap, st));
+                std::memcpy(m->tz_sig, sig, sizeof sig);
+            }
+        }
         ym::RasterArgs a;
         a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
         a.grid_stride = grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
+        a.tile_zero = m->tile_zero.p;
         if ((rc = prof_begin(m, 1, &ev_k))) return rc;
         hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
@@ -814,7 +839,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release();
+    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
     m->tmp_ranges_host.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();

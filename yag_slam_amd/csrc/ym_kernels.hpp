@@ -524,11 +524,13 @@ struct RasterArgs {
     uint8_t *planes;      // [B][2][win_w rows][pitch/2]: plane p holds columns 2*x+p of the window
     const uint8_t *lut;   // smear kernel value by squared cell distance: lut[dx*dx + dy*dy], 2*h*h + 1 entries
     int32_t max_n, max_base;
+    uint8_t *tile_zero;   // [B][tiles_y][tiles_x]: 1 = this tile of the window memory is known to hold zeros
     unsigned long long *stamps;
 };
 
 // grid (tiles_x, tiles_y, B), 256 threads.  Each block owns one 64x32 tile of the window and
-// writes every byte of it exactly once (so no separate clear pass exists).  Karto's SmearPoint
+// writes every byte of it exactly once (so no separate clear pass exists; a tile that is empty now and
+// whose memory is known to be zero from an earlier call is skipped).  Karto's SmearPoint
 // max-stamps a (2h+1)^2 kernel at every occupied cell; the kernel value depends only on the squared
 // cell distance and never grows with it (checked on the host when the matcher is created), so a
 // cell's final value is lut[min squared distance to an occupied cell inside the (2h+1)^2 window]:
@@ -547,59 +549,118 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     const int OW = TW + 2 * h, OH = TH + 2 * h;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     YM_STAMP(a, 4);
-    for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
-    for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
-    __syncthreads();
     // candidate chunks: 64 consecutive cells of one base scan whose bounding box touches tile + halo
     const int n_cchunks = (a.max_n + 63) / 64;
     const int n_boxes = a.max_base * n_cchunks;
     const int4 *bbox = a.bbox + (size_t)b * n_boxes;
+    const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
+    uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
+    const int y = tid / LPR, x8 = (tid % LPR) * 8; // thread -> 8 consecutive cells of one tile row
+    const bool row_ok = (ty0 + y) < a.g.win_w;
+    uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
+    const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
+    uint8_t *pl = a.planes + (size_t)b * a.grid_stride + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
+    uint8_t *tz = a.tile_zero + ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // Most tiles see no box at all: decide that before touching LDS.  Hits are compacted into a list so
+    // that the cell loads of several chunks are in flight together.
+    __shared__ int s_hits[256];
+    __shared__ int s_nhits;
+    if (tid == 0) s_nhits = 0;
+    __syncthreads();
+    for (int c = tid; c < n_boxes; c += NT) {
+        const int4 bb = bbox[c];
+        if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
+            const int at = atomicAdd(&s_nhits, 1);
+            if (at < 256) s_hits[at] = c;
+        }
+    }
+    __syncthreads();
+    const int nhits = s_nhits;
+    if (nhits == 0) {
+        // empty tile: zeros -- unless this memory is already known to be zero from an earlier call
+        if (*tz == 0) {
+            if (row_ok) {
+                *dst = make_uint2(0u, 0u);
+                *reinterpret_cast<uint32_t *>(pl) = 0u;
+                *reinterpret_cast<uint32_t *>(pl + plane_bytes) = 0u;
+            }
+            __syncthreads();
+            if (tid == 0) *tz = 1;
+        }
+        return;
+    }
+    for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
+    for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
+    __syncthreads();
     const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
-    const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
     int any = 0;
-    for (int c0 = 0; c0 < n_boxes; c0 += NT) {
-        const int c = c0 + tid;
-        bool hit = false;
-        if (c < n_boxes) {
-            const int4 bb = bbox[c];
-            hit = bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y;
-        }
-        // every wave walks the hits of its own 64 boxes; lanes then cover the chunk's 64 cells
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int bit = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int chunk = c0 + (tid & ~63) + bit;          // wave-uniform
-            const int slot = chunk / n_cchunks, ci = chunk - slot * n_cchunks;
-            const int i = ci * 64 + (tid & 63);
-            if (i < a.max_n) {
-                const int2 cc = cells[(size_t)slot * a.max_n + i];
-                const int lx = cc.x - lo_x, ly = cc.y - lo_y;
-                if (cc.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+    if (nhits <= 256) {
+        // work item = (hit chunk, cell of the chunk); 4 items per thread in flight
+        const int nwork = nhits * 64;
+        for (int w0 = 0; w0 < nwork; w0 += 4 * NT) {
+            int2 cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = w0 + u * NT + tid;
+                cc[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+                if (w < nwork) {
+                    const int chunk = s_hits[w >> 6];
+                    const int slot = chunk / n_cchunks, i = (chunk - slot * n_cchunks) * 64 + (w & 63);
+                    if (i < a.max_n) cc[u] = cells[(size_t)slot * a.max_n + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int lx = cc[u].x - lo_x, ly = cc[u].y - lo_y;
+                if (cc[u].x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
                     atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
                     any = 1;
+                }
+            }
+        }
+    } else {
+        // more hit chunks than the list holds: walk every box (rare)
+        for (int c0 = 0; c0 < n_boxes; c0 += NT) {
+            const int c = c0 + tid;
+            bool hit = false;
+            if (c < n_boxes) {
+                const int4 bb = bbox[c];
+                hit = bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y;
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int bit = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int chunk = c0 + (tid & ~63) + bit; // wave-uniform
+                const int slot = chunk / n_cchunks, ci = chunk - slot * n_cchunks;
+                const int i = ci * 64 + (tid & 63);
+                if (i < a.max_n) {
+                    const int2 c2 = cells[(size_t)slot * a.max_n + i];
+                    const int lx = c2.x - lo_x, ly = c2.y - lo_y;
+                    if (c2.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+                        atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
+                        any = 1;
+                    }
                 }
             }
         }
     }
     any = __syncthreads_or(any);
     YM_STAMP(a, 5);
-    uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
-    // thread -> 8 consecutive cells of one tile row
-    const int y = tid / LPR, x8 = (tid % LPR) * 8;
-    const bool row_ok = (ty0 + y) < a.g.win_w;
-    uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
-    const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
-    uint8_t *pl = a.planes + (size_t)b * a.grid_stride + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
     if (!any) {
-        if (row_ok) {
-            *dst = make_uint2(0u, 0u);
-            *reinterpret_cast<uint32_t *>(pl) = 0u;
-            *reinterpret_cast<uint32_t *>(pl + plane_bytes) = 0u;
+        if (*tz == 0) {
+            if (row_ok) {
+                *dst = make_uint2(0u, 0u);
+                *reinterpret_cast<uint32_t *>(pl) = 0u;
+                *reinterpret_cast<uint32_t *>(pl + plane_bytes) = 0u;
+            }
+            __syncthreads();
+            if (tid == 0) *tz = 1;
         }
         return;
     }
+    if (tid == 0) *tz = 0;
     // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
     const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
     for (int i = tid; i < OH * TW; i += NT) {
