@@ -793,17 +793,51 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
         uint32_t acc[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[j] = 0u;
-        for (int c = 0; c < a.chunk; c += U) {
-            uint4 w[U];
+        if (SX == 2) {
+            // Plane loads are made dword-aligned (a byte-unaligned 16-byte load costs the vector L1 ~1.4x the
+            // lookups, profiles/r01_c): the lane loads the aligned 16 bytes below its first hypothesis, takes the
+            // 17th..19th byte from its right-hand neighbour lane (same row, next 16 hypotheses: DPP wave shift) and
+            // funnels by the beam's byte misalignment, which is wave-uniform (v_alignbyte_b32).
+            const int lane = threadIdx.x & 63;
+            // lanes whose neighbour is not the next group of the same row load the extra dword themselves
+            const bool extra = (lane == 63 && xg != a.ngx - 1) || (a.nx_pad - a.lat.nx < 3 && xg == a.ngx - 1);
+            for (int c = 0; c < a.chunk; c += U) {
+                uint4 w[U];
+                uint32_t e[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], src + (uint32_t)(lane_off + (uint32_t)offs[c + u]), 16);
+                for (int u = 0; u < U; u++) {
+                    const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u);
+                    w[u] = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(src + ad, 4));
+                    e[u] = 0u;
+                    if (extra) e[u] = *reinterpret_cast<const uint32_t *>(src + ad + 16);
+                }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t m = (i0 + c + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
-                acc[0] += w[u].x & m; acc[1] += (w[u].x >> 8) & m;
-                acc[2] += w[u].y & m; acc[3] += (w[u].y >> 8) & m;
-                acc[4] += w[u].z & m; acc[5] += (w[u].z >> 8) & m;
-                acc[6] += w[u].w & m; acc[7] += (w[u].w >> 8) & m;
+                for (int u = 0; u < U; u++) {
+                    const uint32_t m = (i0 + c + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
+                    const uint32_t rr = (uint32_t)offs[c + u] & 3u;
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[u].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+                    const uint32_t w4 = extra ? e[u] : nb;
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w[u].y, w[u].x, rr), x1 = __builtin_amdgcn_alignbyte(w[u].z, w[u].y, rr);
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(w[u].w, w[u].z, rr), x3 = __builtin_amdgcn_alignbyte(w4, w[u].w, rr);
+                    acc[0] += x0 & m; acc[1] += (x0 >> 8) & m;
+                    acc[2] += x1 & m; acc[3] += (x1 >> 8) & m;
+                    acc[4] += x2 & m; acc[5] += (x2 >> 8) & m;
+                    acc[6] += x3 & m; acc[7] += (x3 >> 8) & m;
+                }
+            }
+        } else {
+            for (int c = 0; c < a.chunk; c += U) {
+                uint4 w[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) __builtin_memcpy(&w[u], src + (uint32_t)(lane_off + (uint32_t)offs[c + u]), 16);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t m = (i0 + c + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
+                    acc[0] += w[u].x & m; acc[1] += (w[u].x >> 8) & m;
+                    acc[2] += w[u].y & m; acc[3] += (w[u].y >> 8) & m;
+                    acc[4] += w[u].z & m; acc[5] += (w[u].z >> 8) & m;
+                    acc[6] += w[u].w & m; acc[7] += (w[u].w >> 8) & m;
+                }
             }
         }
         uint32_t r[G];
