@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=64, help="independent cfg2 matches per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
     args = ap.parse_args()

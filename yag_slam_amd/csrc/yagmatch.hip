@@ -97,6 +97,7 @@ struct CallScan {
     double min_angle, angle_inc, min_range, range_threshold;
     double pose[3];
     double max_valid; // largest reading that survives range gating (bounds the query's reach)
+    double lbox[4];   // sensor-frame bounding box of the points (bounds where a base scan can stamp)
 };
 
 struct CallItem {
@@ -140,6 +141,7 @@ struct ym_scan {
     double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
     double pose[3];
     double max_valid_karto, max_valid_yagpy;
+    double lbox[4]; // sensor-frame bounding box (xmin, ymin, xmax, ymax) of every reading that can become a point
 };
 
 struct ym_batch {
@@ -166,6 +168,7 @@ struct ym_matcher {
     DevBuf<uint8_t> planes;    // even/odd column planes of every window
     DevBuf<uint8_t> tile_zero; // per raster tile: window memory known to be zero (skips rewriting empty tiles)
     size_t tz_sig[6] = {0, 0, 0, 0, 0, 0}; // memory/geometry the flags are valid for
+    int dirty_rect[4] = {0, 0, -1, -1};     // tile rectangle (x0, y0, x1, y1) outside which every window is known to be zero
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
@@ -178,6 +181,7 @@ struct ym_matcher {
     DevBuf<double2> yrot;      // yagpy: points rotated per angle
     DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
     bool stamps_on = false;
+    int full_raster = 0; // development: launch every raster tile
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
@@ -560,14 +564,59 @@ int launch_call(ym_matcher *m, Slot &slot) {
             if (!shrink_only) {
                 HIP_TRY(hipMemsetAsync(m->tile_zero.p, 0, m->tile_zero.cap, st));
                 std::memcpy(m->tz_sig, sig, sizeof sig);
+                m->dirty_rect[0] = m->dirty_rect[1] = 0; // unknown memory: next launch covers every tile
+                m->dirty_rect[2] = tiles_x - 1; m->dirty_rect[3] = tiles_y - 1;
             }
         }
+        // Tiles a base point can stamp: rotate every base scan's sensor-frame box into the world, take the union over
+        // the call, convert to window tiles (+ smear halo, + 1 tile of hysteresis).  Only that sub-grid is launched;
+        // it always contains the rectangle that may still hold old non-zero bytes (dirty_rect), otherwise the whole
+        // tiling is launched once.
+        int want[4] = {tiles_x, tiles_y, -1, -1};
+        for (const CallItem &it : call.items) {
+            const CallScan &q = call.scans[it.query];
+            const double offx = q.pose[0] - (0.5 * (g.roi_w - 1) * g.res), offy = q.pose[1] - (0.5 * (g.roi_w - 1) * g.res);
+            for (int j = 0; j < it.base_count; j++) {
+                const CallScan &bs = call.scans[it.base_begin + j];
+                if (bs.lbox[0] > bs.lbox[2]) continue; // no usable reading
+                const double c = std::cos(bs.pose[2]), sn = std::sin(bs.pose[2]);
+                double wx0 = 1e300, wy0 = 1e300, wx1 = -1e300, wy1 = -1e300;
+                for (int k = 0; k < 4; k++) {
+                    const double lx = bs.lbox[(k & 1) ? 2 : 0], ly = bs.lbox[(k & 2) ? 3 : 1];
+                    const double x = bs.pose[0] + c * lx - sn * ly, y = bs.pose[1] + sn * lx + c * ly;
+                    wx0 = std::min(wx0, x); wx1 = std::max(wx1, x); wy0 = std::min(wy0, y); wy1 = std::max(wy1, y);
+                }
+                const double pad = g.half_kernel + 3; // smear reach + rounding slack, in cells
+                const double cx0 = (wx0 - offx) / g.res + g.border - g.win_origin - pad, cx1 = (wx1 - offx) / g.res + g.border - g.win_origin + pad;
+                const double cy0 = (wy0 - offy) / g.res + g.border - g.win_origin - pad, cy1 = (wy1 - offy) / g.res + g.border - g.win_origin + pad;
+                want[0] = std::min(want[0], (int)std::floor(cx0 / YM_TILE_W) - 1); want[2] = std::max(want[2], (int)std::floor(cx1 / YM_TILE_W) + 1);
+                want[1] = std::min(want[1], (int)std::floor(cy0 / YM_TILE_H) - 1); want[3] = std::max(want[3], (int)std::floor(cy1 / YM_TILE_H) + 1);
+            }
+        }
+        want[0] = std::max(want[0], 0); want[1] = std::max(want[1], 0);
+        want[2] = std::min(want[2], tiles_x - 1); want[3] = std::min(want[3], tiles_y - 1);
+        int launch[4];
+        const bool dirty_empty = m->dirty_rect[2] < m->dirty_rect[0] || m->dirty_rect[3] < m->dirty_rect[1];
+        if (want[2] < want[0] || want[3] < want[1]) { // nothing can be stamped: only clean what may be dirty
+            for (int k = 0; k < 4; k++) launch[k] = m->dirty_rect[k];
+        } else if (dirty_empty) {
+            for (int k = 0; k < 4; k++) launch[k] = want[k];
+        } else { // union: covers both the new stamps and the old leftovers
+            launch[0] = std::min(want[0], m->dirty_rect[0]); launch[1] = std::min(want[1], m->dirty_rect[1]);
+            launch[2] = std::max(want[2], m->dirty_rect[2]); launch[3] = std::max(want[3], m->dirty_rect[3]);
+        }
+        // after this launch only `want` can hold non-zero bytes
+        for (int k = 0; k < 4; k++) m->dirty_rect[k] = want[k];
+        if (m->full_raster) { launch[0] = launch[1] = 0; launch[2] = tiles_x - 1; launch[3] = tiles_y - 1; }
+        const int ltx = launch[2] - launch[0] + 1, lty = launch[3] - launch[1] + 1;
         ym::RasterArgs a;
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tile_x0 = launch[0]; a.tile_y0 = launch[1];
         a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
         a.grid_stride = grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
         a.tile_zero = m->tile_zero.p;
         if ((rc = prof_begin(m, 1, &ev_k))) return rc;
-        hipLaunchKernelGGL(ym::raster_kernel, dim3(tiles_x, tiles_y, B), dim3(YM_RASTER_THREADS), 0, st, a);
+        if (ltx > 0 && lty > 0)
+            hipLaunchKernelGGL(ym::raster_kernel, dim3(ltx, lty, B), dim3(YM_RASTER_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
     }
     if (yag) {
@@ -747,7 +796,21 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->range_threshold = s->range_threshold;
     o->pose[0] = s->pose[0]; o->pose[1] = s->pose[1]; o->pose[2] = s->pose[2];
     o->max_valid = semantics == YM_SEM_YAGPY ? s->max_valid_yagpy : s->max_valid_karto;
+    for (int i = 0; i < 4; i++) o->lbox[i] = s->lbox[i];
     return YM_OK;
+}
+
+// sensor-frame bounding box of all readings either semantics can turn into a point (r <= rt, not NaN)
+void local_bbox(const double *r, int n, double min_angle, double inc, double rt, double box[4]) {
+    box[0] = box[1] = 1e300;
+    box[2] = box[3] = -1e300;
+    for (int i = 0; i < n; i++) {
+        const double v = r[i];
+        if (v > rt || std::isnan(v)) continue;
+        const double a = min_angle + i * inc, x = v * std::cos(a), y = v * std::sin(a);
+        box[0] = std::min(box[0], x); box[1] = std::min(box[1], y);
+        box[2] = std::max(box[2], x); box[3] = std::max(box[3], y);
+    }
 }
 
 void max_valid_ranges(const double *r, int n, double min_range, double rt, double *karto, double *yagpy) {
@@ -889,6 +952,7 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     s->pose[0] = d->pose[0]; s->pose[1] = d->pose[1]; s->pose[2] = d->pose[2];
     s->d_ranges = nullptr;
     max_valid_ranges(d->ranges, d->n, d->min_range, d->range_threshold, &s->max_valid_karto, &s->max_valid_yagpy);
+    local_bbox(d->ranges, d->n, d->min_angle, d->angle_increment, d->range_threshold, s->lbox);
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&s->d_ranges), sizeof(double) * std::max(1, d->n)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot allocate device ranges");
@@ -971,6 +1035,7 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
         double k, y;
         max_valid_ranges(d.ranges, d.n, d.min_range, d.range_threshold, &k, &y);
         c.max_valid = m->cfg.semantics == YM_SEM_YAGPY ? y : k;
+        local_bbox(d.ranges, d.n, d.min_angle, d.angle_increment, d.range_threshold, c.lbox);
         at += (size_t)d.n;
     }
     if (total > 0)
@@ -1163,6 +1228,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
 int ym_debug_option(ym_matcher *m, int option, int value) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
     if (option == 0) m->use_lds_correlate = value;
+    else if (option == 2) m->full_raster = value;
     else return set_err(YM_ERR_INVALID, "unknown option %d", option);
     return YM_OK;
 }

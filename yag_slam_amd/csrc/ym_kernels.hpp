@@ -163,7 +163,7 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 }
 
 // ================================================================== K1 prepare
-#define YM_PREP_THREADS 1024
+#define YM_PREP_THREADS 512
 #define YM_PREP_LDS_BYTES(max_n) ((size_t)(max_n) * 25 + ((size_t)(max_n) / 64 + 2) * 4 + 16)
 #define YM_INLINE_SCANS 16
 struct YmInlineDesc {        // call descriptor passed in the kernel arguments (single item, few scans)
@@ -189,7 +189,7 @@ struct PrepareArgs {
     unsigned long long *stamps;
 };
 
-// grid (max_base + 1, B), 1024 threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n)
+// grid (max_base + 1, B), YM_PREP_THREADS threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n)
 // blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.
 __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -525,10 +525,12 @@ struct RasterArgs {
     const uint8_t *lut;   // smear kernel value by squared cell distance: lut[dx*dx + dy*dy], 2*h*h + 1 entries
     int32_t max_n, max_base;
     uint8_t *tile_zero;   // [B][tiles_y][tiles_x]: 1 = this tile of the window memory is known to hold zeros
+    int32_t tiles_x, tiles_y; // full tiling of the window
+    int32_t tile_x0, tile_y0; // first tile of the launched sub-grid (tiles outside it are known to be zero)
     unsigned long long *stamps;
 };
 
-// grid (tiles_x, tiles_y, B), 256 threads.  Each block owns one 64x32 tile of the window and
+// grid (launched tiles in x, in y, B), 256 threads.  Each block owns one 64x32 tile of the window and
 // writes every byte of it exactly once (so no separate clear pass exists; a tile that is empty now and
 // whose memory is known to be zero from an earlier call is skipped).  Karto's SmearPoint
 // max-stamps a (2h+1)^2 kernel at every occupied cell; the kernel value depends only on the squared
@@ -547,7 +549,10 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     const int b = blockIdx.z;
     const int h = a.g.half_kernel;
     const int OW = TW + 2 * h, OH = TH + 2 * h;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    // Blocks go round-robin over the 8 XCDs by linear id; rotating the tile column by the row keeps a
+    // launch width that is a multiple of 8 from pinning every tile column (i.e. every wall) to one XCD.
+    const int tix = a.tile_x0 + (int)((blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z) % gridDim.x), tiy = a.tile_y0 + (int)blockIdx.y;
+    const int tx0 = tix * TW, ty0 = tiy * TH;
     YM_STAMP(a, 4);
     // candidate chunks: 64 consecutive cells of one base scan whose bounding box touches tile + halo
     const int n_cchunks = (a.max_n + 63) / 64;
@@ -560,23 +565,18 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
     const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
     uint8_t *pl = a.planes + (size_t)b * a.grid_stride + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
-    uint8_t *tz = a.tile_zero + ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    uint8_t *tz = a.tile_zero + ((size_t)b * a.tiles_y + tiy) * a.tiles_x + tix;
     // Most tiles see no box at all: decide that before touching LDS.  Hits are compacted into a list so
     // that the cell loads of several chunks are in flight together.
     __shared__ int s_hits[256];
     __shared__ int s_nhits;
-    if (tid == 0) s_nhits = 0;
-    __syncthreads();
+    int my_hits = 0;
     for (int c = tid; c < n_boxes; c += NT) {
         const int4 bb = bbox[c];
-        if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
-            const int at = atomicAdd(&s_nhits, 1);
-            if (at < 256) s_hits[at] = c;
-        }
+        my_hits += (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) ? 1 : 0;
     }
-    __syncthreads();
-    const int nhits = s_nhits;
-    if (nhits == 0) {
+    if (tid == 0) s_nhits = 0;
+    if (__syncthreads_or(my_hits) == 0) {
         // empty tile: zeros -- unless this memory is already known to be zero from an earlier call
         if (*tz == 0) {
             if (row_ok) {
@@ -589,9 +589,17 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
         }
         return;
     }
+    for (int c = tid; c < n_boxes; c += NT) { // second look at the (L1-resident) boxes: compact the hits
+        const int4 bb = bbox[c];
+        if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
+            const int at = atomicAdd(&s_nhits, 1);
+            if (at < 256) s_hits[at] = c;
+        }
+    }
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
     for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
     __syncthreads();
+    const int nhits = s_nhits;
     const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
@@ -662,24 +670,33 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     }
     if (tid == 0) *tz = 0;
     // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
+    // Walls are thin: most windows hold no bit at all, so the empty case leaves early.
     const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
     for (int i = tid; i < OH * TW; i += NT) {
         const int ry = i / TW, rx = i % TW;
         const int w = rx >> 6, sft = rx & 63;
         const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
-        const unsigned long long win = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & wmask;
-        const unsigned long long right = win >> h, left = win & lmask;
-        const int dr = right ? (__ffsll((long long)right) - 1) : 255;
-        const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
-        grow[i] = (unsigned char)(dr < dl ? dr : dl);
+        unsigned char g = 255;
+        if (lo | hi) {
+            const unsigned long long win = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & wmask;
+            if (win) {
+                const unsigned long long right = win >> h, left = win & lmask;
+                const int dr = right ? (__ffsll((long long)right) - 1) : 255;
+                const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
+                g = (unsigned char)(dr < dl ? dr : dl);
+            }
+        }
+        grow[i] = g;
     }
     __syncthreads();
     YM_STAMP(a, 6);
+    // column pass: 8 cells per lane; a row whose 8 distances are all "none" contributes nothing
     unsigned mn[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) mn[q] = 0x7fffffffu;
     for (int dy = -h; dy <= h; dy++) {
         const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + h + dy) * TW + x8]);
+        if ((gg.x & gg.y) == 0xffffffffu) continue;
         const unsigned d2 = (unsigned)(dy * dy);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
