@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
     ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
     args = ap.parse_args()
 
@@ -115,9 +116,11 @@ def main():
     m.set_stream(stream.cuda_stream)
     if args.correlate_variant >= 0:
         m.debug_option(0, args.correlate_variant)
+    if args.corr_u > 0:
+        m.debug_option(3, args.corr_u)
     query, chains = build_inputs(args.batch, rank)
     batch = m.make_batch(query, chains)
-    nslots = 32
+    nslots = 8  # result slots cycled by the pipelined loop (all touched during warm-up)
     records = torch.zeros((nslots, ymdist.RECORD), dtype=torch.float64, device="cuda")
     gathered = torch.zeros(world * ymdist.RECORD, dtype=torch.float64, device="cuda")
 

@@ -181,6 +181,7 @@ struct ym_matcher {
     DevBuf<double2> yrot;      // yagpy: points rotated per angle
     DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
     bool stamps_on = false;
+    int corr_u = 0;      // development: force the number of beams in flight per lane (16, 32, 48)
     int full_raster = 0; // development: launch every raster tile
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
@@ -453,7 +454,11 @@ int launch_call(ym_matcher *m, Slot &slot) {
     n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
     n_chunks = std::max(n_chunks, (max_n + 511) / 512);
     int chunk = (max_n + n_chunks - 1) / n_chunks;
-    chunk = (chunk + 15) / 16 * 16;
+    // beams in flight per lane: small lattices have few waves per CU and need deep memory-level parallelism,
+    // big ones (many waves) do better with fewer registers (measured: cfg2 batch 890 -> 759 us with 32; stress
+    // 128 -> 158 us)
+    const int corr_u = m->corr_u > 0 ? m->corr_u : (njobs <= 128 ? 32 : 16);
+    chunk = (chunk + corr_u - 1) / corr_u * corr_u;
     n_chunks = (max_n + chunk - 1) / chunk;
 
     const int nt_stride = lc.nt;
@@ -656,8 +661,10 @@ int launch_call(ym_matcher *m, Slot &slot) {
         const dim3 grid_dim(job_blocks, ktiles * n_chunks, B);
         if (sx == 2 && m->use_lds_correlate == 1 && njobs <= 128)
             hipLaunchKernelGGL(ym::correlate_lds_kernel, dim3((njobs + 63) / 64, lc.nt * n_chunks, B), dim3(256), 0, st, a);
-        else if (sx == 2) hipLaunchKernelGGL(ym::correlate_kernel<2>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
-        else hipLaunchKernelGGL(ym::correlate_kernel<1>, grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        else if (sx == 2 && corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        else if (sx == 2 && corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        else if (sx == 2) hipLaunchKernelGGL((ym::correlate_kernel<2, 48>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((ym::correlate_kernel<1, 16>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
     }
     // ---- K5a score
@@ -1229,6 +1236,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
     if (option == 0) m->use_lds_correlate = value;
     else if (option == 2) m->full_raster = value;
+    else if (option == 3) m->corr_u = value;
     else return set_err(YM_ERR_INVALID, "unknown option %d", option);
     return YM_OK;
 }

@@ -756,10 +756,9 @@ struct CorrArgs {
 // sensor-frame point, WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are
 // issued 16 beams at a time; entries past the last beam are 0 and are masked by a scalar.
 // grid (ceil(ny*ngx / 256), nt * n_chunks, B).
-template <int SX>
+template <int SX, int U /* beams in flight per lane */>
 __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
     constexpr int G = 16;           // hypotheses per lane
-    constexpr int U = 16;           // beams in flight per lane
     const int b = blockIdx.z;
     // a block covers jobs_pb lane jobs of each of tpb adjacent angles for one beam chunk: waves of
     // one block read overlapping grid patches (adjacent angles shift the patch by a few cells)
