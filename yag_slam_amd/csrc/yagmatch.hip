@@ -689,7 +689,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = grid_stride;
         a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
         a.fsums_stride = sums_f; a.stamps = stamps;
-        hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
+        hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
         hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
     } // karto

@@ -1318,7 +1318,56 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
     return best;
 }
 
-// ---- K6a fine: grid (max(nt_f,1), B), 256 threads.  Block k scores the 3x3 fine lattice for fine angle k.
+// ScanMatcher::ComputePositionalCovariance over the per-(x,y) maxima of the coarse pass; cov valid in every thread
+template <int NT>
+__device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b, const YmItemState &st, const double mean[3],
+                                                      double best, double cov[9], double *scratch) {
+    const int tid = threadIdx.x;
+    for (int i = 0; i < 9; i++) cov[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    const YmLattice &L = a.lc;
+    const int nx = L.nx, nxy = nx * L.ny;
+    const double cxw = st.pose[0], cyw = st.pose[1];
+    const double start_x = -L.off_x, start_y = -L.off_y;
+    double sums[4] = {0, 0, 0, 0};
+    const double dx = mean[0] - cxw, dy = mean[1] - cyw;
+    if (!(best < YM_KT_TOLERANCE)) {
+        const double *probs = a.probs + (size_t)b * a.probs_stride;
+        for (int c = tid; c < nxy; c += NT) {
+            const int iy = c / nx, ix = c - iy * nx;
+            const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+            const double response = probs[c];
+            if (response >= (best - 0.1)) {
+                sums[0] += response;
+                sums[1] += ((x - dx) * (x - dx)) * response;
+                sums[2] += ((x - dx) * (y - dy) * response);
+                sums[3] += ((y - dy) * (y - dy)) * response;
+            }
+        }
+    }
+    block_sum_vec<4>(sums, scratch);
+    if (best < YM_KT_TOLERANCE) {
+        cov[0] = YM_MAX_VARIANCE; cov[4] = YM_MAX_VARIANCE;
+        cov[8] = 4 * (L.angle_res * L.angle_res);
+    } else {
+        const double norm = sums[0];
+        if (norm > YM_KT_TOLERANCE) {
+            double vxx = sums[1] / norm, vxy = sums[2] / norm, vyy = sums[3] / norm;
+            const double vthth = 4 * (L.angle_res * L.angle_res);
+            const double min_xx = 0.1 * (L.step_x * L.step_x);
+            const double min_yy = 0.1 * (L.step_y * L.step_y);
+            vxx = vxx > min_xx ? vxx : min_xx;
+            vyy = vyy > min_yy ? vyy : min_yy;
+            const double mult = 1.0 / best;
+            cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
+            cov[8] = vthth;
+        }
+        if (kt_double_equal(cov[0], 0.0)) cov[0] = YM_MAX_VARIANCE;
+        if (kt_double_equal(cov[4], 0.0)) cov[4] = YM_MAX_VARIANCE;
+    }
+}
+
+// ---- K6a fine: grid (nt_f + 1, B) (or (1, B) without refinement).  Block k < nt_f scores the 3x3 fine lattice for
+// fine angle k; the extra block computes the coarse pass's positional covariance at the same time.
 #define YM_FINE_THREADS 512
 __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     constexpr int NT = YM_FINE_THREADS;
@@ -1340,13 +1389,18 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride,
                                                  a.blockmax + (size_t)b * a.n_blocks, a.n_blocks, pose, mean, &status,
                                                  scratch, s_list, &s_nlist);
-    if (k == 0 && tid == 0) { // hand the coarse result to final_kernel
-        st.center[0] = mean[0]; st.center[1] = mean[1]; st.center[2] = mean[2];
-        st.coarse_response = best; // unclamped
-        st.status = status;
+    if (k == (a.refine ? a.lf.nt : 0)) { // extra block: coarse result + positional covariance for final_kernel
+        double cov[9];
+        positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
+        if (tid == 0) {
+            st.center[0] = mean[0]; st.center[1] = mean[1]; st.center[2] = mean[2];
+            st.coarse_response = best; // unclamped
+            st.status = status;
+            for (int i = 0; i < 9; i++) st.cov[i] = cov[i];
+        }
+        return;
     }
     YM_STAMP(a, 13);
-    if (!a.refine) return;
 
     const YmLattice &L = a.lf;
     const int nx = L.nx, ny = L.ny, nxy = nx * ny;
@@ -1451,49 +1505,8 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
     double best = st.coarse_response;                             // coarse best, unclamped
     int status = st.status;
 
-    // ------------------------------------------------------------- ComputePositionalCovariance
-    {
-        const YmLattice &L = a.lc;
-        const int nx = L.nx, nxy = nx * L.ny;
-        const double cxw = st.pose[0], cyw = st.pose[1];
-        const double start_x = -L.off_x, start_y = -L.off_y;
-        double sums[4] = {0, 0, 0, 0};
-        const double dx = mean[0] - cxw, dy = mean[1] - cyw;
-        if (!(best < YM_KT_TOLERANCE)) {
-            const double *probs = a.probs + (size_t)b * a.probs_stride;
-            for (int c = tid; c < nxy; c += NT) {
-                const int iy = c / nx, ix = c - iy * nx;
-                const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-                const double response = probs[c];
-                if (response >= (best - 0.1)) {
-                    sums[0] += response;
-                    sums[1] += ((x - dx) * (x - dx)) * response;
-                    sums[2] += ((x - dx) * (y - dy) * response);
-                    sums[3] += ((y - dy) * (y - dy)) * response;
-                }
-            }
-        }
-        block_sum_vec<4>(sums, scratch);
-        if (best < YM_KT_TOLERANCE) {
-            cov[0] = YM_MAX_VARIANCE; cov[4] = YM_MAX_VARIANCE;
-            cov[8] = 4 * (L.angle_res * L.angle_res);
-        } else {
-            const double norm = sums[0];
-            if (norm > YM_KT_TOLERANCE) {
-                double vxx = sums[1] / norm, vxy = sums[2] / norm, vyy = sums[3] / norm;
-                const double vthth = 4 * (L.angle_res * L.angle_res);
-                const double min_xx = 0.1 * (L.step_x * L.step_x);
-                const double min_yy = 0.1 * (L.step_y * L.step_y);
-                vxx = vxx > min_xx ? vxx : min_xx;
-                vyy = vyy > min_yy ? vyy : min_yy;
-                const double mult = 1.0 / best;
-                cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
-                cov[8] = vthth;
-            }
-            if (kt_double_equal(cov[0], 0.0)) cov[0] = YM_MAX_VARIANCE;
-            if (kt_double_equal(cov[4], 0.0)) cov[4] = YM_MAX_VARIANCE;
-        }
-    }
+    // positional covariance of the coarse pass: computed by fine_kernel's extra block
+    for (int i = 0; i < 9; i++) cov[i] = st.cov[i];
     const double coarse_response = best > 1.0 ? 1.0 : best;
     double response = coarse_response;
 
