@@ -205,7 +205,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ym::correlate_kernel<2>",
+                "kernel": "ym::correlate_kernel<2, 32>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
