@@ -275,3 +275,69 @@ def test_lds_staged_correlate_is_bit_exact(variant):
     for ch, p in zip([nb[:5], nb[3:], nb], per):
         s = m2.match_scan(nq, ch, True, True)
         assert s.response == p.response and s.covariance == p.covariance
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at full size
+def test_determinism_and_translation_invariance():
+    """Same inputs -> bitwise the same outputs on every run; moving every pose by a whole number of grid cells
+    moves the answer by exactly that much and leaves responses/covariances unchanged (the grid is anchored at
+    the query pose, so the rasterised window and every integer sum are identical)."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    m = ScanMatcher()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    r1 = m.match_scan(nq, nb, True, True)
+    s1 = m.debug_sums(0, dims=r1.meta["coarse_dims"])
+    for _ in range(5):
+        r = m.match_scan(nq, nb, True, True)
+        assert r.response == r1.response and r.covariance == r1.covariance
+        assert (r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1]) == (r1.best_pose.x, r1.best_pose.y, r1.best_pose.euler[-1])
+    # shift by (+64, -32) cells of 0.01 m = binary-exact offsets keep every fp64 difference identical
+    dx, dy = 0.5, -0.25
+    mk = lambda s: PlainScan(s.ranges, s.min_angle, s.angle_increment, s.min_range, s.range_threshold,
+                             (s.corrected_pose.x + dx, s.corrected_pose.y + dy, s.corrected_pose.euler[-1]))
+    r2 = m.match_scan(mk(q), [mk(b) for b in base], True, True)
+    s2 = m.debug_sums(0, dims=r2.meta["coarse_dims"])
+    assert np.array_equal(s1, s2)
+    assert abs(r2.response - r1.response) <= 1e-15
+    assert abs(r2.best_pose.x - r1.best_pose.x - dx) <= 1e-12 and abs(r2.best_pose.y - r1.best_pose.y - dy) <= 1e-12
+    np.testing.assert_allclose(np.array(r2.covariance), np.array(r1.covariance), rtol=1e-9, atol=1e-18)
+
+
+def test_maximum_scan_size_and_limits():
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd._capi import YmError
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    n = 6000  # YM_MAX_BEAMS
+    inc = 2 * np.pi / n
+    mk = lambda p, idx, nb: PlainScan(scene.scan_ranges(p, index=idx, n_beams=nb, min_angle=-np.pi, inc=inc), -np.pi, inc, 0.05, 20.0, p)
+    cfg = dict(search_size=0.32, resolution=0.02, smear_deviation=0.04, range_threshold=12.0)
+    base = [mk((3.0 + 0.1 * i, 3.0, 0.1 * i), 400 + i, n) for i in range(3)]
+    q = mk((3.12, 3.05, 0.12), 410, n)
+    q.corrected_pose.x, q.corrected_pose.y = 3.1, 3.0
+    compare(cfg, q, base, True, True)
+    with pytest.raises(YmError, match="limit"):
+        ScanMatcher(cfg).match_scan(PlainScan(np.full(6001, 2.0), -np.pi, inc, 0.05, 20.0, (3, 3, 0)), base[:1], True, True)
+
+
+def test_against_karto_wheel_if_present():
+    """Optional: wherever the reference's native dependency is installed, compare against it directly
+    (north_star tolerances: response 1e-4, pose 1e-3 m / 1e-3 rad)."""
+    ks = pytest.importorskip("karto_scanmatcher")
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    cfg = ks.ScanMatcherConfig()
+    from yag_slam_amd.config import default_config
+    for k, v in default_config.items():
+        setattr(cfg, k, v)
+    w = ks.Wrapper(cfg)
+    mk = lambda s: ks.LocalizedRangeScan(ks.LaserScanConfig(s.min_angle, s.max_angle, s.angle_increment, s.min_range, s.max_range, s.range_threshold, ""),
+                                         list(s.ranges), ks.Pose2(s.corrected_pose.x, s.corrected_pose.y, s.corrected_pose.euler[-1]),
+                                         ks.Pose2(s.corrected_pose.x, s.corrected_pose.y, s.corrected_pose.euler[-1]), 0, 0.0)
+    ref = w.match_scan(mk(q), [mk(b) for b in base], True, True)
+    r = ScanMatcher().match_scan(q, base, True, True)
+    assert abs(r.response - ref.response) <= 1e-4
+    assert abs(r.best_pose.x - ref.best_pose.x) <= 1e-3 and abs(r.best_pose.y - ref.best_pose.y) <= 1e-3
+    assert abs(r.best_pose.euler[-1] - ref.best_pose.yaw) <= 1e-3
