@@ -26,3 +26,7 @@ for w, name in enumerate(["correlate", "raster", "call"]):
     print("  %s: %.1f us avg over %d" % (name, ms / max(n, 1) * 1e3, n))
 nqp = r.meta["n_query_points"]; cd = r.meta["coarse_dims"]
 ms, n = 0, 0
+m.debug_stamps(True)
+m.match_scan(nq, nb, True, True)
+st = m.debug_stamps(False)
+print("select stamps (us):", [round((v - st[24]) / 100.0, 2) for v in st[24:30]])

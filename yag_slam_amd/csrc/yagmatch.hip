@@ -546,14 +546,15 @@ int launch_call(ym_matcher *m, Slot &slot) {
     if (g.zone_count > 1) {
         const size_t pts = (size_t)max_base * max_n;
         int log2cap = 10;
-        while (((size_t)1 << log2cap) < 2 * pts) log2cap++;
-        if (log2cap > 15 || g.storage_w >= 32768)
-            return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 16384 readings are not supported",
+        while (((size_t)3 << log2cap) < 4 * pts) log2cap++; // load factor <= 0.75
+        if (log2cap > 14 || g.storage_w >= 32768)
+            return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 12288 readings are not supported",
                            m->cfg.smear_deviation / m->cfg.resolution);
         ym::SelectArgs a;
-        a.cells = m->cells.p; a.max_n = max_n; a.max_base = max_base; a.z2max = m->z2max; a.log2cap = log2cap;
-        if (m->z2max <= 1) hipLaunchKernelGGL(ym::select_kernel<5>, dim3(B), dim3(64), sizeof(unsigned) << log2cap, st, a);
-        else hipLaunchKernelGGL(ym::select_kernel<9>, dim3(B), dim3(64), sizeof(unsigned) << log2cap, st, a);
+        a.cells = m->cells.p; a.max_n = max_n; a.max_base = max_base; a.z2max = m->z2max; a.log2cap = log2cap; a.stamps = stamps;
+        const size_t lds = (size_t)9 << log2cap;
+        if (m->z2max <= 1) hipLaunchKernelGGL(ym::select_kernel<5>, dim3(B), dim3(1024), lds, st, a);
+        else hipLaunchKernelGGL(ym::select_kernel<9>, dim3(B), dim3(1024), lds, st, a);
     }
     // ---- K2 raster
     {
@@ -892,8 +893,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     }
     m->stream = m->own_stream;
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot raise the dynamic LDS limit of prepare_kernel");

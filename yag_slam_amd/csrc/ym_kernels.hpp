@@ -393,121 +393,158 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
 // smear_deviation >= 9.99 * resolution the four neighbours of an occupied cell are stamped 100 as
 // well, so whether a point is rasterised depends on the points before it: a point is EFFECTIVE iff
 // no earlier effective point lies within squared cell distance z2max (the radius of the kernel's
-// 100-valued disc).  This kernel replays that greedy rule in Karto's order (base scans in order,
-// beams in order) and erases the non-effective points from `cells`; the raster kernel then stamps
-// exactly the effective set.  One wave per item: 64 points per step are checked in parallel against
-// an LDS hash set of earlier effective cells, conflicts inside the step are resolved lane by lane.
+// 100-valued disc), in Karto's order (base scans in order, beams in order).
+//
+// Parallel form of that greedy rule.  Only the earliest point of a cell can be effective (a later
+// one is knocked out by it, or by whatever knocked it out).  So: (1) hash every cell to its earliest
+// point index (LDS, atomicMin); (2) relax the undecided cells: a cell whose earlier neighbours are
+// all decided "no" becomes effective, a cell with an effective earlier neighbour is out -- decisions
+// are final, so reading a neighbour's fresh or stale state is equally safe, and the globally
+// earliest undecided cell always resolves, so the loop ends; (3) erase every point
+// that is not the earliest of an effective cell from `cells`.  One block per item.
 struct SelectArgs {
     int2 *cells;          // [B][max_base][max_n]
     int32_t max_n, max_base;
     int32_t z2max;        // largest squared distance whose kernel value is 100
-    int32_t log2cap;      // hash capacity = 1 << log2cap entries (dynamic LDS)
+    int32_t log2cap;      // hash capacity = 1 << log2cap entries (dynamic LDS: 9 bytes per entry)
+    unsigned long long *stamps;
 };
 
 __device__ __forceinline__ unsigned select_key(int x, int y) {
     return ((unsigned)(y + 32768) << 16) | ((unsigned)(x + 32768) & 0xffffu);
 }
-
-// Probe an open-addressing table (empty = 0) for the NB cells of a disc around (x, y), all first
-// probes in flight together.  Returns a bit per neighbour that was found; slot_out receives the slot.
-template <int NB>
-__device__ __forceinline__ unsigned select_probe(const unsigned *table, unsigned maskcap, int shift, int x, int y,
-                                                 unsigned (&slot_out)[NB]) {
-    // neighbour order: centre first, then the 4-neighbourhood, then the diagonals
-    constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
-    constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
-    unsigned key[NB], hsh[NB], t[NB];
-#pragma unroll
-    for (int n = 0; n < NB; n++) {
-        key[n] = select_key(x + DX[n], y + DY[n]);
-        hsh[n] = (key[n] * 2654435761u) >> shift;
+// The table is open addressing over BUCKETS of four keys (one 16-byte LDS read per probe; a plain
+// linear-probing table made the slowest lane of a wave walk 20-40 slots).  Keys fill a bucket front
+// to back and are never removed, so an empty last slot means "not in this bucket or any later one".
+// slot of `key`, or -1.  bmask = buckets - 1, shift = 32 - log2(buckets).
+__device__ __forceinline__ int select_find(const unsigned *keys, unsigned bmask, int shift, unsigned key) {
+    unsigned bk = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + 4 * bk);
+        if (q.x == key) return (int)(4 * bk);
+        if (q.y == key) return (int)(4 * bk + 1);
+        if (q.z == key) return (int)(4 * bk + 2);
+        if (q.w == key) return (int)(4 * bk + 3);
+        if (q.w == 0u) return -1;
+        bk = (bk + 1u) & bmask;
     }
-#pragma unroll
-    for (int n = 0; n < NB; n++) t[n] = table[hsh[n]];
-    unsigned found = 0u, pending = 0u;
-#pragma unroll
-    for (int n = 0; n < NB; n++) {
-        if (t[n] == key[n]) found |= 1u << n;
-        else if (t[n] != 0u) pending |= 1u << n;
+}
+// slot of `key`, inserting it if absent
+__device__ __forceinline__ int select_insert(unsigned *keys, unsigned bmask, int shift, unsigned key) {
+    unsigned bk = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + 4 * bk);
+        int j = (q.x == key || q.x == 0u) ? 0 : (q.y == key || q.y == 0u) ? 1 : (q.z == key || q.z == 0u) ? 2 : (q.w == key || q.w == 0u) ? 3 : 4;
+        for (; j < 4; j++) {
+            const unsigned prev = atomicCAS(&keys[4 * bk + j], 0u, key);
+            if (prev == 0u || prev == key) return (int)(4 * bk + j);
+        }
+        bk = (bk + 1u) & bmask;
     }
-    while (pending) { // collisions: keep probing linearly (rare)
-#pragma unroll
-        for (int n = 0; n < NB; n++)
-            if (pending & (1u << n)) {
-                hsh[n] = (hsh[n] + 1u) & maskcap;
-                const unsigned v = table[hsh[n]];
-                if (v == key[n]) { found |= 1u << n; pending &= ~(1u << n); }
-                else if (v == 0u) pending &= ~(1u << n);
-            }
-    }
-#pragma unroll
-    for (int n = 0; n < NB; n++) slot_out[n] = hsh[n];
-    return found;
 }
 
 // NB = 5 for z2max = 1 (plus-shaped disc), 9 for z2max = 2
 template <int NB>
-__global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
-    extern __shared__ unsigned table[];          // effective cells of all earlier steps
-    __shared__ unsigned step_key[256];           // cells of this step's candidates ...
-    __shared__ unsigned step_cnt[256];           // ... and how many candidates sit on each
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const unsigned cap = 1u << a.log2cap, maskcap = cap - 1u;
-    for (unsigned i = lane; i < cap; i += 64) table[i] = 0u;
+__global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
+    constexpr int NT = 1024, KMAX = 16, NW = (NB - 1) / 4;
+    constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
+    constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
+    extern __shared__ unsigned sel_lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned cap = 1u << a.log2cap, bmask = (cap >> 2) - 1u;
+    const int shift = 32 - (a.log2cap - 2);
+    unsigned *keys = sel_lds;
+    unsigned *minidx = sel_lds + cap;
+    unsigned char *status = reinterpret_cast<unsigned char *>(sel_lds + 2 * cap); // 0 undecided, 1 effective, 2 out
+    YM_STAMP(a, 24);
+    for (unsigned i = tid; i < cap; i += NT) { keys[i] = 0u; minidx[i] = 0xffffffffu; status[i] = 0; }
+    __syncthreads();
     int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     const int total = a.max_base * a.max_n;
-    int2 c_next = lane < total ? cells[lane] : make_int2(YM_CELL_NONE, YM_CELL_NONE);
-    unsigned slots[NB];
-    for (int e0 = 0; e0 < total; e0 += 64) {
-        const int e = e0 + lane;
-        const int2 c = c_next;
-        c_next = (e + 64) < total ? cells[e + 64] : make_int2(YM_CELL_NONE, YM_CELL_NONE); // prefetch
-        for (int i = lane; i < 256; i += 64) { step_key[i] = 0u; step_cnt[i] = 0u; }
-        bool cand = c.x != YM_CELL_NONE, skipped = false;
-        // (1) an earlier effective point within the 100-disc?
-        if (cand && select_probe<NB>(table, maskcap, 32 - a.log2cap, c.x, c.y, slots) != 0u) { cand = false; skipped = true; }
-        // (2) which candidates of this step have another candidate of the step in their disc?
-        if (cand) {
-            const unsigned key = select_key(c.x, c.y);
-            unsigned hsh = (key * 2654435761u) >> 24;
-            for (;;) {
-                const unsigned prev = atomicCAS(&step_key[hsh], 0u, key);
-                if (prev == 0u || prev == key) break;
-                hsh = (hsh + 1u) & 255u;
-            }
-            atomicAdd(&step_cnt[hsh], 1u);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave: LDS ops are in order
-        bool conflict = false;
-        if (cand) {
-            const unsigned found = select_probe<NB>(step_key, 255u, 24, c.x, c.y, slots);
-            conflict = (found & ~1u) != 0u || step_cnt[slots[0]] > 1u; // a neighbour cell, or company on my own cell
-        }
-        // (3) conflict-free candidates are effective; the others are resolved in order:
-        // the lowest remaining one is effective and knocks out later candidates in its disc
-        bool effective = cand && !conflict;
-        bool open = cand && conflict;
-        unsigned long long m = __ballot(open);
-        while (m) {
-            const int L = __ffsll((long long)m) - 1;
-            const int lx = __builtin_amdgcn_readlane(c.x, L), ly = __builtin_amdgcn_readlane(c.y, L);
-            if (lane == L) {
-                effective = true;
-                open = false;
-            } else if (open) {
-                const int dx = c.x - lx, dy = c.y - ly;
-                if (dx * dx + dy * dy <= a.z2max) { open = false; skipped = true; }
-            }
-            m = __ballot(open);
-        }
-        if (effective) { // distinct cells by construction: claim a free slot with a CAS
-            const unsigned key = select_key(c.x, c.y);
-            unsigned hsh = (key * 2654435761u) >> (32 - a.log2cap);
-            while (atomicCAS(&table[hsh], 0u, key) != 0u) hsh = (hsh + 1u) & maskcap;
-        }
-        if (skipped) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
-        __builtin_amdgcn_s_waitcnt(0xC07F); // inserts land before the next step's lookups
+    YM_STAMP(a, 25);
+    // (1) cell -> earliest point index
+    for (int e = tid; e < total; e += NT) {
+        const int2 c = cells[e];
+        if (c.x == YM_CELL_NONE) continue;
+        const int slot = select_insert(keys, bmask, shift, select_key(c.x, c.y));
+        atomicMin(&minidx[slot], (unsigned)e);
     }
+    __syncthreads();
+    YM_STAMP(a, 26);
+    // (2a) per owned slot (tid + k*NT): the slots of the neighbour cells that hold an EARLIER point,
+    // packed as 16-bit slot numbers (0xffff = none).  A cell with no earlier neighbour is effective.
+    unsigned long long nb[KMAX][NW];
+    unsigned und = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) nb[k][w] = ~0ull;
+        const unsigned s = tid + k * NT;
+        if (s >= cap) continue;
+        const unsigned key = keys[s];
+        if (key == 0u) continue;
+        const unsigned me = minidx[s];
+        const int x = (int)(key & 0xffffu) - 32768, y = (int)(key >> 16) - 32768;
+        bool any = false;
+#pragma unroll
+        for (int n = 1; n < NB; n++) {
+            const int t = select_find(keys, bmask, shift, select_key(x + DX[n], y + DY[n]));
+            if (t >= 0 && minidx[t] < me) {
+                any = true;
+                const int j = n - 1;
+                nb[k][j >> 2] &= ~(0xffffull << (16 * (j & 3)));
+                nb[k][j >> 2] |= (unsigned long long)(unsigned)t << (16 * (j & 3));
+            }
+        }
+        if (any) und |= 1u << k;
+        else status[s] = 1;
+    }
+    YM_STAMP(a, 27);
+    // (2b) asynchronous relaxation, no barriers: every wave keeps re-reading the state of the earlier
+    // neighbours of its undecided cells.  A decision is final and is taken only from final states
+    // (a stale "undecided" read merely delays it), and all 16 waves of the block are resident, so
+    // this terminates with the sequential greedy result whatever the interleaving.
+    unsigned char *vst = status;
+    unsigned wmask = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) wmask |= __ballot((und >> k) & 1u) ? (1u << k) : 0u;
+    while (wmask) {
+        unsigned m = wmask;
+        while (m) {
+            const int k = __builtin_ctz(m); // wave-uniform
+            m &= m - 1;
+            bool still = false;
+            asm volatile("" ::: "memory"); // re-read the states every time
+            if ((und >> k) & 1u) {
+                bool knocked = false, pending = false;
+#pragma unroll
+                for (int j = 0; j < NB - 1; j++) {
+                    const unsigned t = (unsigned)(nb[k][j >> 2] >> (16 * (j & 3))) & 0xffffu;
+                    if (t != 0xffffu) {
+                        const unsigned char stt = vst[t];
+                        knocked |= stt == 1;
+                        pending |= stt == 0;
+                    }
+                }
+                const unsigned s = tid + k * NT;
+                if (knocked) vst[s] = 2;
+                else if (!pending) vst[s] = 1;
+                else still = true;
+                if (!still) und &= ~(1u << k);
+            }
+            if (__ballot(still) == 0ull) wmask &= ~(1u << k);
+        }
+    }
+    __syncthreads();
+    YM_STAMP(a, 28);
+    // (3) keep only the earliest point of every effective cell
+    for (int e = tid; e < total; e += NT) {
+        const int2 c = cells[e];
+        if (c.x == YM_CELL_NONE) continue;
+        const int t = select_find(keys, bmask, shift, select_key(c.x, c.y));
+        if (!(t >= 0 && status[t] == 1 && minidx[t] == (unsigned)e)) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    }
+    YM_STAMP(a, 29);
 }
 
 // ================================================================== K2 raster

@@ -174,6 +174,14 @@ class ScanMatcher(object):
                                                    C.byref(n)))
         return buf[:n.value].copy()
 
+    def debug_cells(self, item=0, cap=1 << 16):
+        """Window cells (wx, wy) of the base readings that were rasterised, [slot][beam]; INT32_MIN = filtered."""
+        buf = np.zeros((cap, 2), dtype=np.int32)
+        max_n = C.c_int32()
+        _capi.check(self._lib.ym_debug_cells(self._m, item, buf.ctypes.data_as(C.POINTER(C.c_int32)), buf.size,
+                                             C.byref(max_n)))
+        return buf.reshape(-1, 2), max_n.value
+
     def debug_option(self, option, value):
         _capi.check(self._lib.ym_debug_option(self._m, int(option), int(value)))
 
