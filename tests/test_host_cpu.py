@@ -148,3 +148,97 @@ def test_sequential_mapper_call_pattern():
     # prior = last corrected (which carries the accumulated +0.01 corrections) + odometry increment
     assert abs(calls[-1][3] - (0.1 * 13 + 0.01 * 12)) < 1e-9
     assert len(mp.running_scans) == 10 and mp.running_scans[-1].num == 13
+
+
+def _light_scan(num, pose):
+    from yag_slam_amd.transform import Transform
+
+    class S:
+        pass
+    s = S()
+    s.num = num
+    s.corrected_pose = Transform(pose[0], pose[1], 0.0, pose[2])
+    return s
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_loop_chain_discovery_matches_reference(case):
+    # fixtures come from the reference's own GraphSlam.find_possible_loop_closure_chains
+    # (tests/golden/make_golden_chains.py); includes its squared-vs-plain distance comparison
+    import os
+    from yag_slam_amd.mapping import LoopClosingMapper
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loop_chains.npz"))
+    poses, links = g[case + "_poses"], g[case + "_links"]
+    dist, min_chain = g[case + "_params"]
+    dist = int(dist) if float(dist).is_integer() else float(dist)
+    mp = LoopClosingMapper(None, None, loop_search_dist=dist, loop_search_min_chain_size=int(min_chain))
+    items = [_light_scan(i, p) for i, p in enumerate(poses)]
+    eye = [[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]
+    li = 0
+    for i, it in enumerate(items):
+        mp.add_vertex(it)
+        if i > 0:
+            assert tuple(links[li]) == (i - 1, i)
+            mp.link_scans(items[i - 1], it, eye)
+            li += 1
+    for a, b in links[li:]:
+        mp.link_scans(items[a], items[b], eye)
+    mem, offs, qoffs = g[case + "_chain_members"], g[case + "_chain_offsets"], g[case + "_query_chain_offsets"]
+    total = 0
+    for qi, q in enumerate(g[case + "_queries"]):
+        want = [list(mem[offs[c]:offs[c + 1]]) for c in range(qoffs[qi], qoffs[qi + 1])]
+        got = [[s.num for s in ch] for ch in mp.find_possible_loop_closure_chains(items[q])]
+        assert got == want, (case, q)
+        total += len(want)
+    assert total > 50
+
+
+def test_loop_closing_mapper_two_stage_acceptance():
+    # graph_slam.py:194-261: coarse (loop matcher, no penalty, no fine) gates on 0.35, then the fine
+    # sequential match seeded with the coarse pose; first acceptable chain wins
+    from collections import namedtuple
+    from yag_slam_amd.mapping import LoopClosingMapper
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.transform import Transform
+    R = namedtuple("R", "best_pose response covariance meta")
+    eye = [[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]
+    log = []
+
+    class Seq:
+        def match_scan(self, q, base, pen, fine):
+            log.append(("seq", len(base), pen, fine, round(q.corrected_pose.x, 6)))
+            p = q.corrected_pose
+            return R(Transform(p.x, p.y, 0, p.euler[-1]), 0.9, eye, {})
+
+    class Loop:
+        def match_scan_batch(self, q, chains, pen, fine):
+            log.append(("loop", len(chains), pen, fine))
+            res = []
+            for k, ch in enumerate(chains):
+                good = k == len(chains) - 1          # only the last candidate chain passes the coarse gate
+                res.append(R(Transform(ch[0].corrected_pose.x + 0.5, ch[0].corrected_pose.y, 0, 0.0), 0.8 if good else 0.1, eye, {}))
+            return res, None
+
+    mp = LoopClosingMapper(Seq(), Loop(), loop_search_dist=1.0, loop_search_min_chain_size=5)
+    # out along +x for 4 m, jump back near the start along a parallel line 0.3 m away
+    path = [(0.1 * i, 0.0) for i in range(40)] + [(3.9 - 0.1 * i, 0.3) for i in range(1, 40)]
+    closed_at = []
+    for i, (x, y) in enumerate(path):
+        s = LocalizedRangeScan([1.0] * 5, -1, 1, 0.5, 0, 10, 5, 0, 0, 0)
+        s.odom_pose = Transform(x, y, 0, 0.0)
+        res, closed = mp.process_scan(s)
+        if closed:
+            closed_at.append(i)
+    assert closed_at, "the return leg never closed a loop"
+    first = closed_at[0]
+    num, chain, rc, rf = mp.closures[0]
+    assert num == first and rc.response == 0.8 and rf.response == 0.9
+    # the fine stage ran on the sequential matcher without penalty, with refinement, from the coarse pose
+    k = log.index(next(e for e in log if e[0] == "loop"))
+    assert log[k][2:] == (False, False)
+    assert log[k + 1][0] == "seq" and log[k + 1][2:4] == (False, True)
+    assert abs(log[k + 1][4] - round(mp.scans[chain[0]].corrected_pose.x + 0.5, 6)) < 1e-6
+    # a closure links the closing scan to the nearest member of the chain
+    assert any(t == num and f in chain for f, t, _, _ in mp.constraints)
+    # every scan got the odometry constraint to its predecessor
+    assert all(any(f == n - 1 and t == n for f, t, _, _ in mp.constraints) for n in range(1, len(path)))
