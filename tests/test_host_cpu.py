@@ -242,3 +242,88 @@ def test_loop_closing_mapper_two_stage_acceptance():
     assert any(t == num and f in chain for f, t, _, _ in mp.constraints)
     # every scan got the odometry constraint to its predecessor
     assert all(any(f == n - 1 and t == n for f, t, _, _ in mp.constraints) for n in range(1, len(path)))
+
+
+def _stub_factory(config_dict, loop):
+    from yag_slam_amd.config import make_config
+
+    class M:
+        pass
+    m = M()
+    m.config = make_config(config_dict, loop=loop)
+    m.loop = loop
+    return m
+
+
+def test_mapfile_reads_and_rewrites_reference_file():
+    # tests/golden/graph_ref.bin was written by the reference's GraphSlam.binarize()
+    # (tests/golden/make_golden_mapfile.py)
+    import math, os, zlib, msgpack
+    from yag_slam_amd import mapfile
+    blob = open(os.path.join(os.path.dirname(__file__), "golden", "graph_ref.bin"), "rb").read()
+    want = msgpack.unpackb(zlib.decompress(blob))
+    mp = mapfile.loads(blob, _stub_factory)
+    assert len(mp.scans) == 9 and [s.num for s in mp.running_scans] == [5, 6, 7, 8]
+    assert (mp.scan_buffer_len, mp.loop_search_dist, mp.loop_search_min_chain_size) == (4, 2.5, 3)
+    assert (mp.min_response_coarse, mp.min_response_fine) == (0.3, 0.5)
+    assert mp.seq_matcher.config.search_size == 0.6 and mp.seq_matcher.config.smear_deviation == 0.03
+    assert mp.loop_matcher.config.resolution == 0.05 and mp.loop_matcher.loop
+    for s, sd in zip(mp.scans, want["scans"]):
+        assert np.array_equal(np.asarray(s.ranges), np.asarray(sd["ranges"], dtype=np.float64), equal_nan=True)
+        assert (s.min_angle, s.max_angle, s.angle_increment, s.range_threshold) == (
+            sd["min_angle"], sd["max_angle"], sd["angle_increment"], sd["range_threshold"])
+        for mine, theirs in ((s.odom_pose, sd["odom_pose"]), (s.corrected_pose, sd["corrected_pose"])):
+            assert mine.x == theirs["x"] and mine.y == theirs["y"]
+            assert abs(mine.euler[-1] - 2 * math.atan2(theirs["qz"], theirs["qw"])) < 1e-15
+    assert math.isnan(mp.scans[3].ranges[5])
+    assert sorted((f, t) for f, t, _, _ in mp.constraints) == sorted((e[0], e[1]) for e in want["edges"])
+    assert 7 in mp.adjacent[1] and 1 in mp.adjacent[7]
+
+    # writing it back gives the reference's dict (floats to the last bit except the quaternion
+    # of a pose, which goes yaw -> quaternion once more)
+    got = msgpack.unpackb(zlib.decompress(mapfile.dumps(mp)))
+    assert got.keys() == want.keys()
+
+    def same(a, b, path=""):
+        if isinstance(a, dict):
+            assert isinstance(b, dict) and a.keys() == b.keys(), path
+            for k in a:
+                same(a[k], b[k], path + "/" + str(k))
+        elif isinstance(a, list):
+            assert isinstance(b, list) and len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, path + "/" + str(i))
+        elif isinstance(a, float) and math.isnan(a):
+            assert math.isnan(b), path
+        elif path.endswith(("/qz", "/qw")):
+            assert abs(a - b) < 1e-15, path
+        else:
+            assert a == b, (path, a, b)
+    same(got, want)
+
+
+def test_mapfile_round_trip_of_a_mapper(tmp_path):
+    from yag_slam_amd import mapfile
+    from yag_slam_amd.mapping import LoopClosingMapper
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.transform import Transform
+    mp = LoopClosingMapper(_stub_factory({}, False), None, scan_buffer_len=3)
+    eye = [[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]
+    prev = None
+    for i in range(5):
+        s = LocalizedRangeScan([1.0 + i] * 7, -1, 1, 0.3, 0, 10, 5, 0.2 * i, -0.1 * i, 0.3 * i - 3.0)
+        s.num = i
+        mp.add_vertex(s)
+        if prev is not None:
+            mp.link_scans(prev, s, eye)
+        prev = s
+    mp.running_scans = mp.scans[-3:]
+    p = str(tmp_path / "m.bin")
+    mapfile.to_file(mp, p)
+    back = mapfile.from_file(p, _stub_factory)
+    assert back.loop_matcher is None and len(back.scans) == 5
+    assert [(f, t) for f, t, _, _ in back.constraints] == [(f, t) for f, t, _, _ in mp.constraints]
+    for a, b in zip(mp.scans, back.scans):
+        assert np.array_equal(a.ranges, b.ranges)
+        assert abs(a.corrected_pose.euler[-1] - b.corrected_pose.euler[-1]) < 1e-15
+        assert (a.corrected_pose.x, a.corrected_pose.y) == (b.corrected_pose.x, b.corrected_pose.y)
