@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
+    ap.add_argument("--corr-chunks", type=int, default=0, help="development: beam chunks per angle in the correlate kernel")
+    ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
     ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
     args = ap.parse_args()
 
@@ -118,6 +120,10 @@ def main():
         m.debug_option(0, args.correlate_variant)
     if args.corr_u > 0:
         m.debug_option(3, args.corr_u)
+    if args.corr_chunks:
+        m.debug_option(5, args.corr_chunks)
+    if args.corr_pad_lds:
+        m.debug_option(4, args.corr_pad_lds)
     query, chains = build_inputs(args.batch, rank)
     batch = m.make_batch(query, chains)
     nslots = 8  # result slots cycled by the pipelined loop (all touched during warm-up)
@@ -205,7 +211,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ym::correlate_kernel<2, 32>",
+                "kernel": "ym::correlate_kernel<2, 16>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -3,7 +3,7 @@ import collections, csv, glob, json, sys
 
 def kernel_means(pattern):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(pattern):
+    for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if "ym::" in k:
@@ -19,14 +19,14 @@ def kernel_means(pattern):
 
 if __name__ == "__main__":
     tag, batch = sys.argv[1], int(sys.argv[2])
-    fetch = kernel_means("gpurun_out/%s_fetch/*/*counter_collection.csv" % tag)
-    l2 = kernel_means("gpurun_out/%s_l2/*/*counter_collection.csv" % tag)
+    fetch = kernel_means("gpurun_out/%s_fetch/**/*counter_collection.csv" % tag)
+    l2 = kernel_means("gpurun_out/%s_l2/**/*counter_collection.csv" % tag)
     rows = []
     for k in sorted(set(fetch) | set(l2)):
         f = fetch.get(k, {}).get("FETCH_SIZE", 0.0)
         h, m = l2.get(k, {}).get("TCC_HIT_sum", 0.0), l2.get(k, {}).get("TCC_MISS_sum", 0.0)
         rows.append((k, f, h, m))
-    with open("profiles/%s_pmc_batch%d.csv" % (tag, batch), "w") as o:
+    with open("profiles/%s_pmc_batch%d.csv" % (tag.replace("r01n", "r01_n"), batch), "w") as o:
         o.write("# rocprofv3 --pmc FETCH_SIZE | --pmc TCC_HIT_sum TCC_MISS_sum (separate passes): python3 bench.py --steps 5 --warmup 1 --batch %d --no-cpu-baseline\n" % batch)
         o.write("# FETCH_SIZE in KiB as reported; gfx950 counts half of a 16-B/lane stream (MI355X_MICROARCH.md): bytes ~= 2*1024*FETCH_SIZE\n")
         o.write("kernel,FETCH_SIZE_KiB_mean,TCC_HIT_sum_mean,TCC_MISS_sum_mean,l2_hit_rate\n")
@@ -38,6 +38,6 @@ if __name__ == "__main__":
                    "gfx950_wide_read_correction": 2.0,
                    "hbm_bytes_per_launch": corr[0][1] * 1024 * 2.0,
                    "l2_hit_rate": corr[0][2] / max(corr[0][2] + corr[0][3], 1.0),
-                   "source": "profiles/%s_pmc_batch%d.csv" % (tag, batch)},
+                   "source": "profiles/%s_pmc_batch%d.csv" % (tag.replace("r01n", "r01_n"), batch)},
                   open("profiles/traffic_correlate.json", "w"), indent=1)
-    print(open("profiles/%s_pmc_batch%d.csv" % (tag, batch)).read())
+    print(open("profiles/%s_pmc_batch%d.csv" % (tag.replace("r01n", "r01_n"), batch)).read())

@@ -183,6 +183,8 @@ struct ym_matcher {
     bool stamps_on = false;
     int corr_u = 0;      // development: force the number of beams in flight per lane (16, 32, 48)
     int full_raster = 0; // development: launch every raster tile
+    int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
+    int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
@@ -447,17 +449,20 @@ int launch_call(ym_matcher *m, Slot &slot) {
     const int jobs_pb = YM_CORR_THREADS / tpb;
     const int job_blocks = (njobs + jobs_pb - 1) / jobs_pb;
     const int ktiles = (lc.nt + tpb - 1) / tpb;
-    // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams
+    // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams; a small lattice (one
+    // working wave per block) does best with blocks of ~144 beams even when the batch alone fills the chip
+    // (measured on MI355X, cfg2 x 256: 3 chunks 618 us, 8 chunks 584 us, 17 chunks 563 us but more partial sums)
     const double waves_one_chunk = (double)((njobs + 63) / 64) * lc.nt * B;
     (void)ktiles;
     int n_chunks = (int)std::ceil(2048.0 / std::max(1.0, waves_one_chunk));
     n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
     n_chunks = std::max(n_chunks, (max_n + 511) / 512);
+    if (njobs <= 128) n_chunks = std::max(n_chunks, (max_n + 143) / 144);
+    if (m->corr_chunks > 0) n_chunks = std::max(m->corr_chunks, (max_n + 511) / 512);
     int chunk = (max_n + n_chunks - 1) / n_chunks;
-    // beams in flight per lane: small lattices have few waves per CU and need deep memory-level parallelism,
-    // big ones (many waves) do better with fewer registers (measured: cfg2 batch 890 -> 759 us with 32; stress
-    // 128 -> 158 us)
-    const int corr_u = m->corr_u > 0 ? m->corr_u : (njobs <= 128 ? 32 : 16);
+    // beams in flight per lane: 32 for the latency-bound single match (one 32-beam chunk per block), else 16
+    // (with the items pinned to XCDs 16 beats 32 on the batch: 618 vs 664 us; 48 spills)
+    const int corr_u = m->corr_u > 0 ? m->corr_u : (chunk <= 32 && njobs <= 128 ? 32 : 16);
     chunk = (chunk + corr_u - 1) / corr_u * corr_u;
     n_chunks = (max_n + chunk - 1) / chunk;
 
@@ -660,12 +665,14 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps; a.tpb = tpb;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 grid_dim(job_blocks, ktiles * n_chunks, B);
-        if (sx == 2 && m->use_lds_correlate == 1 && njobs <= 128)
-            hipLaunchKernelGGL(ym::correlate_lds_kernel, dim3((njobs + 63) / 64, lc.nt * n_chunks, B), dim3(256), 0, st, a);
-        else if (sx == 2 && corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
-        else if (sx == 2 && corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
-        else if (sx == 2) hipLaunchKernelGGL((ym::correlate_kernel<2, 48>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((ym::correlate_kernel<1, 16>), grid_dim, dim3(YM_CORR_THREADS), 0, st, a);
+        if (sx == 2 && m->use_lds_correlate >= 1 && njobs <= 128) {
+            a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
+            hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((njobs + 63) / 64, lc.nt * n_chunks, B), dim3(256), 0, st, a);
+        }
+        else if (sx == 2 && corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
+        else if (sx == 2 && corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
+        else if (sx == 2) hipLaunchKernelGGL((ym::correlate_kernel<2, 48>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
+        else hipLaunchKernelGGL((ym::correlate_kernel<1, 16>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
         if ((rc = prof_end(m, ev_k))) return rc;
     }
     // ---- K5a score
@@ -1238,6 +1245,8 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     if (option == 0) m->use_lds_correlate = value;
     else if (option == 2) m->full_raster = value;
     else if (option == 3) m->corr_u = value;
+    else if (option == 4) m->corr_pad_lds = value;
+    else if (option == 5) m->corr_chunks = value;
     else return set_err(YM_ERR_INVALID, "unknown option %d", option);
     return YM_OK;
 }
