@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
 }
 
 // ================================================================== K6 finish
-#define YM_FINISH_THREADS 1024
+#define YM_FINISH_THREADS 256
 #define YM_MAX_FINE_HYP 4096
 struct FinishArgs {
     YmGeom g;
@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     YM_STAMP(a, 15);
 }
 
-// ---- K6b final: grid (B), 1024 threads: positional covariance, fine arg-max / mean, angular covariance.
+// ---- K6b final: grid (B), 256 threads: fine arg-max / mean, angular covariance, result.
 __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) {
     constexpr int NT = YM_FINISH_THREADS;
     __shared__ double scratch[16 * 5];
@@ -1703,25 +1703,37 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         const int base = gy * a.g.pitch + gx;
         const int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
         __syncthreads(); // s_asum cleared above
-        // work item = (angle, beam); beams padded to whole waves so that a wave shares one angle
-        const int nq_pad = (nq + 63) & ~63;
-        const int total = nt * nq_pad;
-        for (int w0 = 0; w0 < total; w0 += 8 * NT) {
-            int kk[8];
-            unsigned idx[8], v[8];
+        // GetResponse(angle k, cell of the mean pose) uses the fine pass's own lookup offsets, so when that cell is one
+        // of the fine lattice's cells (always, unless fp rounding puts the tie mean outside) the sum IS the fine
+        // pass's integer sum for (k, that cell): take it instead of gathering the scan again.
+        int hit_x = -1, hit_y = -1;
+        for (int i = 0; i < nx; i++)
+            if (hyp_cell(cxw, start_x, i, L.step_x, off_x, a.g) == gx) hit_x = i;
+        for (int i = 0; i < ny; i++)
+            if (hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g) == gy) hit_y = i;
+        if (hit_x >= 0 && hit_y >= 0) {
+            for (int k = tid; k < nt; k += NT) s_asum[k] = fs[(size_t)k * nxy + hit_y * nx + hit_x];
+        } else {
+            // work item = (angle, beam); beams padded to whole waves so that a wave shares one angle
+            const int nq_pad = (nq + 63) & ~63;
+            const int total = nt * nq_pad;
+            for (int w0 = 0; w0 < total; w0 += 8 * NT) {
+                int kk[8];
+                unsigned idx[8], v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int w = w0 + u * NT + tid;
-                kk[u] = w < total ? w / nq_pad : -1; // wave-uniform
-                const int i = w - kk[u] * nq_pad;
-                idx[u] = (kk[u] >= 0 && i < nq) ? (unsigned)(base + foff[(size_t)kk[u] * a.max_n + i]) : limit;
-            }
+                for (int u = 0; u < 8; u++) {
+                    const int w = w0 + u * NT + tid;
+                    kk[u] = w < total ? w / nq_pad : -1; // wave-uniform
+                    const int i = w - kk[u] * nq_pad;
+                    idx[u] = (kk[u] >= 0 && i < nq) ? (unsigned)(base + foff[(size_t)kk[u] * a.max_n + i]) : limit;
+                }
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = idx[u] < limit ? grid[idx[u]] : 0u;
+                for (int u = 0; u < 8; u++) v[u] = idx[u] < limit ? grid[idx[u]] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const unsigned sum = wave_reduce(v[u], OpAddU());
-                if (lane == 0 && kk[u] >= 0) atomicAdd(&s_asum[kk[u]], sum);
+                for (int u = 0; u < 8; u++) {
+                    const unsigned sum = wave_reduce(v[u], OpAddU());
+                    if (lane == 0 && kk[u] >= 0) atomicAdd(&s_asum[kk[u]], sum);
+                }
             }
         }
         __syncthreads();
