@@ -162,6 +162,10 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
     return world_to_grid(centre + v, off, g.scale) + g.border - g.win_origin;
 }
 
+// raster tile (also used by prepare_kernel, which builds the raster's work list)
+#define YM_TILE_W 64
+#define YM_TILE_H 32
+
 // ================================================================== K1 prepare
 #define YM_PREP_THREADS 512
 #define YM_PREP_LDS_BYTES(max_n) ((size_t)(max_n) * 25 + ((size_t)(max_n) / 64 + 2) * 4 + 16)
@@ -388,6 +392,63 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     YM_STAMP_B1(a, 23);
 }
 
+// ================================================================== K1c tiles: the raster kernel's work list (batches)
+// One raster block per tile of the window lets ~3 of 4 blocks find out, after a round trip through the chunk boxes
+// and a barrier, that they have nothing to do; on a batch that was most of the raster's time.  For batches this
+// kernel (one block per item) turns the item's chunk boxes into the list of tiles that have work: a tile bitmap in
+// LDS (every box marks the few tiles its smear halo reaches), compacted together with the tiles that hold stale
+// bytes from an earlier call and only need clearing.  The raster kernel then runs one block per list entry.
+// (Doing this in the last prepare block to finish needs a device-scope release per block, which on this part
+// writes the XCD's L2 back: measured 98 -> 771 us for the prepare kernel.  A kernel boundary is cheaper.)
+#define YM_TILES_THREADS 256
+struct TilesArgs {
+    const int4 *bbox;        // [B][max_base][ceil(max_n/64)]
+    uint16_t *tile_list;     // [B][tile_cap] tile index (tiy * tiles_x + tix), | 0x8000 = only needs clearing
+    int32_t *tile_count;     // [B]
+    const uint8_t *tile_zero;// [B][tiles_y][tiles_x] 1 = the tile's memory is known to hold zeros
+    int32_t max_n, max_base, half_kernel;
+    int32_t tiles_x, tiles_y, tile_cap;
+    int32_t launch[4];       // tile rectangle (x0, y0, x1, y1) the raster covers in this call
+};
+// grid (B), dynamic LDS = 4 * ceil(tiles_x * tiles_y / 32) bytes
+__global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
+    extern __shared__ unsigned tile_bits[];
+    __shared__ int s_n;
+    constexpr int NT = YM_TILES_THREADS;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ntiles = a.tiles_x * a.tiles_y, nwords = (ntiles + 31) / 32;
+    for (int i = tid; i < nwords; i += NT) tile_bits[i] = 0u;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int h = a.half_kernel;
+    const int lx0 = a.launch[0], ly0 = a.launch[1], lx1 = a.launch[2], ly1 = a.launch[3];
+    const int n_boxes = a.max_base * ((a.max_n + 63) / 64);
+    const int4 *bbox = a.bbox + (size_t)b * n_boxes;
+    for (int c = tid; c < n_boxes; c += NT) {
+        const int4 bb = bbox[c];
+        if (bb.x > bb.z) continue;
+        // tiles whose halo-extended rectangle [t*T - h, t*T + T + h - 1] meets the box (the raster kernel's own test)
+        const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
+        const int ty0 = max(ly0, max(bb.y - h, 0) / YM_TILE_H), ty1 = min(ly1, (bb.w + h) / YM_TILE_H);
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int t = ty * a.tiles_x + tx;
+                atomicOr(&tile_bits[t >> 5], 1u << (t & 31));
+            }
+    }
+    __syncthreads();
+    const int ltx = lx1 - lx0 + 1, lty = ly1 - ly0 + 1;
+    const uint8_t *tz = a.tile_zero + (size_t)b * ntiles;
+    uint16_t *list = a.tile_list + (size_t)b * a.tile_cap;
+    for (int i = tid; i < ltx * lty; i += NT) {
+        const int ty = ly0 + i / ltx, tx = lx0 + i % ltx, t = ty * a.tiles_x + tx;
+        const bool hit = (tile_bits[t >> 5] >> (t & 31)) & 1u;
+        if (hit || tz[t] == 0) list[atomicAdd(&s_n, 1)] = (uint16_t)(t | (hit ? 0 : 0x8000));
+    }
+    __syncthreads();
+    if (tid == 0) a.tile_count[b] = s_n;
+}
+
 // ================================================================== K1b select (only when the smear kernel has taps == 100 off-centre)
 // Karto's AddScan skips a point whose cell already holds 100 ("value already set").  With
 // smear_deviation >= 9.99 * resolution the four neighbours of an occupied cell are stamped 100 as
@@ -548,9 +609,6 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
 }
 
 // ================================================================== K2 raster
-#define YM_TILE_W 64
-#define YM_TILE_H 32
-#define YM_RASTER_THREADS 256
 struct RasterArgs {
     const int2 *cells;
     const int4 *bbox;     // [B][max_base][ceil(max_n/64)]
@@ -564,6 +622,10 @@ struct RasterArgs {
     uint8_t *tile_zero;   // [B][tiles_y][tiles_x]: 1 = this tile of the window memory is known to hold zeros
     int32_t tiles_x, tiles_y; // full tiling of the window
     int32_t tile_x0, tile_y0; // first tile of the launched sub-grid (tiles outside it are known to be zero)
+    int32_t ltx;              // tile columns of the launched sub-grid
+    const uint16_t *tile_list; // [B][tile_cap] work list built by tiles_kernel, or null: one block per sub-grid tile
+    const int32_t *tile_count; // [B]
+    int32_t tile_cap;
     unsigned long long *stamps;
 };
 
@@ -575,20 +637,36 @@ struct RasterArgs {
 // cell's final value is lut[min squared distance to an occupied cell inside the (2h+1)^2 window]:
 //   row pass   g(y, x)  = min |dx| <= h with cell (y, x+dx) occupied      (bit scans on a row bitmap)
 //   column pass m(y, x) = min over |dy| <= h of dy^2 + g(y+dy, x)^2        (8 cells per lane)
-__global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a) {
-    constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF, NT = YM_RASTER_THREADS;
+// NT = 256: one tile row per thread, shortest latency (single match); NT = 128: two rows per thread, twice the
+// blocks per CU -- the tiles with work are latency-bound, so a batch gains (raster 160 -> 140 us on 256 items)
+template <int NT>
+__global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
+    constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF;
     constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
     constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
     __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
     __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
     __shared__ unsigned char lut[2 * HM * HM + 8];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
+    // grid (tiles of the launched sub-grid, B).  With a work list (batches) block i takes entry i and the blocks
+    // past the list's end leave at once; without one (a few items: one more launch would cost more than it saves)
+    // block i is tile i of the sub-grid and finds out by itself whether any chunk box reaches it.
+    const bool listed = a.tile_list != nullptr;
+    unsigned entry;
+    if (listed) {
+        if ((int)blockIdx.x >= a.tile_count[b]) return;
+        entry = a.tile_list[(size_t)b * a.tile_cap + blockIdx.x];
+    } else {
+        const int sy = (int)blockIdx.x / a.ltx, sx = (int)blockIdx.x - sy * a.ltx;
+        // rotate the tile column by the row: a sub-grid width that is a multiple of 8 would otherwise pin every
+        // tile column (i.e. every wall) to one XCD
+        entry = (unsigned)((a.tile_y0 + sy) * a.tiles_x + a.tile_x0 + (sx + 3 * sy + 5 * b) % a.ltx);
+    }
+    const int tile = (int)(entry & 0x7fffu);
     const int h = a.g.half_kernel;
     const int OW = TW + 2 * h, OH = TH + 2 * h;
-    // Blocks go round-robin over the 8 XCDs by linear id; rotating the tile column by the row keeps a
-    // launch width that is a multiple of 8 from pinning every tile column (i.e. every wall) to one XCD.
-    const int tix = a.tile_x0 + (int)((blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z) % gridDim.x), tiy = a.tile_y0 + (int)blockIdx.y;
+    const int tiy = tile / a.tiles_x, tix = tile - tiy * a.tiles_x;
     const int tx0 = tix * TW, ty0 = tiy * TH;
     YM_STAMP(a, 4);
     // candidate chunks: 64 consecutive cells of one base scan whose bounding box touches tile + halo
@@ -597,36 +675,51 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     const int4 *bbox = a.bbox + (size_t)b * n_boxes;
     const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
     uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
-    const int y = tid / LPR, x8 = (tid % LPR) * 8; // thread -> 8 consecutive cells of one tile row
-    const bool row_ok = (ty0 + y) < a.g.win_w;
-    uint2 *dst = reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8);
+    // thread -> 8 consecutive cells (x8 ..) of tile rows y0, y0 + NT / LPR, ...
+    const int y0 = tid / LPR, x8 = (tid % LPR) * 8;
     const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
-    uint8_t *pl = a.planes + (size_t)b * a.grid_stride + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
+    uint8_t *planes = a.planes + (size_t)b * a.grid_stride;
+    // the window row-major and its even / odd column planes (v_perm_b32 byte gathers) for 8 cells of tile row y
+    auto store8 = [&](int y, uint32_t p0, uint32_t p1) {
+        if (ty0 + y < a.g.win_w) {
+            *reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8) = make_uint2(p0, p1);
+            uint8_t *pl = planes + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
+            *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+            *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
+        }
+    };
+    auto zero_tile = [&]() {
+        for (int y = y0; y < TH; y += NT / LPR) store8(y, 0u, 0u);
+    };
     uint8_t *tz = a.tile_zero + ((size_t)b * a.tiles_y + tiy) * a.tiles_x + tix;
-    // Most tiles see no box at all: decide that before touching LDS.  Hits are compacted into a list so
-    // that the cell loads of several chunks are in flight together.
     __shared__ int s_hits[256];
     __shared__ int s_nhits;
-    int my_hits = 0;
-    for (int c = tid; c < n_boxes; c += NT) {
-        const int4 bb = bbox[c];
-        my_hits += (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) ? 1 : 0;
-    }
-    if (tid == 0) s_nhits = 0;
-    if (__syncthreads_or(my_hits) == 0) {
-        // empty tile: zeros -- unless this memory is already known to be zero from an earlier call
-        if (*tz == 0) {
-            if (row_ok) {
-                *dst = make_uint2(0u, 0u);
-                *reinterpret_cast<uint32_t *>(pl) = 0u;
-                *reinterpret_cast<uint32_t *>(pl + plane_bytes) = 0u;
-            }
-            __syncthreads();
-            if (tid == 0) *tz = 1;
-        }
+    if (entry & 0x8000u) { // no chunk reaches this tile, but its memory still holds an earlier call's bytes
+        zero_tile();
+        if (tid == 0) *tz = 1;
         return;
     }
-    for (int c = tid; c < n_boxes; c += NT) { // second look at the (L1-resident) boxes: compact the hits
+    if (tid == 0) s_nhits = 0;
+    if (!listed) { // decide "no box at all" before touching LDS
+        int my_hits = 0;
+        for (int c = tid; c < n_boxes; c += NT) {
+            const int4 bb = bbox[c];
+            my_hits += (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) ? 1 : 0;
+        }
+        if (__syncthreads_or(my_hits) == 0) {
+            // empty tile: zeros -- unless this memory is already known to be zero from an earlier call
+            if (*tz == 0) {
+                zero_tile();
+                __syncthreads();
+                if (tid == 0) *tz = 1;
+            }
+            return;
+        }
+    } else {
+        __syncthreads();
+    }
+    // chunks whose box touches tile + halo, compacted so that the cell loads of several chunks are in flight together
+    for (int c = tid; c < n_boxes; c += NT) {
         const int4 bb = bbox[c];
         if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
             const int at = atomicAdd(&s_nhits, 1);
@@ -695,11 +788,7 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     YM_STAMP(a, 5);
     if (!any) {
         if (*tz == 0) {
-            if (row_ok) {
-                *dst = make_uint2(0u, 0u);
-                *reinterpret_cast<uint32_t *>(pl) = 0u;
-                *reinterpret_cast<uint32_t *>(pl + plane_bytes) = 0u;
-            }
+            zero_tile();
             __syncthreads();
             if (tid == 0) *tz = 1;
         }
@@ -707,53 +796,65 @@ __global__ __launch_bounds__(YM_RASTER_THREADS) void raster_kernel(RasterArgs a)
     }
     if (tid == 0) *tz = 0;
     // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
-    // Walls are thin: most windows hold no bit at all, so the empty case leaves early.
+    // Work item = 8 consecutive cells of one (halo) row.  Walls are thin: most 8-cell groups see no bit within
+    // reach at all and leave after one test.
     const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
-    for (int i = tid; i < OH * TW; i += NT) {
-        const int ry = i / TW, rx = i % TW;
+    const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
+    for (int i = tid; i < OH * LPR; i += NT) {
+        const int ry = i / LPR, rx = (i % LPR) * 8;
         const int w = rx >> 6, sft = rx & 63;
         const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
-        unsigned char g = 255;
-        if (lo | hi) {
-            const unsigned long long win = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & wmask;
-            if (win) {
-                const unsigned long long right = win >> h, left = win & lmask;
-                const int dr = right ? (__ffsll((long long)right) - 1) : 255;
-                const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
-                g = (unsigned char)(dr < dl ? dr : dl);
+        const unsigned long long sw = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask; // bits rx .. rx + 7 + 2h
+        uint32_t out[2] = {0xffffffffu, 0xffffffffu};
+        if (sw) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const unsigned long long win = (sw >> q) & wmask;
+                if (win) {
+                    const unsigned long long right = win >> h, left = win & lmask;
+                    const int dr = right ? (__ffsll((long long)right) - 1) : 255;
+                    const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
+                    const unsigned g = (unsigned)(dr < dl ? dr : dl);
+                    out[q >> 2] = (out[q >> 2] & ~(0xffu << (8 * (q & 3)))) | (g << (8 * (q & 3)));
+                }
             }
         }
-        grow[i] = g;
+        *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
     }
     __syncthreads();
     YM_STAMP(a, 6);
-    // column pass: 8 cells per lane; a row whose 8 distances are all "none" contributes nothing
-    unsigned mn[8];
+    // column pass: 8 cells per lane as four pairs of 16-bit lanes (cells 0|2, 1|3, 4|6, 5|7): the candidate
+    // g*g + dy*dy is at most 255^2 + h^2 < 65536, so one v_pk_mad_u16 + one v_pk_min_u16 serve two cells.
+    // A row whose 8 distances are all "none" contributes nothing.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const unsigned max_d2 = (unsigned)(2 * h * h);
+    for (int y = y0; y < TH; y += NT / LPR) {
+        us2 mn2[4];
 #pragma unroll
-    for (int q = 0; q < 8; q++) mn[q] = 0x7fffffffu;
-    for (int dy = -h; dy <= h; dy++) {
-        const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + h + dy) * TW + x8]);
-        if ((gg.x & gg.y) == 0xffffffffu) continue;
-        const unsigned d2 = (unsigned)(dy * dy);
+        for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
+        for (int dy = -h; dy <= h; dy++) {
+            const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + h + dy) * TW + x8]);
+            if ((gg.x & gg.y) == 0xffffffffu) continue;
+            const unsigned short d2 = (unsigned short)(dy * dy);
+            const us2 dd = (us2){d2, d2};
+            const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                us2 gq;
+                __builtin_memcpy(&gq, &u[q], 4);
+                mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 (none) is larger than any real distance
+            }
+        }
+        unsigned mn[8];
+        mn[0] = mn2[0].x; mn[2] = mn2[0].y; mn[1] = mn2[1].x; mn[3] = mn2[1].y;
+        mn[4] = mn2[2].x; mn[6] = mn2[2].y; mn[5] = mn2[3].x; mn[7] = mn2[3].y;
+        uint32_t packed[2] = {0u, 0u};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const unsigned gq = ((q < 4 ? gg.x : gg.y) >> (8 * (q & 3))) & 0xffu;
-            const unsigned cand = gq * gq + d2;  // g = 255 (none) is larger than any real distance
-            mn[q] = cand < mn[q] ? cand : mn[q];
+            const unsigned v = mn[q] <= max_d2 ? lut[mn[q]] : 0u;
+            packed[q >> 2] |= v << (8 * (q & 3));
         }
-    }
-    uint32_t packed[2] = {0u, 0u};
-    const unsigned max_d2 = (unsigned)(2 * h * h);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const unsigned v = mn[q] <= max_d2 ? lut[mn[q]] : 0u;
-        packed[q >> 2] |= v << (8 * (q & 3));
-    }
-    if (row_ok) {
-        *dst = make_uint2(packed[0], packed[1]);
-        // even / odd columns of the same 8 cells (v_perm_b32 byte gathers)
-        *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(packed[1], packed[0], 0x06040200u);
-        *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(packed[1], packed[0], 0x07050301u);
+        store8(y, packed[0], packed[1]);
     }
     YM_STAMP(a, 7);
 }
