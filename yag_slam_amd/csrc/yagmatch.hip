@@ -172,7 +172,7 @@ struct ym_matcher {
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
-    DevBuf<uint32_t> partial;  // per beam-chunk partial sums of the coarse lattice
+    DevBuf<uint16_t> partial;  // per beam-chunk partial sums of the coarse lattice
     DevBuf<uint32_t> sums;     // coarse sums, then fine sums
     DevBuf<double> resp;
     DevBuf<double> blockmax;
@@ -452,14 +452,15 @@ int launch_call(ym_matcher *m, Slot &slot) {
     const int job_blocks = (njobs + jobs_pb - 1) / jobs_pb;
     const int ktiles = (lc.nt + tpb - 1) / tpb;
     // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams; a small lattice (one
-    // working wave per block) does best with blocks of ~144 beams even when the batch alone fills the chip
-    // (measured on MI355X, cfg2 x 256: 3 chunks 618 us, 8 chunks 584 us, 17 chunks 563 us but more partial sums)
+    // working wave per block) does best with blocks of 64 beams even when the batch alone fills the chip
+    // (measured on MI355X, cfg2 x 256, whole step: 3 chunks 1.09 ms, 8 chunks 0.95 ms, 17 chunks 0.91 ms, 23 chunks
+    // 0.97 ms; the partial sums are 16-bit)
     const double waves_one_chunk = (double)((njobs + 63) / 64) * lc.nt * B;
     (void)ktiles;
     int n_chunks = (int)std::ceil(2048.0 / std::max(1.0, waves_one_chunk));
     n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
     n_chunks = std::max(n_chunks, (max_n + 511) / 512);
-    if (njobs <= 128) n_chunks = std::max(n_chunks, (max_n + 143) / 144);
+    if (njobs <= 128) n_chunks = std::max(n_chunks, (max_n + 63) / 64);
     if (m->corr_chunks > 0) n_chunks = std::max(m->corr_chunks, (max_n + 511) / 512);
     int chunk = (max_n + n_chunks - 1) / n_chunks;
     // beams in flight per lane: 32 for the latency-bound single match (one 32-beam chunk per block), else 16

@@ -871,7 +871,7 @@ struct CorrArgs {
     const double2 *qlocal;  // [B][max_n] query points in the sensor frame
     const int32_t *hypcell;
     const YmItemState *states;
-    uint32_t *partial;     // [B][n_chunks][nt][ny][nx_pad]
+    uint16_t *partial;     // [B][n_chunks][nt][ny][nx_pad], 16-bit: a chunk sums at most 512 beams x 100
     size_t partial_stride; // per item
     int32_t max_n, nt_stride, dim_stride;
     int32_t chunk;         // beams per chunk (multiple of 16, <= 512 keeps the 16-bit lanes from overflowing)
@@ -913,6 +913,20 @@ __device__ __forceinline__ int xcd_item_of_block_2d(int &inner) {
         inner = t % per_item;
     }
     return item;
+}
+
+// The correlate kernels accumulate 16 hypotheses per lane in eight dwords of two 16-bit lanes each: acc[2j] holds
+// hypotheses 4j and 4j + 2, acc[2j + 1] holds 4j + 1 and 4j + 3 (even / odd bytes of grid dword j).  A chunk is at
+// most 512 beams of at most 100, so partial sums are stored as 16-bit values, in hypothesis order (v_perm_b32).
+__device__ __forceinline__ void store_partial16(uint16_t *out, const uint32_t (&acc)[8]) {
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        w[2 * j] = __builtin_amdgcn_perm(acc[2 * j + 1], acc[2 * j], 0x05040100u);     // hyp 4j, 4j + 1
+        w[2 * j + 1] = __builtin_amdgcn_perm(acc[2 * j + 1], acc[2 * j], 0x07060302u); // hyp 4j + 2, 4j + 3
+    }
+    *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4 *>(out + 8) = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // Lane job = 16 x-adjacent hypotheses of one lattice row for one angle.  The coarse search steps
@@ -970,7 +984,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     if (job >= njobs || !k_ok) return;
     const int iy = job / a.ngx, xg = job - iy * a.ngx;
     const int cyv = cy[iy];
-    uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+    uint16_t *out = a.partial + (size_t)b * a.partial_stride +
                     (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
 
     if (regular) {
@@ -1027,14 +1041,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
                 }
             }
         }
-        uint32_t r[G];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
-            r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
-        }
-#pragma unroll
-        for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+        store_partial16(out, acc);
         YM_STAMP(a, 9);
     } else {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
@@ -1051,7 +1058,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
                     sum += idx < limit ? grid[idx] : 0u;
                 }
             }
-            out[j] = sum;
+            out[j] = (uint16_t)sum;
         }
     }
 }
@@ -1369,16 +1376,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (wave == 0 && active) {
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] = red[j * 64 + lane] + red[(8 + j) * 64 + lane] + red[(16 + j) * 64 + lane] + red[(24 + j) * 64 + lane];
-            uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+            uint16_t *out = a.partial + (size_t)b * a.partial_stride +
                             (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
-            uint32_t r[G];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                r[4 * j] = acc[2 * j] & 0xFFFFu; r[4 * j + 1] = acc[2 * j + 1] & 0xFFFFu;
-                r[4 * j + 2] = acc[2 * j] >> 16; r[4 * j + 3] = acc[2 * j + 1] >> 16;
-            }
-#pragma unroll
-            for (int j = 0; j < G; j += 4) *reinterpret_cast<uint4 *>(out + j) = make_uint4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+            store_partial16(out, acc);
         }
         YM_STAMP(a, 23);
     } else {
@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
         const int32_t *cyp = cxp + a.dim_stride;
-        uint32_t *out = a.partial + (size_t)b * a.partial_stride +
+        uint16_t *out = a.partial + (size_t)b * a.partial_stride +
                         (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
         const int n_here = min(nq - i0, a.chunk);
         for (int j = 0; j < G; j++) {
@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     sum += idx < limit ? grid[idx] : 0u;
                 }
             }
-            out[j] = sum;
+            out[j] = (uint16_t)sum;
         }
     }
 }
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 struct ScoreArgs {
     YmGeom g;
     YmLattice lat;
-    const uint32_t *partial;
+    const uint16_t *partial;
     size_t partial_stride;
     const YmItemState *states;
     uint32_t *sums;       // [B][nt][ny][nx]
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     if (h < nxy * nt) {
         const int k = h / nxy, c = h - k * nxy;
         const int iy = c / nx, ix = c - iy * nx;
-        const uint32_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
+        const uint16_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
         const size_t cstride = (size_t)nt * ny * a.nx_pad;
         unsigned sum = 0;
 #pragma unroll 8
