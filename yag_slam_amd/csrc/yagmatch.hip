@@ -613,7 +613,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
             for (int i = 0; i < nscans; i++) a.inl.scans[i] = hs[i];
         }
         const size_t lds = YM_PREP_LDS_BYTES(max_n);
-        hipLaunchKernelGGL(ym::prepare_kernel, dim3(max_base + 1, B), dim3(YM_PREP_THREADS), lds, st, a);
+        if (B >= 8) hipLaunchKernelGGL(ym::prepare_kernel<256>, dim3(max_base + 1, B), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(max_base + 1, B), dim3(512), lds, st, a);
     }
     // ---- K1b select: Karto's order-dependent "value already set" rule (only when the kernel has 100-valued taps off-centre)
     if (g.zone_count > 1) {
@@ -924,7 +925,9 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot raise the dynamic LDS limit of prepare_kernel");
         ym_destroy(m);

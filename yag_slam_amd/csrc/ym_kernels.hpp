@@ -167,7 +167,6 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 #define YM_TILE_H 32
 
 // ================================================================== K1 prepare
-#define YM_PREP_THREADS 512
 #define YM_PREP_LDS_BYTES(max_n) ((size_t)(max_n) * 25 + ((size_t)(max_n) / 64 + 2) * 4 + 16)
 #define YM_INLINE_SCANS 16
 struct YmInlineDesc {        // call descriptor passed in the kernel arguments (single item, few scans)
@@ -193,12 +192,14 @@ struct PrepareArgs {
     unsigned long long *stamps;
 };
 
-// grid (max_base + 1, B), YM_PREP_THREADS threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n)
+// grid (max_base + 1, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).  NT = 512: shortest latency (single
+// match); NT = 256: the kernel needs ~100 VGPRs (fp64 sincos), i.e. 16 waves per CU, and four blocks of 256 hide
+// each other's barriers and loads better than two of 512 (98 -> 76 us on 256 items).
 // blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.
-__global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ int wave_counts[YM_PREP_THREADS / 64];
-    constexpr int NT = YM_PREP_THREADS;
+    __shared__ int wave_counts[NT / 64];
     YM_STAMP(a, 0);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(YM_PREP_THREADS) void prepare_kernel(PrepareArgs a)
     const int n_cchunks = (a.max_n + 63) / 64;
     if (!is_query && slot >= it.base_count) { // unused chain slot: no points, empty boxes
         int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
-        for (int i = threadIdx.x; i < n_cchunks; i += YM_PREP_THREADS) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
+        for (int i = threadIdx.x; i < n_cchunks; i += NT) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
         return;
     }
     const int si = is_query ? it.query : it.base_begin + slot;
