@@ -164,6 +164,54 @@ def test_batch_matches_single_calls():
     assert best == int(np.argmax([s.response for s in singles]))
 
 
+@pytest.mark.parametrize("finish_form", [0, 1])
+def test_large_batch_matches_single_calls(finish_form):
+    """Batches of 8 or more items take different kernels than a single match (256-thread prepare blocks, the raster's
+    tile work list, the one-block finish kernel; option 6 = 1 forces the per-angle fine/final pair): every result
+    must still be the single call's, bit for bit -- penalty, refinement, ragged and empty chains included."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    chains_p = synth.chain_poses(6, chain_len=5, scene=scene)
+    mk = lambda r, p: PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 20.0, p)
+    far = [[_mk_native(mk(scene.scan_ranges(p, index=500 + 10 * c + i), p)) for i, p in enumerate(ch)]
+           for c, ch in enumerate(chains_p)]
+    chains = [nb, nb[:3], nb[2:9], far[1], [], nb[::-1], far[2], nb[4:5], far[3], nb[1:], far[4]]
+    m = ScanMatcher()
+    m.debug_option(6, finish_form)
+    for pen, fine in ((True, True), (False, False)):
+        per, best = m.match_scan_batch(nq, chains, pen, fine)
+        m.debug_option(6, 0)
+        singles = [m.match_scan(nq, ch, pen, fine) for ch in chains]
+        m.debug_option(6, finish_form)
+        for a, b in zip(per, singles):
+            assert a.response == b.response
+            assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+            assert a.covariance == b.covariance
+            assert a.meta["hypotheses"] == b.meta["hypotheses"] and a.meta["expansions"] == b.meta["expansions"]
+        assert best == int(np.argmax([s.response for s in singles]))
+    # a second, different call on the same matcher: the tile work list must clear what the first one left behind
+    g1 = m.match_scan_batch(nq, [far[5]] * 9, True, True)[0][0]
+    g2 = m.match_scan(nq, far[5], True, True)
+    assert g1.response == g2.response and g1.covariance == g2.covariance
+
+
+def test_finish_kernel_single_item_matches_pair():
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    m = ScanMatcher()
+    ref = m.match_scan(nq, nb, True, True)
+    fs_ref = m.debug_sums(1, dims=ref.meta["fine_dims"])
+    m.debug_option(6, 2)
+    got = m.match_scan(nq, nb, True, True)
+    assert got.response == ref.response and got.covariance == ref.covariance
+    assert (got.best_pose.x, got.best_pose.y, got.best_pose.euler[-1]) == (ref.best_pose.x, ref.best_pose.y, ref.best_pose.euler[-1])
+    assert np.array_equal(m.debug_sums(1, dims=got.meta["fine_dims"]), fs_ref)
+
+
 def test_async_pipeline_matches_sync():
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()

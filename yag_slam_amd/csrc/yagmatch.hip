@@ -185,6 +185,7 @@ struct ym_matcher {
     int full_raster = 0; // development: launch every raster tile
     DevBuf<uint16_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
+    int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
@@ -720,8 +721,12 @@ int launch_call(ym_matcher *m, Slot &slot) {
         a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = grid_stride;
         a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
         a.fsums_stride = sums_f; a.stamps = stamps;
-        hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
-        hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
+        if ((B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
+            hipLaunchKernelGGL(ym::finish_kernel, dim3(B), dim3(YM_FINISH1_THREADS), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
+            hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
+        }
     }
     } // karto
     if (slot.dev_best_out)
@@ -1272,6 +1277,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 3) m->corr_u = value;
     else if (option == 4) m->corr_pad_lds = value;
     else if (option == 5) m->corr_chunks = value;
+    else if (option == 6) m->finish_form = value;
     else return set_err(YM_ERR_INVALID, "unknown option %d", option);
     return YM_OK;
 }

@@ -1500,6 +1500,10 @@ struct FinishArgs {
 };
 
 // sum N doubles across the block in one round (2 barriers); result in every thread
+// Floating-point sums that reach the result (tie means, covariances) are accumulated by the first YM_CANON threads
+// only, element e by thread e % YM_CANON in increasing e: the kernels that share this code run with 256, 512 or 1024
+// threads and must produce the same bits.  (block_sum_vec adds the waves in order; idle waves contribute exact zeros.)
+#define YM_CANON 256
 template <int N>
 __device__ __forceinline__ void block_sum_vec(double (&v)[N], double *scratch /* >= 16*N */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -1544,24 +1548,32 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
     double lb = -1.0;
     for (int i = tid; i < n_blocks; i += NT) { const double v = bm[i]; lb = v > lb ? v : lb; }
     const double best = block_reduce(lb, OpMaxD(), -1.0, scratch);
-    // score blocks that can hold a hypothesis with DoubleEqual(response, best)
-    int overflow = 0;
-    for (int i = tid; i < n_blocks; i += NT)
-        if (bm[i] >= best - YM_KT_TOLERANCE) {
-            const int at = atomicAdd(s_nlist, 1);
-            if (at < NT) s_list[at] = i; else overflow = 1;
-        }
+    // score blocks that can hold a hypothesis with DoubleEqual(response, best), in ascending order (ordered
+    // compaction: which thread sums which hypothesis must not depend on a race)
+    int overflow = 0, listed = 0;
+    int *wave_counts = reinterpret_cast<int *>(scratch + 64);
+    for (int i0 = 0; i0 < n_blocks; i0 += NT) {
+        const int i = i0 + tid;
+        const bool hit = i < n_blocks && bm[i] >= best - YM_KT_TOLERANCE;
+        int total;
+        const int at = listed + block_scan_flag(hit, &total, wave_counts);
+        if (hit) { if (at < NT) s_list[at] = i; else overflow = 1; }
+        listed += total;
+    }
+    if (tid == 0) *s_nlist = listed < NT ? listed : NT;
     overflow = __syncthreads_or(overflow);
     double acc[5] = {0, 0, 0, 0, 0};
-    if (!overflow) {
-        const int nlist = *s_nlist;
-        for (int w = tid; w < nlist * YM_SCORE_THREADS; w += NT) {
-            const int h = s_list[w / YM_SCORE_THREADS] * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
-            if (h < nh && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+    if (tid < YM_CANON) {
+        if (!overflow) {
+            const int nlist = *s_nlist;
+            for (int w = tid; w < nlist * YM_SCORE_THREADS; w += YM_CANON) {
+                const int h = s_list[w / YM_SCORE_THREADS] * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
+                if (h < nh && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+            }
+        } else {
+            for (int h = tid; h < nh; h += YM_CANON)
+                if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
         }
-    } else {
-        for (int h = tid; h < nh; h += NT)
-            if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
     }
     block_sum_vec<5>(acc, scratch);
     if (acc[4] > 0.0) {
@@ -1589,7 +1601,7 @@ __device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b
     const double dx = mean[0] - cxw, dy = mean[1] - cyw;
     if (!(best < YM_KT_TOLERANCE)) {
         const double *probs = a.probs + (size_t)b * a.probs_stride;
-        for (int c = tid; c < nxy; c += NT) {
+        for (int c = tid; c < nxy && tid < YM_CANON; c += YM_CANON) {
             const int iy = c / nx, ix = c - iy * nx;
             const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
             const double response = probs[c];
@@ -1787,7 +1799,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         for (int k = tid; k < nt; k += NT) s_asum[k] = 0u;
         best = block_reduce(lb, OpMaxD(), -1.0, scratch);
         double acc[5] = {0, 0, 0, 0, 0};
-        for (int h = tid; h < nh; h += NT)
+        for (int h = tid; h < nh && tid < YM_CANON; h += YM_CANON)
             if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
         block_sum_vec<5>(acc, scratch);
         if (acc[4] > 0.0) {
@@ -1867,6 +1879,186 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         if (a.host_out) a.host_out[b] = st;
     }
     YM_STAMP(a, 19);
+}
+
+// ---- K6 finish, one block per item (batches): everything fine_kernel + final_kernel do, without the eleven-fold
+// recomputation of the coarse arg-max that one-block-per-fine-angle costs.  Wave w scores the 3x3 fine lattice for
+// fine angles w, w + 16, ...; the fine sums stay in LDS.  grid (B), 1024 threads.
+#define YM_FINISH1_THREADS 1024
+__global__ __launch_bounds__(YM_FINISH1_THREADS) void finish_kernel(FinishArgs a) {
+    constexpr int NT = YM_FINISH1_THREADS, NW = NT / 64;
+    __shared__ double scratch[16 * 5];
+    __shared__ int s_list[NT];
+    __shared__ int s_nlist;
+    __shared__ double2 s_cs[YM_MAX_FINE_NT];
+    __shared__ int s_cx[64], s_cy[64];
+    __shared__ unsigned s_sum[YM_MAX_FINE_HYP];
+    __shared__ double s_fresp[YM_MAX_FINE_HYP];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    YmItemState &st = a.states[b];
+    const int nq = st.nq;
+    if (nq == 0) {
+        // MatchScan: "scan has no readings; cannot do scan matching" -> pose, maximum covariance, 0
+        if (tid == 0) {
+            for (int i = 0; i < 9; i++) st.cov[i] = 0.0;
+            st.cov[0] = YM_MAX_VARIANCE; st.cov[4] = YM_MAX_VARIANCE;
+            st.cov[8] = 4 * (a.lc.angle_res * a.lc.angle_res);
+            for (int i = 0; i < 3; i++) { st.mean[i] = st.pose[i]; st.center[i] = st.pose[i]; }
+            st.response = 0.0;
+            st.coarse_response = 1.0; // nothing to retry with a wider angle
+            if (a.host_out) a.host_out[b] = st;
+        }
+        return;
+    }
+    const double pose[3] = {st.pose[0], st.pose[1], st.pose[2]};
+    const double off_x = st.off_x, off_y = st.off_y;
+    double mean[3], cov[9];
+    int status = 0;
+    double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride, a.blockmax + (size_t)b * a.n_blocks,
+                                           a.n_blocks, pose, mean, &status, scratch, s_list, &s_nlist);
+    positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
+    const double coarse_response = best > 1.0 ? 1.0 : best;
+    const double cmean[3] = {mean[0], mean[1], mean[2]};
+    double response = coarse_response;
+    const uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
+    const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+
+    if (a.refine) { // ------------------------------------------------ fine pass (CorrelateScan, doingFineMatch)
+        const YmLattice &L = a.lf;
+        const int nx = L.nx, ny = L.ny, nt = L.nt, nxy = nx * ny, nh = nxy * nt;
+        const double cxw = cmean[0], cyw = cmean[1], ct = cmean[2];
+        const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
+        for (int k = tid; k < nt; k += NT) {
+            const double angle = start_angle + k * L.angle_res;
+            s_cs[k] = make_double2(cos(angle), sin(angle));
+        }
+        for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(cxw, start_x, i, L.step_x, off_x, a.g);
+        for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g);
+        for (int h = tid; h < nh; h += NT) s_sum[h] = 0u;
+        __syncthreads();
+        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
+                            s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
+        for (int k = wave; k < nt; k += NW) { // wave-uniform
+            const double cosine = s_cs[k].x, sine = s_cs[k].y;
+            if (block3) {
+                // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its beam as three
+                // 4-byte words
+                const uint32_t base0 = (uint32_t)(s_cy[0] * a.g.pitch + s_cx[0]);
+                unsigned acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = lane; i < nq; i += 4 * 64) {
+                    uint32_t w[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int ii = i + u * 64;
+                        const int off = ii < nq ? lookup_offset(ql[ii], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch) : 0;
+                        const uint32_t idx = base0 + (uint32_t)off;
+#pragma unroll
+                        for (int r = 0; r < 3; r++) __builtin_memcpy(&w[u][r], grid + (uint32_t)(idx + r * a.g.pitch), 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t m = (i + u * 64) < nq ? 0xffu : 0u;
+#pragma unroll
+                        for (int r = 0; r < 3; r++) {
+                            acc[3 * r] += w[u][r] & m; acc[3 * r + 1] += (w[u][r] >> 8) & m; acc[3 * r + 2] += (w[u][r] >> 16) & m;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 9; j++) acc[j] = wave_reduce(acc[j], OpAddU());
+                if (lane == 0)
+#pragma unroll
+                    for (int j = 0; j < 9; j++) s_sum[k * 9 + j] = acc[j];
+            } else {
+                // generic lattice: per beam, every (iy, ix) cell
+                for (int i = lane; i < nq; i += 64) {
+                    const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+                    for (int c = 0; c < nxy; c++) {
+                        const int iy = c / nx, ix = c - iy * nx;
+                        const unsigned idx = (unsigned)(s_cy[iy] * a.g.pitch + s_cx[ix] + off);
+                        if (idx < limit) atomicAdd(&s_sum[k * nxy + c], (unsigned)grid[idx]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride; // kept for the parity tests
+        double lb = -1.0;
+        for (int h = tid; h < nh; h += NT) {
+            const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+            const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+            const double r = hyp_response(a.g, L.penalize, s_sum[h], nq, x * x + y * y, start_angle + k * L.angle_res, ct);
+            s_fresp[h] = r;
+            fs[h] = s_sum[h];
+            lb = r > lb ? r : lb;
+        }
+        best = block_reduce(lb, OpMaxD(), -1.0, scratch);
+        double acc[5] = {0, 0, 0, 0, 0};
+        for (int h = tid; h < nh && tid < YM_CANON; h += YM_CANON)
+            if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
+        block_sum_vec<5>(acc, scratch);
+        if (acc[4] > 0.0) {
+            const double cnt = acc[4];
+            mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
+            mean[2] = atan2(acc[3] / cnt, acc[2] / cnt);
+        } else {
+            status = -5;
+        }
+        // ComputeAngularCovariance: GetResponse(angle k, cell of the mean pose) with the fine pass's lookup offsets is the
+        // fine pass's own sum whenever that cell is a cell of the fine lattice (always, unless fp rounding puts the
+        // tie mean outside); otherwise gather again.
+        const double best_angle = kt_normalize_angle_difference(mean[2], ct);
+        const int gx = world_to_grid(mean[0], off_x, a.g.scale) + a.g.border - a.g.win_origin;
+        const int gy = world_to_grid(mean[1], off_y, a.g.scale) + a.g.border - a.g.win_origin;
+        int hit_x = -1, hit_y = -1;
+        for (int i = 0; i < nx; i++) if (s_cx[i] == gx) hit_x = i;
+        for (int i = 0; i < ny; i++) if (s_cy[i] == gy) hit_y = i;
+        unsigned *s_asum = reinterpret_cast<unsigned *>(s_list); // free by now
+        __syncthreads();
+        if (hit_x >= 0 && hit_y >= 0) {
+            for (int k = tid; k < nt; k += NT) s_asum[k] = s_sum[k * nxy + hit_y * nx + hit_x];
+        } else {
+            const int base = gy * a.g.pitch + gx;
+            for (int k = wave; k < nt; k += NW) {
+                const double cosine = s_cs[k].x, sine = s_cs[k].y;
+                unsigned v = 0;
+                for (int i = lane; i < nq; i += 64) {
+                    const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch));
+                    v += idx < limit ? grid[idx] : 0u;
+                }
+                v = wave_reduce(v, OpAddU());
+                if (lane == 0) s_asum[k] = v;
+            }
+        }
+        __syncthreads();
+        double norm = 0.0, accv = 0.0;
+        for (int k = 0; k < nt; k++) {
+            const double angle = start_angle + k * L.angle_res;
+            double r = (double)s_asum[k];
+            r /= (double)(nq * YM_OCCUPIED);
+            if (r >= (best - 0.1)) {
+                norm += r;
+                accv += ((angle - best_angle) * (angle - best_angle)) * r;
+            }
+        }
+        if (norm > YM_KT_TOLERANCE) {
+            if (accv < YM_KT_TOLERANCE) accv = L.angle_res * L.angle_res;
+            accv /= norm;
+        } else {
+            accv = 1000 * (L.angle_res * L.angle_res);
+        }
+        cov[8] = accv;
+        response = best > 1.0 ? 1.0 : best;
+    }
+    if (tid == 0) {
+        for (int i = 0; i < 9; i++) st.cov[i] = cov[i];
+        for (int i = 0; i < 3; i++) { st.mean[i] = mean[i]; st.center[i] = mean[i]; }
+        st.response = response;
+        st.coarse_response = coarse_response;
+        st.status = status;
+        if (a.host_out) a.host_out[b] = st;
+    }
 }
 
 // ================================================================== K7 arg-best over the items of a call
