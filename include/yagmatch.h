@@ -169,7 +169,10 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
  * out[(slot*max_n + i)*2 + {0,1}] = wx, wy  or (INT32_MIN, INT32_MIN) for filtered points */
 int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int32_t *max_n);
 
-/* development aid: option 0 = coarse correlate kernel form (0 global loads = default, 1 experimental LDS staging) */
+/* development aid.  option 0: coarse correlate kernel form (0 = global loads, default; 1 = experimental LDS staging);
+ * 2: rasterise every tile of the window; 3: beams in flight per lane in the correlate kernel (16 / 32);
+ * 4: extra LDS bytes per correlate block; 5: beam chunks per angle; 6: finish stage (0 = by batch size,
+ * 1 = fine + final kernels, 2 = one-block finish kernel). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.
