@@ -51,6 +51,27 @@ def _result(r):
                              meta)
 
 
+# numpy view of an array of ym_result (include/yagmatch.h): converting a batch result field by field through ctypes
+# costs ~8 us per chain, more than the GPU spends on it
+_RESULT_DTYPE = np.dtype([("response", "<f8"), ("pose", "<f8", (3,)), ("cov", "<f8", (9,)), ("coarse_response", "<f8"),
+                          ("hypotheses", "<i8"), ("coarse_dims", "<i4", (3,)), ("fine_dims", "<i4", (3,)),
+                          ("n_query_points", "<i4"), ("expansions", "<i4"), ("status", "<i4"), ("reserved", "<i4")])
+assert _RESULT_DTYPE.itemsize == C.sizeof(_capi.YmResult)
+
+
+def _results(per):
+    """list of ScanMatcherResult from a ctypes array of YmResult, converted column-wise"""
+    a = np.frombuffer(per, dtype=_RESULT_DTYPE)
+    resp, pose, cov = a["response"].tolist(), a["pose"].tolist(), a["cov"].reshape(-1, 3, 3).tolist()
+    cresp, hyp = a["coarse_response"].tolist(), a["hypotheses"].tolist()
+    cd, fd = a["coarse_dims"].tolist(), a["fine_dims"].tolist()
+    nq, ex, stt = a["n_query_points"].tolist(), a["expansions"].tolist(), a["status"].tolist()
+    return [ScanMatcherResult(resp[i], cov[i], Transform(pose[i][0], pose[i][1], 0.0, pose[i][2]),
+                              {"coarse_response": cresp[i], "hypotheses": hyp[i], "coarse_dims": tuple(cd[i]),
+                               "fine_dims": tuple(fd[i]), "n_query_points": nq[i], "expansions": ex[i], "status": stt[i]})
+            for i in range(len(resp))]
+
+
 class ScanMatcher(object):
     """MI355X correlative scan matcher behind yag-slam's matcher plugin surface."""
 
@@ -81,13 +102,19 @@ class ScanMatcher(object):
 
     # ---- handles -------------------------------------------------------------------------
     def _native(self, scan):
-        """ym_scan* of a scan with the CURRENT corrected pose (resident if it is our LocalizedRangeScan)."""
+        """ym_scan* of a resident scan (our LocalizedRangeScan), else None.  Like the reference's C++ twin
+        (/root/reference/yag_slam/models.py:67-75) the device twin follows the pose through the `corrected_pose`
+        setter, so nothing is re-sent here."""
         if isinstance(scan, LocalizedRangeScan):
-            h = scan.native(self.device)
+            return scan.native(self.device)
+        return None
+
+    def _push_pose(self, scan):
+        """re-send the current corrected pose (for poses mutated in place, behind the setter's back)"""
+        h = self._native(scan)
+        if h is not None:
             x, y, t = _pose_of(scan)
             _capi.check(self._lib.ym_scan_set_pose(h, x, y, t))
-            return h
-        return None
 
     # ---- the plugin call -------------------------------------------------------------------
     def match_scan(self, query, base_scans, penalty=True, do_fine=False):
@@ -115,18 +142,28 @@ class ScanMatcher(object):
             flat.extend(ch)
             offs.append(len(flat))
         hq = self._require_native(query)
-        hs = (C.c_void_p * max(1, len(flat)))(*[self._require_native(s) for s in flat])
+        hs = (C.c_void_p * max(1, len(flat)))(*self._handles(flat))
         co = (C.c_int32 * len(offs))(*offs)
         per = (_capi.YmResult * len(chains))()
         best = _capi.YmResult()
         bi = C.c_int32(-1)
         _capi.check(self._lib.ym_match_batch(self._m, hq, hs, co, len(chains), int(bool(penalty)), int(bool(do_fine)),
                                              per, C.byref(best), C.byref(bi)))
-        return [_result(r) for r in per], int(bi.value)
+        return _results(per), int(bi.value)
 
     def make_batch(self, query, chains):
         """Reusable (query, chains) batch for the pipelined loop-closure path."""
         return MatchBatch(self, query, chains)
+
+    def _handles(self, scans):
+        """ym_scan* of every scan; the twins that already live on this device are taken without a call"""
+        dev, out = self.device, []
+        for s in scans:
+            h = getattr(s, "_native", None)
+            if h is None or getattr(s, "_native_device", None) != dev or not isinstance(s, LocalizedRangeScan):
+                h = self._require_native(s)
+            out.append(h)
+        return out
 
     def _require_native(self, scan):
         h = self._native(scan)
@@ -137,7 +174,7 @@ class ScanMatcher(object):
     # ---- pipelined form ----------------------------------------------------------------------
     def match_scan_async(self, query, base_scans, penalty=True, do_fine=False, slot=0):
         hq = self._require_native(query)
-        arr = (C.c_void_p * max(1, len(base_scans)))(*[self._require_native(s) for s in base_scans])
+        arr = (C.c_void_p * max(1, len(base_scans)))(*self._handles(base_scans))
         _capi.check(self._lib.ym_match_scans_async(self._m, hq, arr, len(base_scans), int(bool(penalty)),
                                                    int(bool(do_fine)), int(slot)))
 
@@ -215,7 +252,7 @@ class MatchBatch(object):
             offs.append(len(flat))
         self._flat = flat
         hq = matcher._require_native(query)
-        hs = (C.c_void_p * max(1, len(flat)))(*[matcher._require_native(s) for s in flat])
+        hs = (C.c_void_p * max(1, len(flat)))(*matcher._handles(flat))
         co = (C.c_int32 * len(offs))(*offs)
         self._h = matcher._lib.ym_batch_create(matcher._m, hq, hs, co, len(self.chains))
         if not self._h:
@@ -233,7 +270,7 @@ class MatchBatch(object):
     def push_poses(self):
         """Write the scans' current corrected poses through to their device twins."""
         for s in [self.query] + self._flat:
-            self.m._native(s)
+            self.m._push_pose(s)
 
     def run_async(self, penalty=False, do_fine=False, slot=0, chain_id_base=0, dev_best_out=None):
         _capi.check(self.m._lib.ym_batch_run_async(self.m._m, self._h, int(bool(penalty)), int(bool(do_fine)), int(slot),
@@ -244,7 +281,7 @@ class MatchBatch(object):
         best = _capi.YmResult()
         bi = C.c_int32(-1)
         _capi.check(self.m._lib.ym_batch_wait(self.m._m, int(slot), per, C.byref(best), C.byref(bi)))
-        return ([_result(r) for r in per] if per_chain else None), _result(best), int(bi.value)
+        return (_results(per) if per_chain else None), _result(best), int(bi.value)
 
 
 # names the reference exports (scan_matching.py:32,224)
