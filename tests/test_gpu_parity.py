@@ -292,6 +292,21 @@ def test_order_dependent_smear_boundary():
     compare(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0), q, base[:4], True, True)
 
 
+def test_order_dependent_smear_in_a_batch():
+    # the select kernel, the tile work list and the one-block finish kernel together: every item of a batch of 9
+    # equals its single call when smear_deviation = 10 * resolution
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans(range_threshold=12.0)
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    m = ScanMatcher(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0))
+    chains = [nb[:4], nb[2:6], nb[:2], nb[5:], nb[1:4], nb[:4][::-1], nb[3:4], nb[4:9], nb[:6]]
+    per, best = m.match_scan_batch(nq, chains, True, True)
+    for ch, a in zip(chains, per):
+        b = m.match_scan(nq, ch, True, True)
+        assert a.response == b.response and a.covariance == b.covariance
+        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+
+
 def test_stress_config_full_lattice():
     # BASELINE configs[4]: search_size=2.0 resolution=0.005 coarse_angle_offset=0.785 (201x201x46 + 99
     # hypotheses); every one of the 1.86 M integer sums is compared with the oracle
