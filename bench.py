@@ -128,15 +128,20 @@ def main():
     batch = m.make_batch(query, chains)
     nslots = 8  # result slots cycled by the pipelined loop (all touched during warm-up)
     records = torch.zeros((nslots, ymdist.RECORD), dtype=torch.float64, device="cuda")
-    gathered = torch.zeros(world * ymdist.RECORD, dtype=torch.float64, device="cuda")
+    gathered = torch.zeros((nslots, world * ymdist.RECORD), dtype=torch.float64, device="cuda")
+    works = [None] * nslots
 
     def step(i):
         s = i % nslots
         if i >= nslots:
             batch.wait(s, per_chain=False)  # recycle the slot (long since finished)
+        if works[s] is not None:
+            works[s].wait()                 # its gathered records are about to be overwritten
         batch.run_async(True, True, slot=s, chain_id_base=rank * args.batch, dev_best_out=records[s].data_ptr())
         if dist is not None:
-            dist.all_gather_into_tensor(gathered, records[s])
+            # cross-rank arg-max payload: one 64-byte record per rank.  Asynchronous: RCCL's stream waits for this
+            # step's record, the launch stream goes straight on to the next step
+            works[s] = dist.all_gather_into_tensor(gathered[s], records[s], async_op=True)
 
     def drain(n):
         for s in range(min(n, nslots)):
@@ -165,6 +170,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     drain(args.steps)
+    if dist is not None:  # the last step's gather carries this rank's own record in its place
+        s_last = (args.steps - 1) % nslots
+        assert torch.equal(gathered[s_last].view(world, ymdist.RECORD)[rank], records[s_last])
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
