@@ -230,7 +230,7 @@ def main():
                 "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run item
             cb = cpu_baseline()
             line["cpu_baseline"] = {
                 "value": cb["single"]["hyp_per_s"], "unit": "hypotheses/s", "cores": 1, "kind": "port",
