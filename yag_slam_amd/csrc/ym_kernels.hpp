@@ -199,7 +199,6 @@ struct PrepareArgs {
 template <int NT>
 __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ int wave_counts[NT / 64];
     YM_STAMP(a, 0);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -227,18 +226,39 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     const double px = (is_query && yag) ? 0.0 : sr.pose[0];
     const double py = (is_query && yag) ? 0.0 : sr.pose[1];
     const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
+    // One barrier for the whole scan instead of two per NT beams: pass 1 counts the valid beams of every (chunk of NT
+    // beams, wave) by ballot, pass 2 re-reads the ranges (L1) and places each valid beam after everything before it.
+    constexpr int NW = NT / 64;
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * NW];
+    const int lane_ = tid & 63, wave_ = tid >> 6;
+    const int per = (sr.n + NT - 1) / NT; // chunks of NT beams
+    auto valid = [&](int i, double &r) {
+        r = 0.0;
+        if (i >= sr.n) return false;
+        r = sr.ranges[i];
+        return yag ? !(r > sr.range_threshold || isnan(r)) : (r >= sr.min_range && r <= sr.range_threshold);
+    };
+    for (int k = 0; k < per; k++) {
+        double r;
+        const unsigned long long m = __ballot(valid(k * NT + tid, r));
+        if (lane_ == 0) s_cnt[k * NW + wave_] = __popcll(m);
+    }
+    __syncthreads();
     int running = 0;
-    for (int c0 = 0; c0 < sr.n; c0 += NT) {
-        const int i = c0 + tid;
-        double r = 0.0;
-        bool ok = false;
-        if (i < sr.n) {
-            r = sr.ranges[i];
-            ok = yag ? !(r > sr.range_threshold || isnan(r)) : (r >= sr.min_range && r <= sr.range_threshold);
+    for (int k = 0; k < per; k++) {
+        const int i = k * NT + tid;
+        double r;
+        const bool ok = valid(i, r);
+        const unsigned long long m = __ballot(ok);
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int c = s_cnt[k * NW + w];
+            before += w < wave_ ? c : 0;
+            total += c;
         }
-        int total;
-        const int pos = running + block_scan_flag(ok, &total, wave_counts);
         if (ok) {
+            const int pos = running + before + __popcll(m & ((1ull << lane_) - 1ull));
             const double angle = pt + sr.min_angle + i * sr.angle_inc;
             sx[pos] = px + r * cos(angle);
             sy[pos] = py + r * sin(angle);
