@@ -54,6 +54,17 @@ def traffic_bytes(batch):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds=6.0):
     """The CPU oracle (karto semantics, -O3 -march=native on this host) on the same cfg2 problem."""
     from oracle import oracle as orc
@@ -236,6 +247,7 @@ def main():
                 "value": cb["single"]["hyp_per_s"], "unit": "hypotheses/s", "cores": 1, "kind": "port",
                 "sample": "%d cfg2 matches (coarse+fine, penalty) in %.1f s, oracle/ym_oracle.c karto semantics, "
                           "-O3 -march=native, 1 thread" % (cb["single"]["matches"], cb["single"]["seconds"]),
+                "host": {"cpu_model": cpu_model(), "logical_cpus": os.cpu_count() or 1},
                 "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
                               "sample": "%d matches in %.1f s, OpenMP over the coarse lattice, host has %d cores" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
             }
