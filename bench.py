@@ -198,6 +198,28 @@ def main():
     call_ms, call_n = m.profile_read(2)
     m.profile(False)
 
+    # the same problem as ONE match_scan call (BASELINE configs[1] as the reference runs it: no batching), for reference
+    single = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        n1 = 300
+        for _ in range(20):
+            m.match_scan(query, chains[0], True, True)
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            m.match_scan(query, chains[0], True, True)
+        sync_s = (time.perf_counter() - t1) / n1
+        t1 = time.perf_counter()
+        for i in range(n1):
+            if i >= 8:
+                m.wait(i % 8)
+            m.match_scan_async(query, chains[0], True, True, slot=i % 8)
+        for sl in range(8):
+            m.wait(sl)
+        pipe_s = (time.perf_counter() - t1) / n1
+        single = {"sync_us_per_match": sync_s * 1e6, "pipelined_us_per_match": pipe_s * 1e6,
+                  "hypotheses_per_s_sync": hyp_per_match / sync_s, "hypotheses_per_s_pipelined": hyp_per_match / pipe_s}
+
     if rank == 0:
         nq = per[0].meta["n_query_points"]
         cd = per[0].meta["coarse_dims"]
@@ -227,6 +249,7 @@ def main():
                 "hypotheses_per_match": hyp_per_match,
                 "scan_matches_per_s": args.batch * world * args.steps / dt,
                 "collective": "all_gather of one 64-byte best record per rank per step" if world > 1 else "none",
+                "single_match": single,
             },
             "roofline": {
                 "bound": "hbm",
