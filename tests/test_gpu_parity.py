@@ -404,3 +404,52 @@ def test_against_karto_wheel_if_present():
     assert abs(r.response - ref.response) <= 1e-4
     assert abs(r.best_pose.x - ref.best_pose.x) <= 1e-3 and abs(r.best_pose.y - ref.best_pose.y) <= 1e-3
     assert abs(r.best_pose.euler[-1] - ref.best_pose.yaw) <= 1e-3
+
+
+def test_c_abi_error_behaviour():
+    """The boundary never throws: bad calls return a negative YM_ERR_* and leave a message (include/yagmatch.h)."""
+    import ctypes as C
+    from yag_slam_amd import _capi
+    from yag_slam_amd.scan_matching import ScanMatcher
+    L = _capi.lib()
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    m = ScanMatcher()
+    res = _capi.YmResult()
+    # collecting a slot nothing was submitted to
+    assert L.ym_wait(m._m, 3, C.byref(res)) == -6 and b"slot" in L.ym_last_error()
+    assert L.ym_wait(m._m, 10 ** 6, C.byref(res)) == -1
+    # a slot cannot be reused before it is collected
+    m.match_scan_async(nq, nb, True, True, slot=1)
+    arr = (C.c_void_p * len(nb))(*[s.native(0) for s in nb])
+    assert L.ym_match_scans_async(m._m, nq.native(0), arr, len(nb), 1, 1, 1) == -6
+    r1 = m.wait(1)
+    assert r1.response == m.match_scan(nq, nb, True, True).response
+    # null arguments
+    assert L.ym_match_scans(m._m, None, arr, len(nb), 1, 1, C.byref(res)) == -1
+    assert L.ym_match_scans(m._m, nq.native(0), arr, len(nb), 1, 1, None) == -1
+    assert L.ym_match_scans(None, nq.native(0), arr, len(nb), 1, 1, C.byref(res)) == -1
+    assert L.ym_debug_option(m._m, 99, 0) == -1
+    # no base scans: Karto correlates against an empty grid -> response 0 after the expansion retries, no error
+    assert L.ym_match_scans(m._m, nq.native(0), arr, 0, 1, 1, C.byref(res)) == 0
+    assert res.response == 0.0 and res.expansions == 3 and res.status == 0
+    # an empty batch is a valid request with nothing in it
+    co = (C.c_int32 * 1)(0)
+    bi = C.c_int32(7)
+    best = _capi.YmResult()
+    rc = L.ym_match_batch(m._m, nq.native(0), arr, co, 0, 1, 1, None, C.byref(best), C.byref(bi))
+    assert rc in (0, -1)
+    if rc == 0:
+        assert bi.value == -1
+    # config and scan accessors round-trip
+    cfg = _capi.YmConfig()
+    assert L.ym_get_config(m._m, C.byref(cfg)) == 0 and cfg.search_size == 0.5 and cfg.resolution == 0.01
+    pose = (C.c_double * 3)()
+    h = nb[0].native(0)
+    assert L.ym_scan_set_pose(h, 1.25, -2.5, 0.75) == 0 and L.ym_scan_get_pose(h, pose) == 0
+    assert tuple(pose) == (1.25, -2.5, 0.75) and L.ym_scan_size(h) == 1081
+    p = nb[0].corrected_pose
+    assert L.ym_scan_set_pose(h, p.x, p.y, p.euler[-1]) == 0
+    # the introspection calls refuse an item the last call did not have
+    info = _capi.YmGridInfo()
+    assert L.ym_debug_grid_info(m._m, 5, C.byref(info)) == -1

@@ -327,3 +327,15 @@ def test_mapfile_round_trip_of_a_mapper(tmp_path):
         assert np.array_equal(a.ranges, b.ranges)
         assert abs(a.corrected_pose.euler[-1] - b.corrected_pose.euler[-1]) < 1e-15
         assert (a.corrected_pose.x, a.corrected_pose.y) == (b.corrected_pose.x, b.corrected_pose.y)
+
+
+def test_product_never_touches_the_oracle():
+    # the oracle is test infrastructure: nothing under yag_slam_amd/ (Python or HIP) may import, link or call it
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yag_slam_amd")
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|ym_oracle|orc_[a-z_]+\s*\(|libym_oracle)")
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
+                text = open(os.path.join(d, f), errors="replace").read()
+                assert not pat.search(text), os.path.join(d, f)
