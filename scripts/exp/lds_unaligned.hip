@@ -1,3 +1,4 @@
+// build: hipcc -O2 --offload-arch=gfx950 -o scripts/exp/lds_unaligned scripts/exp/lds_unaligned.hip
 // experiment: does ds_read_b128 honour 4-byte-aligned (not 16-byte-aligned) LDS addresses on gfx950, and what does it cost?
 #include <hip/hip_runtime.h>
 #include <cstdio>
