@@ -272,7 +272,7 @@ def main():
                           "-O3 -march=native, 1 thread" % (cb["single"]["matches"], cb["single"]["seconds"]),
                 "host": {"cpu_model": cpu_model(), "logical_cpus": os.cpu_count() or 1},
                 "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
-                              "sample": "%d matches in %.1f s, OpenMP over the coarse lattice, host has %d cores" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
+                              "sample": "%d matches in %.1f s, OpenMP over the coarse lattice (grid clear and rasterisation stay serial, as in Karto), host has %d cores" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
             }
         print(json.dumps(line))
     if dist is not None:
