@@ -453,3 +453,46 @@ def test_c_abi_error_behaviour():
     # the introspection calls refuse an item the last call did not have
     info = _capi.YmGridInfo()
     assert L.ym_debug_grid_info(m._m, 5, C.byref(info)) == -1
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_sweep_against_oracle(seed):
+    """Seeded random scenes, sensors, poses and matcher configs: grid bytes and both integer sum volumes bit-exact,
+    response / pose / covariance to 1e-12 / 1e-9 -- far-from-origin and negative coordinates, rotated chains, short
+    scans, dirty readings, every resolution the reference's configs use."""
+    from yag_slam_amd import synth
+    rng = np.random.default_rng(9000 + seed)
+    scene = synth.Scene(width=float(rng.uniform(6, 10)), height=float(rng.uniform(5, 8)), n_boxes=int(rng.integers(2, 8)),
+                        seed=int(rng.integers(1, 10 ** 6)))
+    res = float(rng.choice([0.01, 0.02, 0.05]))
+    cfg = dict(resolution=res,
+               search_size=float(rng.choice([10, 16, 24, 40])) * res,
+               smear_deviation=float(rng.choice([1.0, 2.5, 5.0, 8.0])) * res,
+               coarse_search_angle_offset=float(rng.choice([0.1745, 0.349, 0.5])),
+               coarse_angle_resolution=float(rng.choice([0.0349, 0.0175, 0.05])),
+               range_threshold=float(rng.choice([6.0, 12.0, 20.0])),
+               use_response_expansion=bool(rng.integers(0, 2)))
+    n_beams = int(rng.choice([181, 360, 721, 1081]))
+    fov = float(rng.choice([np.pi, 1.5 * np.pi, 2 * np.pi * (1 - 1.0 / n_beams)]))
+    min_angle, inc = -fov / 2, fov / (n_beams - 1)
+    shift = np.array([float(rng.choice([0.0, -37.3, 1250.0])), float(rng.choice([0.0, 512.25, -88.0]))])
+    x0, y0 = rng.uniform(1.5, scene.width - 1.5), rng.uniform(1.5, scene.height - 1.5)
+    th0 = float(rng.uniform(-np.pi, np.pi))
+    n_base = int(rng.integers(1, 11))
+    dirty = bool(rng.integers(0, 2))
+
+    def scan(pose, idx, noise_pose=(0, 0, 0)):
+        r = scene.scan_ranges(pose, index=idx, dirty=dirty, n_beams=n_beams, min_angle=min_angle, inc=inc)
+        p = (pose[0] + shift[0] + noise_pose[0], pose[1] + shift[1] + noise_pose[1], pose[2] + noise_pose[2])
+        return PlainScan(r, min_angle, inc, 0.05, cfg["range_threshold"], p)
+
+    base = []
+    for i in range(n_base):
+        px = min(max(x0 + 0.08 * i * np.cos(th0), 1.2), scene.width - 1.2)
+        py = min(max(y0 + 0.08 * i * np.sin(th0), 1.2), scene.height - 1.2)
+        base.append(scan((px, py, th0 + 0.02 * i), 700 + i))
+    qx = min(max(x0 + 0.08 * n_base * np.cos(th0), 1.2), scene.width - 1.2)
+    qy = min(max(y0 + 0.08 * n_base * np.sin(th0), 1.2), scene.height - 1.2)
+    err = (float(rng.normal(0, 0.2 * cfg["search_size"])), float(rng.normal(0, 0.2 * cfg["search_size"])), float(rng.normal(0, 0.05)))
+    query = scan((qx, qy, th0 + 0.02 * n_base), 900, noise_pose=err)
+    compare(cfg, query, base, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
