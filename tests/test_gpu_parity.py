@@ -455,11 +455,8 @@ def test_c_abi_error_behaviour():
     assert L.ym_debug_grid_info(m._m, 5, C.byref(info)) == -1
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
-def test_random_sweep_against_oracle(seed):
-    """Seeded random scenes, sensors, poses and matcher configs: grid bytes and both integer sum volumes bit-exact,
-    response / pose / covariance to 1e-12 / 1e-9 -- far-from-origin and negative coordinates, rotated chains, short
-    scans, dirty readings, every resolution the reference's configs use."""
+def _random_case(seed):
+    """seeded random scene, sensor, poses and matcher config -> (cfg, query, base scans, penalty, fine)"""
     from yag_slam_amd import synth
     rng = np.random.default_rng(9000 + seed)
     scene = synth.Scene(width=float(rng.uniform(6, 10)), height=float(rng.uniform(5, 8)), n_boxes=int(rng.integers(2, 8)),
@@ -495,4 +492,36 @@ def test_random_sweep_against_oracle(seed):
     qy = min(max(y0 + 0.08 * n_base * np.sin(th0), 1.2), scene.height - 1.2)
     err = (float(rng.normal(0, 0.2 * cfg["search_size"])), float(rng.normal(0, 0.2 * cfg["search_size"])), float(rng.normal(0, 0.05)))
     query = scan((qx, qy, th0 + 0.02 * n_base), 900, noise_pose=err)
-    compare(cfg, query, base, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    return cfg, query, base, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), rng
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_sweep_against_oracle(seed):
+    """Seeded random scenes, sensors, poses and matcher configs: grid bytes and both integer sum volumes bit-exact,
+    response / pose / covariance to 1e-12 / 1e-9 -- far-from-origin and negative coordinates, rotated chains, short
+    scans, dirty readings, every resolution the reference's configs use."""
+    cfg, query, base, pen, fine, _ = _random_case(seed)
+    compare(cfg, query, base, pen, fine)
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102, 103, 104, 105])
+def test_random_batches_equal_single_calls(seed):
+    """the same random cases as batches of 8..12 chains (sub-chains, reversed, empty): the batch kernels (tile work
+    list, 256-thread prepare, one-block finish) give every chain the single call's result, bit for bit"""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    cfg, query, base, pen, fine, rng = _random_case(seed)
+    nq, nb = _mk_native(query), [_mk_native(b) for b in base]
+    chains = []
+    for _ in range(int(rng.integers(8, 13))):
+        kind = int(rng.integers(0, 5))
+        lo = int(rng.integers(0, len(nb)))
+        hi = int(rng.integers(lo, len(nb))) + 1
+        ch = nb[lo:hi]
+        chains.append([] if kind == 0 else ch[::-1] if kind == 1 else ch)
+    m = ScanMatcher(cfg)
+    per, best = m.match_scan_batch(nq, chains, pen, fine)
+    singles = [m.match_scan(nq, ch, pen, fine) for ch in chains]
+    for a, b in zip(per, singles):
+        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+    assert best == int(np.argmax([s.response for s in singles]))
