@@ -1560,28 +1560,41 @@ __device__ __forceinline__ void tie_accumulate(double (&acc)[5], const YmLattice
 template <int NT>
 __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const double *resp, const double *bm,
                                                        int n_blocks, const double pose[3], double mean[3], int *status,
-                                                       double *scratch /* >= 80 */, int *s_list /* NT */, int *s_nlist) {
+                                                       double *scratch /* >= 80 */, int *s_list /* NT */, int *s_tmp /* NT */,
+                                                       int *s_nlist) {
     const int tid = threadIdx.x;
     const int nh = L.nx * L.ny * L.nt;
     const double start_angle = pose[2] - L.angle_off;
     if (tid == 0) *s_nlist = 0;
     double lb = -1.0;
-    for (int i = tid; i < n_blocks; i += NT) { const double v = bm[i]; lb = v > lb ? v : lb; }
-    const double best = block_reduce(lb, OpMaxD(), -1.0, scratch);
-    // score blocks that can hold a hypothesis with DoubleEqual(response, best), in ascending order (ordered
-    // compaction: which thread sums which hypothesis must not depend on a race)
-    int overflow = 0, listed = 0;
-    int *wave_counts = reinterpret_cast<int *>(scratch + 64);
-    for (int i0 = 0; i0 < n_blocks; i0 += NT) {
-        const int i = i0 + tid;
-        const bool hit = i < n_blocks && bm[i] >= best - YM_KT_TOLERANCE;
-        int total;
-        const int at = listed + block_scan_flag(hit, &total, wave_counts);
-        if (hit) { if (at < NT) s_list[at] = i; else overflow = 1; }
-        listed += total;
+    for (int i0 = tid; i0 < n_blocks; i0 += 4 * NT) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = (i0 + u * NT) < n_blocks ? bm[i0 + u * NT] : -1.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) lb = v[u] > lb ? v[u] : lb;
     }
-    if (tid == 0) *s_nlist = listed < NT ? listed : NT;
+    const double best = block_reduce(lb, OpMaxD(), -1.0, scratch);
+    // score blocks that can hold a hypothesis with DoubleEqual(response, best), in ASCENDING order: which thread sums
+    // which hypothesis must not depend on a race.  Unordered compaction by atomics, then every entry finds its
+    // rank among the (few) others.
+    int overflow = 0;
+    for (int i = tid; i < n_blocks; i += NT)
+        if (bm[i] >= best - YM_KT_TOLERANCE) {
+            const int at = atomicAdd(s_nlist, 1);
+            if (at < NT) s_tmp[at] = i; else overflow = 1;
+        }
     overflow = __syncthreads_or(overflow);
+    if (!overflow) {
+        const int n = *s_nlist;
+        if (tid < n) {
+            const int mine = s_tmp[tid];
+            int rank = 0;
+            for (int j = 0; j < n; j++) rank += s_tmp[j] < mine ? 1 : 0;
+            s_list[rank] = mine;
+        }
+        __syncthreads();
+    }
     double acc[5] = {0, 0, 0, 0, 0};
     if (tid < YM_CANON) {
         if (!overflow) {
@@ -1621,15 +1634,23 @@ __device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b
     const double dx = mean[0] - cxw, dy = mean[1] - cyw;
     if (!(best < YM_KT_TOLERANCE)) {
         const double *probs = a.probs + (size_t)b * a.probs_stride;
-        for (int c = tid; c < nxy && tid < YM_CANON; c += YM_CANON) {
-            const int iy = c / nx, ix = c - iy * nx;
-            const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-            const double response = probs[c];
-            if (response >= (best - 0.1)) {
-                sums[0] += response;
-                sums[1] += ((x - dx) * (x - dx)) * response;
-                sums[2] += ((x - dx) * (y - dy) * response);
-                sums[3] += ((y - dy) * (y - dy)) * response;
+        // eight loads in flight; the additions stay in increasing cell order (the canonical order above)
+        for (int c0 = tid; c0 < nxy && tid < YM_CANON; c0 += 8 * YM_CANON) {
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) pv[u] = (c0 + u * YM_CANON) < nxy ? probs[c0 + u * YM_CANON] : -1.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = c0 + u * YM_CANON;
+                const double response = pv[u];
+                if (c < nxy && response >= (best - 0.1)) {
+                    const int iy = c / nx, ix = c - iy * nx;
+                    const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+                    sums[0] += response;
+                    sums[1] += ((x - dx) * (x - dx)) * response;
+                    sums[2] += ((x - dx) * (y - dy) * response);
+                    sums[3] += ((y - dy) * (y - dy)) * response;
+                }
             }
         }
     }
@@ -1661,7 +1682,7 @@ __device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b
 __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     constexpr int NT = YM_FINE_THREADS;
     __shared__ double scratch[16 * 5];
-    __shared__ int s_list[NT];
+    __shared__ int s_list[NT], s_tmp[NT];
     __shared__ int s_nlist;
     __shared__ double s_cs[2];
     __shared__ int s_cx[64], s_cy[64];
@@ -1679,7 +1700,7 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     int status = 0;
     const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride,
                                                  a.blockmax + (size_t)b * a.n_blocks, a.n_blocks, pose, mean, &status,
-                                                 scratch, s_list, &s_nlist);
+                                                 scratch, s_list, s_tmp, &s_nlist);
     if (k == (a.refine ? a.lf.nt : 0)) { // extra block: coarse result + positional covariance for final_kernel
         double cov[9];
         positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
@@ -1908,7 +1929,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
 __global__ __launch_bounds__(YM_FINISH1_THREADS) void finish_kernel(FinishArgs a) {
     constexpr int NT = YM_FINISH1_THREADS, NW = NT / 64;
     __shared__ double scratch[16 * 5];
-    __shared__ int s_list[NT];
+    __shared__ int s_list[NT], s_tmp[NT];
     __shared__ int s_nlist;
     __shared__ double2 s_cs[YM_MAX_FINE_NT];
     __shared__ int s_cx[64], s_cy[64];
@@ -1935,7 +1956,7 @@ __global__ __launch_bounds__(YM_FINISH1_THREADS) void finish_kernel(FinishArgs a
     double mean[3], cov[9];
     int status = 0;
     double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride, a.blockmax + (size_t)b * a.n_blocks,
-                                           a.n_blocks, pose, mean, &status, scratch, s_list, &s_nlist);
+                                           a.n_blocks, pose, mean, &status, scratch, s_list, s_tmp, &s_nlist);
     positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
     const double coarse_response = best > 1.0 ? 1.0 : best;
     const double cmean[3] = {mean[0], mean[1], mean[2]};
