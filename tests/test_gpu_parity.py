@@ -525,3 +525,43 @@ def test_random_batches_equal_single_calls(seed):
         assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
         assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
     assert best == int(np.argmax([s.response for s in singles]))
+
+
+def test_one_matcher_through_changing_batch_sizes():
+    """The window memory, its 'tile already zero' flags, the dirty rectangle and the tile work list live across calls.
+    One matcher driven through growing / shrinking batches, single calls and moved chains must give what a fresh
+    matcher gives for the same call, bit for bit."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    mk = lambda r, p: PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 20.0, p)
+    far = [[_mk_native(mk(scene.scan_ranges(p, index=800 + 10 * c + i), p)) for i, p in enumerate(ch)]
+           for c, ch in enumerate(synth.chain_poses(8, chain_len=6, scene=scene))]
+    plans = [
+        [nb] * 9,
+        [far[1], far[2], nb[:4]],
+        [far[3]] * 4 + [nb, far[4]] * 4,
+        [nb[5:]],
+        [far[5], far[6], far[7], nb[:2], nb[2:4], nb[4:6], nb[6:8], nb[8:], far[1]],
+        [[]] * 8,
+        [nb] * 16,
+        [far[2]],
+    ]
+    m = ScanMatcher()
+    for step, chains in enumerate(plans):
+        if len(chains) == 1:
+            got = [m.match_scan(nq, chains[0], True, True)]
+        else:
+            got = m.match_scan_batch(nq, chains, True, True)[0]
+        fresh = ScanMatcher()
+        for ch, a in zip(chains, got):
+            b = fresh.match_scan(nq, ch, True, True)
+            assert a.response == b.response and a.covariance == b.covariance, (step, len(ch))
+            assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+        # and the grid of the last item is exactly a fresh raster's
+        g, info = m.debug_grid(len(chains) - 1)
+        fg, finfo = fresh.debug_grid(0)
+        assert np.array_equal(g, fg), (step, int((g != fg).sum()))
+        fresh.close()
