@@ -565,3 +565,40 @@ def test_one_matcher_through_changing_batch_sizes():
         fg, finfo = fresh.debug_grid(0)
         assert np.array_equal(g, fg), (step, int((g != fg).sum()))
         fresh.close()
+
+
+def test_distinct_matchers_in_threads():
+    """include/yagmatch.h: distinct matchers are independent -- four threads, each with its own matcher and scans,
+    matching at the same time, all get the single-threaded answers (ctypes releases the GIL during the calls)."""
+    import threading
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    want = {}
+    m0 = ScanMatcher()
+    nq0, nb0 = _mk_native(q), [_mk_native(b) for b in base]
+    for n in (3, 5, 8, 10):
+        r = m0.match_scan(nq0, nb0[:n], True, True)
+        want[n] = (r.response, r.covariance, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1])
+    errors = []
+
+    def work(n):
+        try:
+            m = ScanMatcher()
+            nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+            for i in range(40):
+                if i % 4 == 3:
+                    r = m.match_scan_batch(nq, [nb[:n]] * 9, True, True)[0][4]
+                else:
+                    r = m.match_scan(nq, nb[:n], True, True)
+                got = (r.response, r.covariance, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1])
+                if got != want[n]:
+                    errors.append((n, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((n, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(n,)) for n in (3, 5, 8, 10)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
