@@ -378,29 +378,59 @@ int prof_collect(ym_matcher *m) {
 }
 
 // ---------------------------------------------------------------- launch one call
-int launch_call(ym_matcher *m, Slot &slot) {
-    Call &call = slot.call;
-    const int B = (int)call.items.size();
-    const int nscans = (int)call.scans.size();
-    if (B <= 0) return set_err(YM_ERR_INVALID, "empty call");
-    HIP_TRY(hipSetDevice(m->device));
-    YmGeom g = m->geom;
+// Everything one call's launches share: sizes, lattices, the device window, how the coarse correlate is cut up,
+// strides, the descriptor, and which tiles the raster covers.  Filled in by the plan_* functions below.
+struct CallPlan {
+    int B = 0, nscans = 0, max_n = 1, max_base = 1;
+    bool yag = false;
+    YmGeom g;
+    YmLattice lc, lf;
+    // device window
+    int tiles_x = 0, tiles_y = 0;
+    size_t grid_stride = 0;
+    // coarse correlate decomposition
+    int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
+    // yagpy lattice bounds
+    int ymaxd = 0, ymaxt = 0;
+    size_t yvol = 0;
+    // strides
+    int nt_stride = 0, dim_stride = 0, score_blocks = 0;
+    size_t sums_c = 0, sums_f = 0, partial_stride = 0;
+    // call descriptor
+    size_t scans_bytes = 0, desc_bytes = 0;
+    bool inline_desc = false;
+    YmScanRef *hs = nullptr;
+    YmItem *hi = nullptr;
+    const YmScanRef *d_scans = nullptr;
+    const YmItem *d_items = nullptr;
+    // raster coverage
+    int launch[4] = {0, 0, -1, -1}, ltx = 0, lty = 0, tile_cap = 1;
+    bool use_tile_list = false;
+    unsigned long long *stamps = nullptr;
+};
 
-    // ---- sizes
-    int max_n = 1, max_base = 1;
+// sizes, lattices (ScanMatcher::MatchScan), the device window, the correlate decomposition, device buffers
+int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
+    Call &call = slot.call;
+    P.B = (int)call.items.size();
+    P.nscans = (int)call.scans.size();
+    if (P.B <= 0) return set_err(YM_ERR_INVALID, "empty call");
+    const int B = P.B;
+    YmGeom &g = P.g;
+    g = m->geom;
     double rq = 0;
     for (const CallItem &it : call.items) {
-        max_base = std::max(max_base, it.base_count);
+        P.max_base = std::max(P.max_base, it.base_count);
         rq = std::max(rq, call.scans[it.query].max_valid);
     }
-    for (const CallScan &s : call.scans) max_n = std::max(max_n, s.n);
+    for (const CallScan &s : call.scans) P.max_n = std::max(P.max_n, s.n);
+    const int max_n = P.max_n, max_base = P.max_base;
     if (max_n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", max_n, YM_MAX_BEAMS);
 
-    const bool yag = g.semantics == YM_SEM_YAGPY;
-    // ---- lattices (ScanMatcher::MatchScan)
+    const bool yag = P.yag = g.semantics == YM_SEM_YAGPY;
     const double coarse_off = yag ? 0.5 * m->cfg.search_size : 0.5 * (g.side - 1) * g.res;
     const double coarse_step = 2 * g.res;
-    YmLattice lc, lf;
+    YmLattice &lc = P.lc, &lf = P.lf;
     if (yag) { // lattices are built on the device from np.arange; the Karto tables stay empty
         std::memset(&lc, 0, sizeof lc);
         std::memset(&lf, 0, sizeof lf);
@@ -423,10 +453,10 @@ int launch_call(ym_matcher *m, Slot &slot) {
     wh = std::min(wh, centre);
     g.win_origin = centre - wh;
     g.win_w = std::min(2 * wh + 1 + (yag ? 1 : 0), g.storage_w - g.win_origin); // even yagpy grids have no centre cell
-    const int tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
-    const int tiles_y = (g.win_w + YM_TILE_H - 1) / YM_TILE_H;
-    g.pitch = tiles_x * YM_TILE_W + 64;
-    const size_t grid_stride = align_up((size_t)g.pitch * g.win_w + 64, 256);
+    P.tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
+    P.tiles_y = (g.win_w + YM_TILE_H - 1) / YM_TILE_H;
+    g.pitch = P.tiles_x * YM_TILE_W + 64;
+    P.grid_stride = align_up((size_t)g.pitch * g.win_w + 64, 256);
     if ((double)g.pitch * g.win_w > 2.0e9) return set_err(YM_ERR_UNSUPPORTED, "correlation window too large");
     if (lf.nx > 64 || lf.ny > 64 || lf.nt > YM_MAX_FINE_NT || (int64_t)lf.nx * lf.ny * lf.nt > YM_MAX_FINE_HYP)
         return set_err(YM_ERR_UNSUPPORTED, "fine lattice %dx%dx%d exceeds the built-in limit", lf.nx, lf.ny, lf.nt);
@@ -434,30 +464,29 @@ int launch_call(ym_matcher *m, Slot &slot) {
         return set_err(YM_ERR_UNSUPPORTED, "%d coarse angles exceed the built-in limit of %d", lc.nt, YM_MAX_COARSE_NT);
 
     // ---- coarse correlate decomposition
-    const int sx = yag ? 2 : (int)kt_round_h(lc.step_x * g.scale);
-    if (sx != 1 && sx != 2) return set_err(YM_ERR_UNSUPPORTED, "coarse lattice step of %d cells", sx);
+    P.sx = yag ? 2 : (int)kt_round_h(lc.step_x * g.scale);
+    if (P.sx != 1 && P.sx != 2) return set_err(YM_ERR_UNSUPPORTED, "coarse lattice step of %d cells", P.sx);
     // yagpy lattice bounds (np.arange lengths are fixed on the device; these only size the buffers)
-    const int ymaxd = yag ? std::max(8, (int)std::ceil(m->cfg.search_size / coarse_step) + 2) : 0;
-    const int ymaxt = yag ? std::max(13, (int)std::ceil(m->cfg.coarse_search_angle_offset / m->cfg.coarse_angle_resolution) + 2) : 0;
-    if (yag && (ymaxd > YM_YAG_MAX_DIM || ymaxt > YM_YAG_MAX_NT))
-        return set_err(YM_ERR_UNSUPPORTED, "yagpy lattice %d x %d x %d exceeds the built-in limit", ymaxd, ymaxd, ymaxt);
-    const size_t yvol = (size_t)ymaxt * ymaxd * ymaxd;
+    P.ymaxd = yag ? std::max(8, (int)std::ceil(m->cfg.search_size / coarse_step) + 2) : 0;
+    P.ymaxt = yag ? std::max(13, (int)std::ceil(m->cfg.coarse_search_angle_offset / m->cfg.coarse_angle_resolution) + 2) : 0;
+    if (yag && (P.ymaxd > YM_YAG_MAX_DIM || P.ymaxt > YM_YAG_MAX_NT))
+        return set_err(YM_ERR_UNSUPPORTED, "yagpy lattice %d x %d x %d exceeds the built-in limit", P.ymaxd, P.ymaxd, P.ymaxt);
+    P.yvol = (size_t)P.ymaxt * P.ymaxd * P.ymaxd;
     const int G = 16;
-    const int ngx = (lc.nx + G - 1) / G;
-    const int nx_pad = ngx * G;
-    const int njobs = lc.ny * ngx;
+    P.ngx = (lc.nx + G - 1) / G;
+    P.nx_pad = P.ngx * G;
+    const int njobs = P.njobs = lc.ny * P.ngx;
     // (measured on MI355X: sharing a block between adjacent angles does not help -- the kernel is bound by
     //  L1 tag lookups per lane, not by line reuse -- so one angle per block)
-    const int tpb = 1;
-    const int jobs_pb = YM_CORR_THREADS / tpb;
-    const int job_blocks = (njobs + jobs_pb - 1) / jobs_pb;
-    const int ktiles = (lc.nt + tpb - 1) / tpb;
+    P.tpb = 1;
+    const int jobs_pb = YM_CORR_THREADS / P.tpb;
+    P.job_blocks = (njobs + jobs_pb - 1) / jobs_pb;
+    P.ktiles = (lc.nt + P.tpb - 1) / P.tpb;
     // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams; a small lattice (one
     // working wave per block) does best with blocks of 64 beams even when the batch alone fills the chip
     // (measured on MI355X, cfg2 x 256, whole step: 3 chunks 1.09 ms, 8 chunks 0.95 ms, 17 chunks 0.91 ms, 23 chunks
     // 0.97 ms; the partial sums are 16-bit)
     const double waves_one_chunk = (double)((njobs + 63) / 64) * lc.nt * B;
-    (void)ktiles;
     int n_chunks = (int)std::ceil(2048.0 / std::max(1.0, waves_one_chunk));
     n_chunks = std::max(1, std::min(n_chunks, (max_n + 31) / 32));
     n_chunks = std::max(n_chunks, (max_n + 511) / 512);
@@ -466,45 +495,53 @@ int launch_call(ym_matcher *m, Slot &slot) {
     int chunk = (max_n + n_chunks - 1) / n_chunks;
     // beams in flight per lane: 32 for the latency-bound single match (one 32-beam chunk per block), else 16
     // (with the items pinned to XCDs 16 beats 32 on the batch: 618 vs 664 us; 48 spills)
-    const int corr_u = m->corr_u > 0 ? m->corr_u : (chunk <= 32 && njobs <= 128 ? 32 : 16);
-    chunk = (chunk + corr_u - 1) / corr_u * corr_u;
-    n_chunks = (max_n + chunk - 1) / chunk;
+    P.corr_u = m->corr_u > 0 ? m->corr_u : (chunk <= 32 && njobs <= 128 ? 32 : 16);
+    chunk = (chunk + P.corr_u - 1) / P.corr_u * P.corr_u;
+    P.chunk = chunk;
+    P.n_chunks = (max_n + chunk - 1) / chunk;
 
-    const int nt_stride = lc.nt;
-    const int dim_stride = std::max(lc.nx, lc.ny);
-    const size_t sums_c = (size_t)lc.nt * lc.ny * lc.nx;
-    const size_t sums_f = (size_t)lf.nt * lf.ny * lf.nx;
-    const size_t partial_stride = (size_t)n_chunks * lc.nt * lc.ny * nx_pad;
-    const int score_blocks = (int)((sums_c + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS);
+    P.nt_stride = lc.nt;
+    P.dim_stride = std::max(lc.nx, lc.ny);
+    P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
+    P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
+    P.partial_stride = (size_t)P.n_chunks * lc.nt * lc.ny * P.nx_pad;
+    P.score_blocks = (int)((P.sums_c + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS);
 
     int rc;
     if ((rc = m->states.ensure(B))) return rc;
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * ((max_n + 63) / 64)))) return rc;
-    if ((rc = m->grid.ensure((size_t)B * grid_stride))) return rc;
-    if ((rc = m->planes.ensure((size_t)B * grid_stride))) return rc;
-    if ((rc = m->ctrig.ensure((size_t)B * nt_stride))) return rc;
+    if ((rc = m->grid.ensure((size_t)B * P.grid_stride))) return rc;
+    if ((rc = m->planes.ensure((size_t)B * P.grid_stride))) return rc;
+    if ((rc = m->ctrig.ensure((size_t)B * P.nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
-    if ((rc = m->hypcell.ensure((size_t)B * 2 * dim_stride))) return rc;
-    if ((rc = m->partial.ensure((size_t)B * partial_stride + 16))) return rc;
-    if ((rc = m->sums.ensure((size_t)B * std::max(sums_c + sums_f, 2 * yvol)))) return rc;
-    if ((rc = m->resp.ensure((size_t)B * std::max(sums_c, yvol)))) return rc;
+    if ((rc = m->hypcell.ensure((size_t)B * 2 * P.dim_stride))) return rc;
+    if ((rc = m->partial.ensure((size_t)B * P.partial_stride + 16))) return rc;
+    if ((rc = m->sums.ensure((size_t)B * std::max(P.sums_c + P.sums_f, 2 * P.yvol)))) return rc;
+    if ((rc = m->resp.ensure((size_t)B * std::max(P.sums_c, P.yvol)))) return rc;
     if (yag) {
         if ((rc = m->yaxes.ensure((size_t)B * 3 * YM_YAG_MAX_DIM))) return rc;
-        if ((rc = m->yrot.ensure((size_t)B * ymaxt * max_n))) return rc;
+        if ((rc = m->yrot.ensure((size_t)B * P.ymaxt * max_n))) return rc;
     }
-    if ((rc = m->blockmax.ensure((size_t)B * score_blocks))) return rc;
+    if ((rc = m->blockmax.ensure((size_t)B * P.score_blocks))) return rc;
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
+    P.stamps = m->stamps_on ? m->stamps.p : nullptr;
+    return YM_OK;
+}
 
-    // ---- call descriptor: written into pinned host memory the kernels read directly
-    const size_t scans_bytes = align_up(sizeof(YmScanRef) * nscans, 16);
-    const size_t desc_bytes = scans_bytes + sizeof(YmItem) * B;
-    if ((rc = slot.desc.ensure(desc_bytes))) return rc;
-    if ((rc = slot.result.ensure(sizeof(YmItemState) * B))) return rc;
-    YmScanRef *hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
-    YmItem *hi = reinterpret_cast<YmItem *>(slot.desc.p + scans_bytes);
-    for (int i = 0; i < nscans; i++) {
+// the call descriptor: written into pinned host memory; a single match carries it in the kernel arguments, a batch
+// gets it by one async H2D copy (hundreds of blocks reading pinned host memory directly is slower)
+int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
+    const Call &call = slot.call;
+    int rc;
+    P.scans_bytes = align_up(sizeof(YmScanRef) * P.nscans, 16);
+    P.desc_bytes = P.scans_bytes + sizeof(YmItem) * P.B;
+    if ((rc = slot.desc.ensure(P.desc_bytes))) return rc;
+    if ((rc = slot.result.ensure(sizeof(YmItemState) * P.B))) return rc;
+    YmScanRef *hs = P.hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
+    YmItem *hi = P.hi = reinterpret_cast<YmItem *>(slot.desc.p + P.scans_bytes);
+    for (int i = 0; i < P.nscans; i++) {
         const CallScan &s = call.scans[i];
         hs[i].ranges = s.d_ranges;
         hs[i].n = s.n;
@@ -515,39 +552,40 @@ int launch_call(ym_matcher *m, Slot &slot) {
         hs[i].range_threshold = s.range_threshold;
         hs[i].pose[0] = s.pose[0]; hs[i].pose[1] = s.pose[1]; hs[i].pose[2] = s.pose[2];
     }
-    for (int i = 0; i < B; i++) {
+    for (int i = 0; i < P.B; i++) {
         hi[i].query = call.items[i].query;
         hi[i].base_begin = call.items[i].base_begin;
         hi[i].base_count = call.items[i].base_count;
         hi[i].pad = 0;
     }
-    hipStream_t st = m->stream;
-    const bool inline_desc = (B == 1 && nscans <= YM_INLINE_SCANS);
-    const YmScanRef *d_scans = nullptr;
-    const YmItem *d_items = nullptr;
-    if (!inline_desc) { // one async H2D copy; hundreds of blocks reading pinned host memory directly is slower
-        if ((rc = m->desc_dev.ensure(desc_bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(m->desc_dev.p, slot.desc.p, desc_bytes, hipMemcpyHostToDevice, st));
-        d_scans = reinterpret_cast<const YmScanRef *>(m->desc_dev.p);
-        d_items = reinterpret_cast<const YmItem *>(m->desc_dev.p + scans_bytes);
+    P.inline_desc = (P.B == 1 && P.nscans <= YM_INLINE_SCANS);
+    if (!P.inline_desc) {
+        if ((rc = m->desc_dev.ensure(P.desc_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(m->desc_dev.p, slot.desc.p, P.desc_bytes, hipMemcpyHostToDevice, m->stream));
+        P.d_scans = reinterpret_cast<const YmScanRef *>(m->desc_dev.p);
+        P.d_items = reinterpret_cast<const YmItem *>(m->desc_dev.p + P.scans_bytes);
     }
-    unsigned long long *stamps = m->stamps_on ? m->stamps.p : nullptr;
-    hipEvent_t ev_call = nullptr, ev_k = nullptr;
-    if ((rc = prof_begin(m, 2, &ev_call))) return rc;
+    return YM_OK;
+}
 
-    // ---- which tiles the raster covers in this call (host side; the device builds the work list inside it)
-    int launch[4];
+// which tiles of the window the raster covers in this call (host side; on batches the device builds the work list
+// inside that rectangle)
+int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
+    const Call &call = slot.call;
+    const YmGeom &g = P.g;
+    const int B = P.B, tiles_x = P.tiles_x, tiles_y = P.tiles_y;
+    int rc;
     // the "tile is already zero" flags describe window MEMORY: they survive from call to call while the buffers and
     // the tiling stay the same, otherwise they are cleared
     const size_t ntiles = (size_t)B * tiles_x * tiles_y;
-    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, grid_stride, (size_t)g.pitch, (size_t)g.win_w, ntiles};
+    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, ntiles};
     const bool tz_grow = ntiles > m->tile_zero.cap;
     if ((rc = m->tile_zero.ensure(ntiles))) return rc;
     if (tz_grow || std::memcmp(sig, m->tz_sig, sizeof sig) != 0) {
         // a smaller batch inside the same buffers keeps valid flags for the items it covers; anything else: reset
         const bool shrink_only = !tz_grow && std::memcmp(sig, m->tz_sig, 5 * sizeof(size_t)) == 0 && ntiles <= m->tz_sig[5];
         if (!shrink_only) {
-            HIP_TRY(hipMemsetAsync(m->tile_zero.p, 0, m->tile_zero.cap, st));
+            HIP_TRY(hipMemsetAsync(m->tile_zero.p, 0, m->tile_zero.cap, m->stream));
             std::memcpy(m->tz_sig, sig, sizeof sig);
             m->dirty_rect[0] = m->dirty_rect[1] = 0; // unknown memory: next launch covers every tile
             m->dirty_rect[2] = tiles_x - 1; m->dirty_rect[3] = tiles_y - 1;
@@ -580,6 +618,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     }
     want[0] = std::max(want[0], 0); want[1] = std::max(want[1], 0);
     want[2] = std::min(want[2], tiles_x - 1); want[3] = std::min(want[3], tiles_y - 1);
+    int *launch = P.launch;
     const bool dirty_empty = m->dirty_rect[2] < m->dirty_rect[0] || m->dirty_rect[3] < m->dirty_rect[1];
     if (want[2] < want[0] || want[3] < want[1]) { // nothing can be stamped: only clean what may be dirty
         for (int k = 0; k < 4; k++) launch[k] = m->dirty_rect[k];
@@ -592,160 +631,205 @@ int launch_call(ym_matcher *m, Slot &slot) {
     // after this launch only `want` can hold non-zero bytes
     for (int k = 0; k < 4; k++) m->dirty_rect[k] = want[k];
     if (m->full_raster) { launch[0] = launch[1] = 0; launch[2] = tiles_x - 1; launch[3] = tiles_y - 1; }
-    const int ltx = std::max(0, launch[2] - launch[0] + 1), lty = std::max(0, launch[3] - launch[1] + 1);
-    const int tile_cap = std::max(1, ltx * lty);
+    P.ltx = std::max(0, launch[2] - launch[0] + 1);
+    P.lty = std::max(0, launch[3] - launch[1] + 1);
+    P.tile_cap = std::max(1, P.ltx * P.lty);
     // a work list pays for its extra launch from a handful of items on (raster 210 -> 159 us on 256 items)
-    const bool use_tile_list = B >= 8 && ltx * lty > 0 && tiles_x * tiles_y < 32768;
-    if (use_tile_list) {
-        if ((rc = m->tile_list.ensure((size_t)B * tile_cap))) return rc;
+    P.use_tile_list = B >= 8 && P.ltx * P.lty > 0 && tiles_x * tiles_y < 32768;
+    if (P.use_tile_list) {
+        if ((rc = m->tile_list.ensure((size_t)B * P.tile_cap))) return rc;
         if ((rc = m->tile_count.ensure(B))) return rc;
     }
-    // ---- K1 prepare
-    {
-        ym::PrepareArgs a;
-        a.scans = d_scans; a.items = d_items; a.g = g; a.lat = lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
-        a.cells = m->cells.p; a.bbox = m->bbox.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
-        a.max_n = max_n; a.max_base = max_base; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.stamps = stamps;
-        a.use_inline = inline_desc ? 1 : 0;
-        a.pad0 = 0;
-        std::memset(&a.inl, 0, sizeof a.inl);
-        if (a.use_inline) { // descriptor travels in the kernel arguments: no host-memory reads on the device
-            a.inl.item = hi[0];
-            for (int i = 0; i < nscans; i++) a.inl.scans[i] = hs[i];
-        }
-        const size_t lds = YM_PREP_LDS_BYTES(max_n);
-        if (B >= 8) hipLaunchKernelGGL(ym::prepare_kernel<256>, dim3(max_base + 1, B), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(max_base + 1, B), dim3(512), lds, st, a);
+    return YM_OK;
+}
+
+// ---- K1 prepare
+void enqueue_prepare(ym_matcher *m, const CallPlan &P) {
+    ym::PrepareArgs a;
+    a.scans = P.d_scans; a.items = P.d_items; a.g = P.g; a.lat = P.lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
+    a.cells = m->cells.p; a.bbox = m->bbox.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
+    a.max_n = P.max_n; a.max_base = P.max_base; a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.stamps = P.stamps;
+    a.use_inline = P.inline_desc ? 1 : 0;
+    a.pad0 = 0;
+    std::memset(&a.inl, 0, sizeof a.inl);
+    if (a.use_inline) { // descriptor travels in the kernel arguments: no host-memory reads on the device
+        a.inl.item = P.hi[0];
+        for (int i = 0; i < P.nscans; i++) a.inl.scans[i] = P.hs[i];
     }
-    // ---- K1b select: Karto's order-dependent "value already set" rule (only when the kernel has 100-valued taps off-centre)
-    if (g.zone_count > 1) {
-        const size_t pts = (size_t)max_base * max_n;
-        int log2cap = 10;
-        while (((size_t)3 << log2cap) < 4 * pts) log2cap++; // load factor <= 0.75
-        if (log2cap > 14 || g.storage_w >= 32768)
-            return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 12288 readings are not supported",
-                           m->cfg.smear_deviation / m->cfg.resolution);
-        ym::SelectArgs a;
-        a.cells = m->cells.p; a.max_n = max_n; a.max_base = max_base; a.z2max = m->z2max; a.log2cap = log2cap; a.stamps = stamps;
-        const size_t lds = (size_t)9 << log2cap;
-        if (m->z2max <= 1) hipLaunchKernelGGL(ym::select_kernel<5>, dim3(B), dim3(1024), lds, st, a);
-        else hipLaunchKernelGGL(ym::select_kernel<9>, dim3(B), dim3(1024), lds, st, a);
+    const size_t lds = YM_PREP_LDS_BYTES(P.max_n);
+    if (P.B >= 8) hipLaunchKernelGGL(ym::prepare_kernel<256>, dim3(P.max_base + 1, P.B), dim3(256), lds, m->stream, a);
+    else hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(P.max_base + 1, P.B), dim3(512), lds, m->stream, a);
+}
+
+// ---- K1b select: Karto's order-dependent "value already set" rule (only when the kernel has 100-valued taps off-centre)
+int enqueue_select(ym_matcher *m, const CallPlan &P) {
+    if (P.g.zone_count <= 1) return YM_OK;
+    const size_t pts = (size_t)P.max_base * P.max_n;
+    int log2cap = 10;
+    while (((size_t)3 << log2cap) < 4 * pts) log2cap++; // load factor <= 0.75
+    if (log2cap > 14 || P.g.storage_w >= 32768)
+        return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 12288 readings are not supported",
+                       m->cfg.smear_deviation / m->cfg.resolution);
+    ym::SelectArgs a;
+    a.cells = m->cells.p; a.max_n = P.max_n; a.max_base = P.max_base; a.z2max = m->z2max; a.log2cap = log2cap; a.stamps = P.stamps;
+    const size_t lds = (size_t)9 << log2cap;
+    if (m->z2max <= 1) hipLaunchKernelGGL(ym::select_kernel<5>, dim3(P.B), dim3(1024), lds, m->stream, a);
+    else hipLaunchKernelGGL(ym::select_kernel<9>, dim3(P.B), dim3(1024), lds, m->stream, a);
+    return YM_OK;
+}
+
+// ---- K1c tiles (batches; after select: it reads the boxes only) and K2 raster
+int enqueue_raster(ym_matcher *m, const CallPlan &P) {
+    hipStream_t st = m->stream;
+    const YmGeom &g = P.g;
+    if (P.use_tile_list) {
+        ym::TilesArgs t;
+        t.bbox = m->bbox.p; t.tile_list = m->tile_list.p; t.tile_count = m->tile_count.p; t.tile_zero = m->tile_zero.p;
+        t.max_n = P.max_n; t.max_base = P.max_base; t.half_kernel = g.half_kernel;
+        t.tiles_x = P.tiles_x; t.tiles_y = P.tiles_y; t.tile_cap = P.tile_cap;
+        for (int k = 0; k < 4; k++) t.launch[k] = P.launch[k];
+        hipLaunchKernelGGL(ym::tiles_kernel, dim3(P.B), dim3(YM_TILES_THREADS), (size_t)4 * ((P.tiles_x * P.tiles_y + 31) / 32), st, t);
     }
-    // ---- K2 raster
-    {
-        if (use_tile_list) { // ---- K1c tiles (after select: it reads the boxes only)
-            ym::TilesArgs t;
-            t.bbox = m->bbox.p; t.tile_list = m->tile_list.p; t.tile_count = m->tile_count.p; t.tile_zero = m->tile_zero.p;
-            t.max_n = max_n; t.max_base = max_base; t.half_kernel = g.half_kernel;
-            t.tiles_x = tiles_x; t.tiles_y = tiles_y; t.tile_cap = tile_cap;
-            for (int k = 0; k < 4; k++) t.launch[k] = launch[k];
-            hipLaunchKernelGGL(ym::tiles_kernel, dim3(B), dim3(YM_TILES_THREADS), (size_t)4 * ((tiles_x * tiles_y + 31) / 32), st, t);
-        }
-        ym::RasterArgs a;
-        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tile_x0 = launch[0]; a.tile_y0 = launch[1]; a.ltx = ltx;
-        a.tile_list = use_tile_list ? m->tile_list.p : nullptr; a.tile_count = m->tile_count.p; a.tile_cap = tile_cap;
-        a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
-        a.grid_stride = grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = max_n; a.max_base = max_base; a.stamps = stamps;
-        a.tile_zero = m->tile_zero.p;
-        if ((rc = prof_begin(m, 1, &ev_k))) return rc;
-        if (ltx > 0 && lty > 0) {
-            if (use_tile_list) hipLaunchKernelGGL(ym::raster_kernel<128>, dim3(ltx * lty, B), dim3(128), 0, st, a);
-            else hipLaunchKernelGGL(ym::raster_kernel<256>, dim3(ltx * lty, B), dim3(256), 0, st, a);
-        }
-        if ((rc = prof_end(m, ev_k))) return rc;
+    ym::RasterArgs a;
+    a.tiles_x = P.tiles_x; a.tiles_y = P.tiles_y; a.tile_x0 = P.launch[0]; a.tile_y0 = P.launch[1]; a.ltx = P.ltx;
+    a.tile_list = P.use_tile_list ? m->tile_list.p : nullptr; a.tile_count = m->tile_count.p; a.tile_cap = P.tile_cap;
+    a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
+    a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
+    a.tile_zero = m->tile_zero.p;
+    int rc;
+    hipEvent_t ev_k = nullptr;
+    if ((rc = prof_begin(m, 1, &ev_k))) return rc;
+    if (P.ltx > 0 && P.lty > 0) {
+        if (P.use_tile_list) hipLaunchKernelGGL(ym::raster_kernel<128>, dim3(P.ltx * P.lty, P.B), dim3(128), 0, st, a);
+        else hipLaunchKernelGGL(ym::raster_kernel<256>, dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
     }
-    if (yag) {
-        // ---- the Python matcher's two find_best_pose passes (scan_matching.py:204-214)
-        m->sums_pass_offset[0] = 0;
-        m->sums_pass_offset[1] = (size_t)B * yvol;
-        for (int pass = 0; pass < (call.refine ? 2 : 1); pass++) {
-            ym::YagArgs a;
-            std::memset(&a, 0, sizeof a);
-            a.g = g; a.pass = pass; a.penalize = call.penalize; a.refine = call.refine;
-            a.last = (pass == 1 || !call.refine) ? 1 : 0;
-            if (pass == 0) {
-                a.search_xy = m->cfg.search_size * 0.5; a.step_xy = g.res * 2;
-                a.search_t = m->cfg.coarse_search_angle_offset * 0.5; a.step_t = m->cfg.coarse_angle_resolution;
-            } else {
-                a.search_xy = g.res * 2; a.step_xy = g.res; a.search_t = 0.0349 * 0.5; a.step_t = 0.00349;
-            }
-            a.coarse_angle_res = m->cfg.coarse_angle_resolution;
-            a.states = m->states.p; a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
-            a.qlocal = m->qlocal.p; a.axes = m->yaxes.p; a.rot = m->yrot.p;
-            a.sums = m->sums.p + m->sums_pass_offset[pass]; a.out = m->resp.p;
-            a.grid = m->grid.p; a.grid_stride = grid_stride; a.vol_stride = yvol;
-            a.max_n = max_n; a.maxd = ymaxd; a.maxt = ymaxt;
-            hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(ymaxt, B), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(ym::yag_score_kernel, dim3((ymaxd * ymaxd + 255) / 256, ymaxt, B), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(B), dim3(1024), 0, st, a);
-        }
-    } else {
-    // ---- K4 coarse correlate
-    {
-        ym::CorrArgs a;
-        a.g = g; a.lat = lc; a.grid = m->grid.p; a.grid_stride = grid_stride; a.planes = m->planes.p; a.ctrig = m->ctrig.p;
-        a.qlocal = m->qlocal.p; a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = partial_stride;
-        a.max_n = max_n; a.nt_stride = nt_stride; a.dim_stride = dim_stride; a.chunk = chunk; a.n_chunks = n_chunks;
-        a.ngx = ngx; a.nx_pad = nx_pad; a.sx = sx; a.stamps = stamps; a.tpb = tpb;
-        if ((rc = prof_begin(m, 0, &ev_k))) return rc;
-        const dim3 grid_dim(job_blocks, ktiles * n_chunks, B);
-        if (sx == 2 && m->use_lds_correlate >= 1 && njobs <= 128) {
-            a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
-            hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((njobs + 63) / 64, lc.nt * n_chunks, B), dim3(256), 0, st, a);
-        }
-        else if (sx == 2 && corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
-        else if (sx == 2 && corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
-        else if (sx == 2) hipLaunchKernelGGL((ym::correlate_kernel<2, 48>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
-        else hipLaunchKernelGGL((ym::correlate_kernel<1, 16>), grid_dim, dim3(YM_CORR_THREADS), (size_t)m->corr_pad_lds, st, a);
-        if ((rc = prof_end(m, ev_k))) return rc;
-    }
-    // ---- K5a score
+    return prof_end(m, ev_k);
+}
+
+// ---- the Python matcher's two find_best_pose passes (scan_matching.py:204-214)
+void enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
+    const Call &call = slot.call;
+    const YmGeom &g = P.g;
     m->sums_pass_offset[0] = 0;
-    m->sums_pass_offset[1] = (size_t)B * sums_c;
+    m->sums_pass_offset[1] = (size_t)P.B * P.yvol;
+    for (int pass = 0; pass < (call.refine ? 2 : 1); pass++) {
+        ym::YagArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.g = g; a.pass = pass; a.penalize = call.penalize; a.refine = call.refine;
+        a.last = (pass == 1 || !call.refine) ? 1 : 0;
+        if (pass == 0) {
+            a.search_xy = m->cfg.search_size * 0.5; a.step_xy = g.res * 2;
+            a.search_t = m->cfg.coarse_search_angle_offset * 0.5; a.step_t = m->cfg.coarse_angle_resolution;
+        } else {
+            a.search_xy = g.res * 2; a.step_xy = g.res; a.search_t = 0.0349 * 0.5; a.step_t = 0.00349;
+        }
+        a.coarse_angle_res = m->cfg.coarse_angle_resolution;
+        a.states = m->states.p; a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
+        a.qlocal = m->qlocal.p; a.axes = m->yaxes.p; a.rot = m->yrot.p;
+        a.sums = m->sums.p + m->sums_pass_offset[pass]; a.out = m->resp.p;
+        a.grid = m->grid.p; a.grid_stride = P.grid_stride; a.vol_stride = P.yvol;
+        a.max_n = P.max_n; a.maxd = P.ymaxd; a.maxt = P.ymaxt;
+        hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(P.ymaxt, P.B), dim3(256), 0, m->stream, a);
+        hipLaunchKernelGGL(ym::yag_score_kernel, dim3((P.ymaxd * P.ymaxd + 255) / 256, P.ymaxt, P.B), dim3(256), 0, m->stream, a);
+        hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(P.B), dim3(1024), 0, m->stream, a);
+    }
+}
+
+// ---- K4 coarse correlate
+int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
+    hipStream_t st = m->stream;
+    ym::CorrArgs a;
+    a.g = P.g; a.lat = P.lc; a.grid = m->grid.p; a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.ctrig = m->ctrig.p;
+    a.qlocal = m->qlocal.p; a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = P.partial_stride;
+    a.max_n = P.max_n; a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.chunk = P.chunk; a.n_chunks = P.n_chunks;
+    a.ngx = P.ngx; a.nx_pad = P.nx_pad; a.sx = P.sx; a.stamps = P.stamps; a.tpb = P.tpb;
+    int rc;
+    hipEvent_t ev_k = nullptr;
+    if ((rc = prof_begin(m, 0, &ev_k))) return rc;
+    const dim3 grid_dim(P.job_blocks, P.ktiles * P.n_chunks, P.B);
+    const size_t pad_lds = (size_t)m->corr_pad_lds;
+    if (P.sx == 2 && m->use_lds_correlate >= 1 && P.njobs <= 128) {
+        a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
+        hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((P.njobs + 63) / 64, P.lc.nt * P.n_chunks, P.B), dim3(256), 0, st, a);
+    }
+    else if (P.sx == 2 && P.corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
+    else if (P.sx == 2 && P.corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
+    else if (P.sx == 2) hipLaunchKernelGGL((ym::correlate_kernel<2, 48>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
+    else hipLaunchKernelGGL((ym::correlate_kernel<1, 16>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
+    return prof_end(m, ev_k);
+}
+
+// ---- K5 score, then the finish stage: fine_kernel (coarse arg-max/mean + 3x3 fine lattice, one block per fine angle)
+// + final_kernel (covariances, fine arg-max/mean) for a few items, the one-block finish_kernel on batches; results
+// land in pinned host memory
+void enqueue_score_and_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
+    hipStream_t st = m->stream;
+    const Call &call = slot.call;
+    const YmLattice &lc = P.lc, &lf = P.lf;
+    m->sums_pass_offset[0] = 0;
+    m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
     {
         ym::ScoreArgs a;
-        a.g = g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = partial_stride; a.states = m->states.p;
-        a.sums = m->sums.p; a.sums_stride = sums_c; a.resp = m->resp.p; a.blockmax = m->blockmax.p;
-        a.n_chunks = n_chunks; a.nx_pad = nx_pad; a.n_blocks = score_blocks; a.stamps = stamps;
+        a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
+        a.sums = m->sums.p; a.sums_stride = P.sums_c; a.resp = m->resp.p; a.blockmax = m->blockmax.p;
+        a.n_chunks = P.n_chunks; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
         a.probs = reinterpret_cast<unsigned long long *>(m->probs.p); a.probs_stride = (size_t)lc.nx * lc.ny;
-        hipLaunchKernelGGL(ym::score_kernel, dim3(score_blocks, B), dim3(YM_SCORE_THREADS), 0, st, a);
+        hipLaunchKernelGGL(ym::score_kernel, dim3(P.score_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
     }
-    // ---- K6a fine (coarse arg-max/mean + 3x3 fine lattice, one block per fine angle) and
-    // ---- K6b final (covariances, fine arg-max/mean); results land in pinned host memory
-    {
-        ym::FinishArgs a;
-        a.g = g; a.lc = lc; a.lf = lf; a.refine = call.refine; a.max_n = max_n; a.nt_stride = lf.nt;
-        a.n_blocks = score_blocks; a.states = m->states.p;
-        a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
-        a.resp = m->resp.p; a.sums_stride = sums_c; a.blockmax = m->blockmax.p; a.probs = m->probs.p;
-        a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = grid_stride;
-        a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
-        a.fsums_stride = sums_f; a.stamps = stamps;
-        if ((B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
-            hipLaunchKernelGGL(ym::finish_kernel, dim3(B), dim3(YM_FINISH1_THREADS), 0, st, a);
-        } else {
-            hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, B), dim3(YM_FINE_THREADS), 0, st, a);
-            hipLaunchKernelGGL(ym::final_kernel, dim3(B), dim3(YM_FINISH_THREADS), 0, st, a);
-        }
+    ym::FinishArgs a;
+    a.g = P.g; a.lc = lc; a.lf = lf; a.refine = call.refine; a.max_n = P.max_n; a.nt_stride = lf.nt;
+    a.n_blocks = P.score_blocks; a.states = m->states.p;
+    a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
+    a.resp = m->resp.p; a.sums_stride = P.sums_c; a.blockmax = m->blockmax.p; a.probs = m->probs.p;
+    a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = P.grid_stride;
+    a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
+    a.fsums_stride = P.sums_f; a.stamps = P.stamps;
+    if ((P.B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
+        hipLaunchKernelGGL(ym::finish_kernel, dim3(P.B), dim3(YM_FINISH1_THREADS), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
+        hipLaunchKernelGGL(ym::final_kernel, dim3(P.B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
-    } // karto
+}
+
+int launch_call(ym_matcher *m, Slot &slot) {
+    HIP_TRY(hipSetDevice(m->device));
+    CallPlan P;
+    int rc;
+    if ((rc = plan_sizes(m, slot, P))) return rc;
+    if ((rc = plan_descriptor(m, slot, P))) return rc;
+    hipStream_t st = m->stream;
+    hipEvent_t ev_call = nullptr;
+    if ((rc = prof_begin(m, 2, &ev_call))) return rc;
+    if ((rc = plan_raster(m, slot, P))) return rc;
+
+    enqueue_prepare(m, P);
+    if ((rc = enqueue_select(m, P))) return rc;
+    if ((rc = enqueue_raster(m, P))) return rc;
+    if (P.yag) {
+        enqueue_yagpy_passes(m, slot, P);
+    } else {
+        if ((rc = enqueue_correlate(m, P))) return rc;
+        enqueue_score_and_finish(m, slot, P);
+    }
     if (slot.dev_best_out)
-        hipLaunchKernelGGL(ym::argbest_kernel, dim3(1), dim3(256), 0, st, m->states.p, B, (long long)slot.chain_id_base,
+        hipLaunchKernelGGL(ym::argbest_kernel, dim3(1), dim3(256), 0, st, m->states.p, P.B, (long long)slot.chain_id_base,
                            reinterpret_cast<double *>(slot.dev_best_out));
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, ev_call))) return rc;
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(slot.done, st));
     slot.in_flight = true;
-    slot.n_items = B;
+    slot.n_items = P.B;
 
-    m->last_geom = g;
-    m->last_lat[0] = lc;
-    m->last_lat[1] = lf;
-    m->last_B = B; m->last_max_n = max_n; m->last_max_base = max_base;
-    m->last_nt_stride = nt_stride; m->last_dim_stride = dim_stride;
-    m->last_grid_stride = grid_stride;
-    m->last_sums_stride[0] = yag ? yvol : sums_c; m->last_sums_stride[1] = call.refine ? (yag ? yvol : sums_f) : 0;
+    m->last_geom = P.g;
+    m->last_lat[0] = P.lc;
+    m->last_lat[1] = P.lf;
+    m->last_B = P.B; m->last_max_n = P.max_n; m->last_max_base = P.max_base;
+    m->last_nt_stride = P.nt_stride; m->last_dim_stride = P.dim_stride;
+    m->last_grid_stride = P.grid_stride;
+    m->last_sums_stride[0] = P.yag ? P.yvol : P.sums_c;
+    m->last_sums_stride[1] = slot.call.refine ? (P.yag ? P.yvol : P.sums_f) : 0;
     m->last_valid = true;
     return YM_OK;
 }
