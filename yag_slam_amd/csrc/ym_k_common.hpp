@@ -1,0 +1,152 @@
+// ym_k_common.hpp -- shared device helpers: Karto math, block/wave reductions, stamps, tile size.
+// Part of ym_kernels.hpp (include that, not this file).
+#pragma once
+
+namespace ym {
+
+// ------------------------------------------------------------------ Karto math:: helpers
+__device__ __forceinline__ double kt_round(double v) { return v >= 0.0 ? floor(v + 0.5) : ceil(v - 0.5); }
+__device__ __forceinline__ bool kt_double_equal(double a, double b) {
+    double d = a - b;
+    return d < 0.0 ? d >= -YM_KT_TOLERANCE : d <= YM_KT_TOLERANCE;
+}
+__device__ inline double kt_normalize_angle(double angle) {
+    while (angle < -YM_KT_PI) {
+        if (angle < -YM_KT_2PI) angle += (double)(unsigned int)(angle / -YM_KT_2PI) * YM_KT_2PI;
+        else angle += YM_KT_2PI;
+    }
+    while (angle > YM_KT_PI) {
+        if (angle > YM_KT_2PI) angle -= (double)(unsigned int)(angle / YM_KT_2PI) * YM_KT_2PI;
+        else angle -= YM_KT_2PI;
+    }
+    return angle;
+}
+__device__ inline double kt_normalize_angle_difference(double minuend, double subtrahend) {
+    while (minuend - subtrahend < -YM_KT_PI) minuend += YM_KT_2PI;
+    while (minuend - subtrahend > YM_KT_PI) minuend -= YM_KT_2PI;
+    return minuend;
+}
+// (int)math::Round(v): half away from zero.  trunc(|v| + 0.5) with the sign restored is the same
+// integer as floor(v + 0.5) / ceil(v - 0.5) for every |v| < 2^31 and needs no floor/ceil pair.
+__device__ __forceinline__ int kt_round_int(double v) {
+    const int r = (int)(fabs(v) + 0.5);
+    return v < 0.0 ? -r : r;
+}
+__device__ __forceinline__ int world_to_grid(double w, double off, double scale) {
+    return kt_round_int((w - off) * scale);
+}
+
+// ------------------------------------------------------------------ block helpers
+// exclusive prefix position of `flag` inside the block + block total; wave = 64 lanes
+__device__ __forceinline__ int block_scan_flag(bool flag, int *total, int *wave_counts) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    unsigned long long m = __ballot(flag);
+    int pre = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_counts[w] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+        int c = wave_counts[i];
+        if (i < w) base += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + pre;
+}
+
+// ---- wave64 reductions on DPP row operations (no LDS traffic).  After the four row steps every
+// lane of a 16-lane row holds its row's result; the four row results are combined through
+// v_readlane, so the combination order is fixed (bit-reproducible fp64 sums).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#define YM_DPP_QUAD_1032 0xB1
+#define YM_DPP_QUAD_2301 0x4E
+#define YM_DPP_ROW_ROR4 0x124
+#define YM_DPP_ROW_ROR8 0x128
+template <typename Op>
+__device__ __forceinline__ double wave_reduce(double v, Op op) {
+    v = op(v, dpp_f64<YM_DPP_QUAD_1032>(v));
+    v = op(v, dpp_f64<YM_DPP_QUAD_2301>(v));
+    v = op(v, dpp_f64<YM_DPP_ROW_ROR4>(v));
+    v = op(v, dpp_f64<YM_DPP_ROW_ROR8>(v));
+    return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+template <typename Op>
+__device__ __forceinline__ int wave_reduce(int v, Op op) {
+    v = op(v, dpp_i32<YM_DPP_QUAD_1032>(v));
+    v = op(v, dpp_i32<YM_DPP_QUAD_2301>(v));
+    v = op(v, dpp_i32<YM_DPP_ROW_ROR4>(v));
+    v = op(v, dpp_i32<YM_DPP_ROW_ROR8>(v));
+    return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+              op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+template <typename Op>
+__device__ __forceinline__ unsigned wave_reduce(unsigned v, Op op) {
+    struct Wrap { Op op; __device__ int operator()(int a, int b) const { return (int)op((unsigned)a, (unsigned)b); } };
+    return (unsigned)wave_reduce((int)v, Wrap{op});
+}
+// block-wide reduce, result valid in every thread; scratch >= 16 entries of T
+template <typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, Op op, T identity, T *scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_reduce(v, op);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T r = identity;
+    for (int i = 0; i < nw; i++) r = op(r, scratch[i]);
+    return r;
+}
+struct OpMaxD { __device__ double operator()(double a, double b) const { return a > b ? a : b; } };
+struct OpAddD { __device__ double operator()(double a, double b) const { return a + b; } };
+struct OpAddU { __device__ unsigned operator()(unsigned a, unsigned b) const { return a + b; } };
+struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
+struct OpMinI { __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
+
+// development aid: block (0,0,0) thread 0 records the 100 MHz wall clock at phase boundaries
+#define YM_STAMP(args, idx)                                                                       \
+    do {                                                                                          \
+        if ((args).stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
+            (args).stamps[idx] = wall_clock64();                                                  \
+    } while (0)
+
+#define YM_STAMP_B1(args, idx)                                                                    \
+    do {                                                                                          \
+        if ((args).stamps && threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) \
+            (args).stamps[idx] = wall_clock64();                                                  \
+    } while (0)
+
+// GridIndexLookup::ComputeOffsets for one angle and one point -> window-linear offset
+__device__ __forceinline__ int lookup_offset(double2 p, double cosine, double sine, double off_x, double off_y,
+                                             double scale, int pitch) {
+    const double ox = cosine * p.x - sine * p.y;
+    const double oy = sine * p.x + cosine * p.y;
+    const int gx = world_to_grid(ox + off_x, off_x, scale);
+    const int gy = world_to_grid(oy + off_y, off_y, scale);
+    return gx + gy * pitch;
+}
+
+// hypothesis cells of one lattice axis: WorldToGrid(centre + (start + i*step)), window coordinates
+__device__ __forceinline__ int hyp_cell(double centre, double start, int i, double step, double off, const YmGeom &g) {
+    const double v = start + i * step;
+    return world_to_grid(centre + v, off, g.scale) + g.border - g.win_origin;
+}
+
+// raster tile (also used by prepare_kernel, which builds the raster's work list)
+#define YM_TILE_W 64
+#define YM_TILE_H 32
+
+}  // namespace ym

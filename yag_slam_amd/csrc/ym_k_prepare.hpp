@@ -1,0 +1,470 @@
+// ym_k_prepare.hpp -- K1 prepare_kernel, K1c tiles_kernel, K1b select_kernel.
+// Part of ym_kernels.hpp (include that, not this file).
+#pragma once
+
+namespace ym {
+
+// ================================================================== K1 prepare
+#define YM_PREP_LDS_BYTES(max_n) ((size_t)(max_n) * 25 + ((size_t)(max_n) / 64 + 2) * 4 + 16)
+#define YM_INLINE_SCANS 16
+struct YmInlineDesc {        // call descriptor passed in the kernel arguments (single item, few scans)
+    YmItem item;
+    YmScanRef scans[YM_INLINE_SCANS];
+};
+struct PrepareArgs {
+    const YmScanRef *scans;  // pinned host memory (device-mapped); unused when use_inline
+    const YmItem *items;
+    int32_t use_inline;
+    int32_t pad0;
+    YmInlineDesc inl;
+    YmGeom g;
+    YmLattice lat;           // coarse lattice
+    YmItemState *states;
+    double2 *qlocal;         // [B][max_n]
+    int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
+    int4 *bbox;              // [B][max_base][ceil(max_n/64)] window bounding box of 64 consecutive cells
+    double2 *ctrig;          // [B][nt_stride] (cos, sin) of every coarse angle
+    int32_t *hypcell;        // [B][2][dim_stride]
+    double *probs;           // [B][ny*nx] cleared here, filled by score_kernel
+    int32_t max_n, max_base, nt_stride, dim_stride;
+    unsigned long long *stamps;
+};
+
+// grid (max_base + 1, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).  NT = 512: shortest latency (single
+// match); NT = 256: the kernel needs ~100 VGPRs (fp64 sincos), i.e. 16 waves per CU, and four blocks of 256 hide
+// each other's barriers and loads better than two of 512 (98 -> 76 us on 256 items).
+// blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.
+template <int NT>
+__global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    YM_STAMP(a, 0);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const YmItem it = a.use_inline ? a.inl.item : a.items[b];
+    const bool is_query = blockIdx.x == 0;
+    const int slot = (int)blockIdx.x - 1;
+    const int n_cchunks = (a.max_n + 63) / 64;
+    if (!is_query && slot >= it.base_count) { // unused chain slot: no points, empty boxes
+        int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
+        for (int i = threadIdx.x; i < n_cchunks; i += NT) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
+        return;
+    }
+    const int si = is_query ? it.query : it.base_begin + slot;
+    const YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
+    const YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
+    double *sx = reinterpret_cast<double *>(lds_raw);
+    double *sy = sx + a.max_n;
+    int *nxt = reinterpret_cast<int *>(sy + a.max_n);
+    int *ex = nxt + a.max_n;                     // exit of the chain walk from point i out of its segment
+    int *ent = ex + a.max_n;                     // chain entry node per 64-point segment (max_n/64 + 1)
+    unsigned char *chain = reinterpret_cast<unsigned char *>(ent + a.max_n / 64 + 2);
+    const bool yag = a.g.semantics == 1;
+
+    // ---- point readings, compacted in beam order (LocalizedRangeScan::Update / _get_point_readings)
+    const double px = (is_query && yag) ? 0.0 : sr.pose[0];
+    const double py = (is_query && yag) ? 0.0 : sr.pose[1];
+    const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
+    // One barrier for the whole scan instead of two per NT beams: pass 1 counts the valid beams of every (chunk of NT
+    // beams, wave) by ballot, pass 2 re-reads the ranges (L1) and places each valid beam after everything before it.
+    constexpr int NW = NT / 64;
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * NW];
+    const int lane_ = tid & 63, wave_ = tid >> 6;
+    const int per = (sr.n + NT - 1) / NT; // chunks of NT beams
+    auto valid = [&](int i, double &r) {
+        r = 0.0;
+        if (i >= sr.n) return false;
+        r = sr.ranges[i];
+        return yag ? !(r > sr.range_threshold || isnan(r)) : (r >= sr.min_range && r <= sr.range_threshold);
+    };
+    for (int k = 0; k < per; k++) {
+        double r;
+        const unsigned long long m = __ballot(valid(k * NT + tid, r));
+        if (lane_ == 0) s_cnt[k * NW + wave_] = __popcll(m);
+    }
+    __syncthreads();
+    int running = 0;
+    for (int k = 0; k < per; k++) {
+        const int i = k * NT + tid;
+        double r;
+        const bool ok = valid(i, r);
+        const unsigned long long m = __ballot(ok);
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int c = s_cnt[k * NW + w];
+            before += w < wave_ ? c : 0;
+            total += c;
+        }
+        if (ok) {
+            const int pos = running + before + __popcll(m & ((1ull << lane_) - 1ull));
+            const double angle = pt + sr.min_angle + i * sr.angle_inc;
+            sx[pos] = px + r * cos(angle);
+            sy[pos] = py + r * sin(angle);
+        }
+        running += total;
+    }
+    const int np = running;
+    __syncthreads();
+    YM_STAMP(a, 1);
+    YM_STAMP_B1(a, 20);
+    // world offset of ROI cell (0,0): MatchScan, "set scan pose to be center of grid"
+    const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+
+    if (is_query) {
+        if (tid == 0) {
+            YmItemState &st = a.states[b];
+            st.pose[0] = sr.pose[0]; st.pose[1] = sr.pose[1]; st.pose[2] = sr.pose[2];
+            st.center[0] = sr.pose[0]; st.center[1] = sr.pose[1]; st.center[2] = sr.pose[2];
+            st.off_x = off_x;
+            st.off_y = off_y;
+            st.nq = np;
+            st.status = 0;
+            st.regular[0] = st.regular[1] = 0;
+            st.base_count = it.base_count;
+        }
+        // sensor-frame coordinates (karto: Transform(pose).InverseTransformPose; yagpy: points_local)
+        double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        const bool identity = yag || (sr.pose[0] == 0.0 && sr.pose[1] == 0.0 && sr.pose[2] == 0.0);
+        const double cr = cos(0.0 - sr.pose[2]), sn = sin(0.0 - sr.pose[2]);
+        __syncthreads();
+        for (int i = tid; i < np; i += NT) {
+            double2 l;
+            if (identity) {
+                l = make_double2(sx[i], sy[i]);
+            } else {
+                const double dx = sx[i] - sr.pose[0], dy = sy[i] - sr.pose[1];
+                l = make_double2(cr * dx + (0.0 - sn) * dy, sn * dx + cr * dy);
+            }
+            ql[i] = l;
+        }
+        // one fp64 sin/cos per coarse angle (GridIndexLookup::ComputeOffsets); the cell offsets
+        // themselves are computed by the correlate blocks that consume them
+        if (tid < a.lat.nt) {
+            const double angle = (sr.pose[2] - a.lat.angle_off) + tid * a.lat.angle_res;
+            a.ctrig[(size_t)b * a.nt_stride + tid] = make_double2(cos(angle), sin(angle));
+        }
+        YM_STAMP(a, 2);
+        for (int i = tid; i < a.lat.nx * a.lat.ny; i += NT) a.probs[(size_t)b * a.lat.nx * a.lat.ny + i] = 0.0;
+        // coarse hypothesis cells + regularity flag
+        int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+        int32_t *cy = cx + a.dim_stride;
+        for (int i = tid; i < a.lat.nx; i += NT) cx[i] = hyp_cell(sr.pose[0], -a.lat.off_x, i, a.lat.step_x, off_x, a.g);
+        for (int i = tid; i < a.lat.ny; i += NT) cy[i] = hyp_cell(sr.pose[1], -a.lat.off_y, i, a.lat.step_y, off_y, a.g);
+        __syncthreads();
+        {
+            const int stx = kt_round_int(a.lat.step_x * a.g.scale), sty = kt_round_int(a.lat.step_y * a.g.scale);
+            int ok = 1;
+            for (int i = tid; i < a.lat.nx; i += NT) ok &= (cx[i] == cx[0] + i * stx);
+            for (int i = tid; i < a.lat.ny; i += NT) ok &= (cy[i] == cy[0] + i * sty);
+            ok = __syncthreads_and(ok);
+            if (tid == 0) a.states[b].regular[0] = ok;
+        }
+        YM_STAMP(a, 18);
+        return;
+    }
+
+    // ---- valid-point filter (ScanMatcher::FindValidPoints / validate_points), parallel form:
+    // nxt[i] = first j > i farther than d from point i; the trigger chain is 0 -> nxt[0] -> ...;
+    // the run that ends at chain node t = nxt[s] is kept or dropped by the sign of ss(s, t).
+    const double min_sq = yag ? 0.2 * 0.2 : 0.1 * 0.1;
+    const double vpx = qr.pose[0], vpy = qr.pose[1];
+    for (int i = tid; i < np; i += NT) {
+        const double fx = sx[i], fy = sy[i];
+        int j = i + 1;
+        for (; j < np; j++) {
+            const double dx = fx - sx[j], dy = fy - sy[j];
+            if (dx * dx + dy * dy > min_sq) break;
+        }
+        nxt[i] = j;
+        chain[i] = 0;
+    }
+    __syncthreads();
+    YM_STAMP_B1(a, 21);
+    // Mark the chain 0 -> nxt[0] -> ... without one long serial walk: cut the points into segments
+    // of 64; (1) every point walks to the first node past its own segment, (2) one thread hops from
+    // segment to segment with those exits (<= n/64 hops), (3) one thread per entered segment marks
+    // the chain nodes inside it.
+    constexpr int SEG = 64;
+    const int nseg = (np + SEG - 1) / SEG;
+    for (int i = tid; i < np; i += NT) {
+        const int seg_end = min(np, (i / SEG + 1) * SEG);
+        int j = nxt[i];
+        while (j < seg_end) j = nxt[j];
+        ex[i] = j;
+    }
+    for (int i = tid; i < nseg; i += NT) ent[i] = -1;
+    __syncthreads();
+    if (tid == 0)
+        for (int cur = 0; cur < np; cur = ex[cur]) ent[cur / SEG] = cur;
+    __syncthreads();
+    for (int sgi = tid; sgi < nseg; sgi += NT) {
+        int c = ent[sgi];
+        if (c >= 0) {
+            const int seg_end = min(np, (sgi + 1) * SEG);
+            for (; c < seg_end; c = nxt[c]) chain[c] = 1;
+        }
+    }
+    __syncthreads();
+    YM_STAMP_B1(a, 22);
+    int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
+    int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
+    for (int i0 = 0; i0 < n_cchunks * 64; i0 += NT) {
+        const int i = i0 + tid; // a wave covers one 64-cell chunk
+        int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+        if (i < np) {
+            bool keep = false;
+            int s = yag ? i - 1 : i;
+            if (s >= 0) {
+                while (!chain[s]) s--;
+                const int t = nxt[s];
+                if (t < np) {
+                    const double fx = sx[s], fy = sy[s], cx = sx[t], cy = sy[t];
+                    const double aa = vpy - fy;
+                    const double bb = fx - vpx;
+                    const double cc = fy * vpx - fx * vpy;
+                    const double ss = cx * aa + cy * bb + cc;
+                    keep = yag ? (ss > 0.0) : !(ss < 0.0);
+                }
+            }
+            if (keep) {
+                int gx, gy;
+                if (yag) {
+                    gx = (int)rint((sx[i] - off_x) / a.g.res);
+                    gy = (int)rint((sy[i] - off_y) / a.g.res);
+                } else {
+                    gx = world_to_grid(sx[i], off_x, a.g.scale);
+                    gy = world_to_grid(sy[i], off_y, a.g.scale);
+                }
+                if (gx >= 0 && gx < a.g.roi_w && gy >= 0 && gy < a.g.roi_w)
+                    c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
+            }
+        }
+        if (i < a.max_n) cells[i] = c;
+        // bounding box of the chunk's rasterised cells: the raster kernel reads a chunk only when
+        // this box touches its tile
+        const bool has = c.x != YM_CELL_NONE;
+        const int x0 = wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = wave_reduce(has ? c.y : INT32_MAX, OpMinI());
+        const int x1 = wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+        if ((tid & 63) == 0 && i / 64 < n_cchunks) bbox[i / 64] = make_int4(x0, y0, x1, y1);
+    }
+    YM_STAMP_B1(a, 23);
+}
+
+// ================================================================== K1c tiles: the raster kernel's work list (batches)
+// One raster block per tile of the window lets ~3 of 4 blocks find out, after a round trip through the chunk boxes
+// and a barrier, that they have nothing to do; on a batch that was most of the raster's time.  For batches this
+// kernel (one block per item) turns the item's chunk boxes into the list of tiles that have work: a tile bitmap in
+// LDS (every box marks the few tiles its smear halo reaches), compacted together with the tiles that hold stale
+// bytes from an earlier call and only need clearing.  The raster kernel then runs one block per list entry.
+// (Doing this in the last prepare block to finish needs a device-scope release per block, which on this part
+// writes the XCD's L2 back: measured 98 -> 771 us for the prepare kernel.  A kernel boundary is cheaper.)
+#define YM_TILES_THREADS 256
+struct TilesArgs {
+    const int4 *bbox;        // [B][max_base][ceil(max_n/64)]
+    uint16_t *tile_list;     // [B][tile_cap] tile index (tiy * tiles_x + tix), | 0x8000 = only needs clearing
+    int32_t *tile_count;     // [B]
+    const uint8_t *tile_zero;// [B][tiles_y][tiles_x] 1 = the tile's memory is known to hold zeros
+    int32_t max_n, max_base, half_kernel;
+    int32_t tiles_x, tiles_y, tile_cap;
+    int32_t launch[4];       // tile rectangle (x0, y0, x1, y1) the raster covers in this call
+};
+// grid (B), dynamic LDS = 4 * ceil(tiles_x * tiles_y / 32) bytes
+__global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
+    extern __shared__ unsigned tile_bits[];
+    __shared__ int s_n;
+    constexpr int NT = YM_TILES_THREADS;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ntiles = a.tiles_x * a.tiles_y, nwords = (ntiles + 31) / 32;
+    for (int i = tid; i < nwords; i += NT) tile_bits[i] = 0u;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int h = a.half_kernel;
+    const int lx0 = a.launch[0], ly0 = a.launch[1], lx1 = a.launch[2], ly1 = a.launch[3];
+    const int n_boxes = a.max_base * ((a.max_n + 63) / 64);
+    const int4 *bbox = a.bbox + (size_t)b * n_boxes;
+    for (int c = tid; c < n_boxes; c += NT) {
+        const int4 bb = bbox[c];
+        if (bb.x > bb.z) continue;
+        // tiles whose halo-extended rectangle [t*T - h, t*T + T + h - 1] meets the box (the raster kernel's own test)
+        const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
+        const int ty0 = max(ly0, max(bb.y - h, 0) / YM_TILE_H), ty1 = min(ly1, (bb.w + h) / YM_TILE_H);
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int t = ty * a.tiles_x + tx;
+                atomicOr(&tile_bits[t >> 5], 1u << (t & 31));
+            }
+    }
+    __syncthreads();
+    const int ltx = lx1 - lx0 + 1, lty = ly1 - ly0 + 1;
+    const uint8_t *tz = a.tile_zero + (size_t)b * ntiles;
+    uint16_t *list = a.tile_list + (size_t)b * a.tile_cap;
+    for (int i = tid; i < ltx * lty; i += NT) {
+        const int ty = ly0 + i / ltx, tx = lx0 + i % ltx, t = ty * a.tiles_x + tx;
+        const bool hit = (tile_bits[t >> 5] >> (t & 31)) & 1u;
+        if (hit || tz[t] == 0) list[atomicAdd(&s_n, 1)] = (uint16_t)(t | (hit ? 0 : 0x8000));
+    }
+    __syncthreads();
+    if (tid == 0) a.tile_count[b] = s_n;
+}
+
+// ================================================================== K1b select (only when the smear kernel has taps == 100 off-centre)
+// Karto's AddScan skips a point whose cell already holds 100 ("value already set").  With
+// smear_deviation >= 9.99 * resolution the four neighbours of an occupied cell are stamped 100 as
+// well, so whether a point is rasterised depends on the points before it: a point is EFFECTIVE iff
+// no earlier effective point lies within squared cell distance z2max (the radius of the kernel's
+// 100-valued disc), in Karto's order (base scans in order, beams in order).
+//
+// Parallel form of that greedy rule.  Only the earliest point of a cell can be effective (a later
+// one is knocked out by it, or by whatever knocked it out).  So: (1) hash every cell to its earliest
+// point index (LDS, atomicMin); (2) relax the undecided cells: a cell whose earlier neighbours are
+// all decided "no" becomes effective, a cell with an effective earlier neighbour is out -- decisions
+// are final, so reading a neighbour's fresh or stale state is equally safe, and the globally
+// earliest undecided cell always resolves, so the loop ends; (3) erase every point
+// that is not the earliest of an effective cell from `cells`.  One block per item.
+struct SelectArgs {
+    int2 *cells;          // [B][max_base][max_n]
+    int32_t max_n, max_base;
+    int32_t z2max;        // largest squared distance whose kernel value is 100
+    int32_t log2cap;      // hash capacity = 1 << log2cap entries (dynamic LDS: 9 bytes per entry)
+    unsigned long long *stamps;
+};
+
+__device__ __forceinline__ unsigned select_key(int x, int y) {
+    return ((unsigned)(y + 32768) << 16) | ((unsigned)(x + 32768) & 0xffffu);
+}
+// The table is open addressing over BUCKETS of four keys (one 16-byte LDS read per probe; a plain
+// linear-probing table made the slowest lane of a wave walk 20-40 slots).  Keys fill a bucket front
+// to back and are never removed, so an empty last slot means "not in this bucket or any later one".
+// slot of `key`, or -1.  bmask = buckets - 1, shift = 32 - log2(buckets).
+__device__ __forceinline__ int select_find(const unsigned *keys, unsigned bmask, int shift, unsigned key) {
+    unsigned bk = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + 4 * bk);
+        if (q.x == key) return (int)(4 * bk);
+        if (q.y == key) return (int)(4 * bk + 1);
+        if (q.z == key) return (int)(4 * bk + 2);
+        if (q.w == key) return (int)(4 * bk + 3);
+        if (q.w == 0u) return -1;
+        bk = (bk + 1u) & bmask;
+    }
+}
+// slot of `key`, inserting it if absent
+__device__ __forceinline__ int select_insert(unsigned *keys, unsigned bmask, int shift, unsigned key) {
+    unsigned bk = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + 4 * bk);
+        int j = (q.x == key || q.x == 0u) ? 0 : (q.y == key || q.y == 0u) ? 1 : (q.z == key || q.z == 0u) ? 2 : (q.w == key || q.w == 0u) ? 3 : 4;
+        for (; j < 4; j++) {
+            const unsigned prev = atomicCAS(&keys[4 * bk + j], 0u, key);
+            if (prev == 0u || prev == key) return (int)(4 * bk + j);
+        }
+        bk = (bk + 1u) & bmask;
+    }
+}
+
+// NB = 5 for z2max = 1 (plus-shaped disc), 9 for z2max = 2
+template <int NB>
+__global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
+    constexpr int NT = 1024, KMAX = 16, NW = (NB - 1) / 4;
+    constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
+    constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
+    extern __shared__ unsigned sel_lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned cap = 1u << a.log2cap, bmask = (cap >> 2) - 1u;
+    const int shift = 32 - (a.log2cap - 2);
+    unsigned *keys = sel_lds;
+    unsigned *minidx = sel_lds + cap;
+    unsigned char *status = reinterpret_cast<unsigned char *>(sel_lds + 2 * cap); // 0 undecided, 1 effective, 2 out
+    YM_STAMP(a, 24);
+    for (unsigned i = tid; i < cap; i += NT) { keys[i] = 0u; minidx[i] = 0xffffffffu; status[i] = 0; }
+    __syncthreads();
+    int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
+    const int total = a.max_base * a.max_n;
+    YM_STAMP(a, 25);
+    // (1) cell -> earliest point index
+    for (int e = tid; e < total; e += NT) {
+        const int2 c = cells[e];
+        if (c.x == YM_CELL_NONE) continue;
+        const int slot = select_insert(keys, bmask, shift, select_key(c.x, c.y));
+        atomicMin(&minidx[slot], (unsigned)e);
+    }
+    __syncthreads();
+    YM_STAMP(a, 26);
+    // (2a) per owned slot (tid + k*NT): the slots of the neighbour cells that hold an EARLIER point,
+    // packed as 16-bit slot numbers (0xffff = none).  A cell with no earlier neighbour is effective.
+    unsigned long long nb[KMAX][NW];
+    unsigned und = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) nb[k][w] = ~0ull;
+        const unsigned s = tid + k * NT;
+        if (s >= cap) continue;
+        const unsigned key = keys[s];
+        if (key == 0u) continue;
+        const unsigned me = minidx[s];
+        const int x = (int)(key & 0xffffu) - 32768, y = (int)(key >> 16) - 32768;
+        bool any = false;
+#pragma unroll
+        for (int n = 1; n < NB; n++) {
+            const int t = select_find(keys, bmask, shift, select_key(x + DX[n], y + DY[n]));
+            if (t >= 0 && minidx[t] < me) {
+                any = true;
+                const int j = n - 1;
+                nb[k][j >> 2] &= ~(0xffffull << (16 * (j & 3)));
+                nb[k][j >> 2] |= (unsigned long long)(unsigned)t << (16 * (j & 3));
+            }
+        }
+        if (any) und |= 1u << k;
+        else status[s] = 1;
+    }
+    YM_STAMP(a, 27);
+    // (2b) asynchronous relaxation, no barriers: every wave keeps re-reading the state of the earlier
+    // neighbours of its undecided cells.  A decision is final and is taken only from final states
+    // (a stale "undecided" read merely delays it), and all 16 waves of the block are resident, so
+    // this terminates with the sequential greedy result whatever the interleaving.
+    unsigned char *vst = status;
+    unsigned wmask = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) wmask |= __ballot((und >> k) & 1u) ? (1u << k) : 0u;
+    while (wmask) {
+        unsigned m = wmask;
+        while (m) {
+            const int k = __builtin_ctz(m); // wave-uniform
+            m &= m - 1;
+            bool still = false;
+            asm volatile("" ::: "memory"); // re-read the states every time
+            if ((und >> k) & 1u) {
+                bool knocked = false, pending = false;
+#pragma unroll
+                for (int j = 0; j < NB - 1; j++) {
+                    const unsigned t = (unsigned)(nb[k][j >> 2] >> (16 * (j & 3))) & 0xffffu;
+                    if (t != 0xffffu) {
+                        const unsigned char stt = vst[t];
+                        knocked |= stt == 1;
+                        pending |= stt == 0;
+                    }
+                }
+                const unsigned s = tid + k * NT;
+                if (knocked) vst[s] = 2;
+                else if (!pending) vst[s] = 1;
+                else still = true;
+                if (!still) und &= ~(1u << k);
+            }
+            if (__ballot(still) == 0ull) wmask &= ~(1u << k);
+        }
+    }
+    __syncthreads();
+    YM_STAMP(a, 28);
+    // (3) keep only the earliest point of every effective cell
+    for (int e = tid; e < total; e += NT) {
+        const int2 c = cells[e];
+        if (c.x == YM_CELL_NONE) continue;
+        const int t = select_find(keys, bmask, shift, select_key(c.x, c.y));
+        if (!(t >= 0 && status[t] == 1 && minidx[t] == (unsigned)e)) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    }
+    YM_STAMP(a, 29);
+}
+
+}  // namespace ym

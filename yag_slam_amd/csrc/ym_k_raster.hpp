@@ -1,0 +1,258 @@
+// ym_k_raster.hpp -- K2 raster_kernel.
+// Part of ym_kernels.hpp (include that, not this file).
+#pragma once
+
+namespace ym {
+
+// ================================================================== K2 raster
+struct RasterArgs {
+    const int2 *cells;
+    const int4 *bbox;     // [B][max_base][ceil(max_n/64)]
+    const YmItemState *states;
+    YmGeom g;
+    uint8_t *grid;        // [B][win_w rows][pitch]
+    size_t grid_stride;   // bytes per item
+    uint8_t *planes;      // [B][2][win_w rows][pitch/2]: plane p holds columns 2*x+p of the window
+    const uint8_t *lut;   // smear kernel value by squared cell distance: lut[dx*dx + dy*dy], 2*h*h + 1 entries
+    int32_t max_n, max_base;
+    uint8_t *tile_zero;   // [B][tiles_y][tiles_x]: 1 = this tile of the window memory is known to hold zeros
+    int32_t tiles_x, tiles_y; // full tiling of the window
+    int32_t tile_x0, tile_y0; // first tile of the launched sub-grid (tiles outside it are known to be zero)
+    int32_t ltx;              // tile columns of the launched sub-grid
+    const uint16_t *tile_list; // [B][tile_cap] work list built by tiles_kernel, or null: one block per sub-grid tile
+    const int32_t *tile_count; // [B]
+    int32_t tile_cap;
+    unsigned long long *stamps;
+};
+
+// grid (launched tiles in x, in y, B), 256 threads.  Each block owns one 64x32 tile of the window and
+// writes every byte of it exactly once (so no separate clear pass exists; a tile that is empty now and
+// whose memory is known to be zero from an earlier call is skipped).  Karto's SmearPoint
+// max-stamps a (2h+1)^2 kernel at every occupied cell; the kernel value depends only on the squared
+// cell distance and never grows with it (checked on the host when the matcher is created), so a
+// cell's final value is lut[min squared distance to an occupied cell inside the (2h+1)^2 window]:
+//   row pass   g(y, x)  = min |dx| <= h with cell (y, x+dx) occupied      (bit scans on a row bitmap)
+//   column pass m(y, x) = min over |dy| <= h of dy^2 + g(y+dy, x)^2        (8 cells per lane)
+// NT = 256: one tile row per thread, shortest latency (single match); NT = 128: two rows per thread, twice the
+// blocks per CU -- the tiles with work are latency-bound, so a batch gains (raster 160 -> 140 us on 256 items)
+template <int NT>
+__global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
+    constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF;
+    constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
+    constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
+    __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
+    __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
+    __shared__ unsigned char lut[2 * HM * HM + 8];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    // grid (tiles of the launched sub-grid, B).  With a work list (batches) block i takes entry i and the blocks
+    // past the list's end leave at once; without one (a few items: one more launch would cost more than it saves)
+    // block i is tile i of the sub-grid and finds out by itself whether any chunk box reaches it.
+    const bool listed = a.tile_list != nullptr;
+    unsigned entry;
+    if (listed) {
+        if ((int)blockIdx.x >= a.tile_count[b]) return;
+        entry = a.tile_list[(size_t)b * a.tile_cap + blockIdx.x];
+    } else {
+        const int sy = (int)blockIdx.x / a.ltx, sx = (int)blockIdx.x - sy * a.ltx;
+        // rotate the tile column by the row: a sub-grid width that is a multiple of 8 would otherwise pin every
+        // tile column (i.e. every wall) to one XCD
+        entry = (unsigned)((a.tile_y0 + sy) * a.tiles_x + a.tile_x0 + (sx + 3 * sy + 5 * b) % a.ltx);
+    }
+    const int tile = (int)(entry & 0x7fffu);
+    const int h = a.g.half_kernel;
+    const int OW = TW + 2 * h, OH = TH + 2 * h;
+    const int tiy = tile / a.tiles_x, tix = tile - tiy * a.tiles_x;
+    const int tx0 = tix * TW, ty0 = tiy * TH;
+    YM_STAMP(a, 4);
+    // candidate chunks: 64 consecutive cells of one base scan whose bounding box touches tile + halo
+    const int n_cchunks = (a.max_n + 63) / 64;
+    const int n_boxes = a.max_base * n_cchunks;
+    const int4 *bbox = a.bbox + (size_t)b * n_boxes;
+    const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
+    uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
+    // thread -> 8 consecutive cells (x8 ..) of tile rows y0, y0 + NT / LPR, ...
+    const int y0 = tid / LPR, x8 = (tid % LPR) * 8;
+    const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
+    uint8_t *planes = a.planes + (size_t)b * a.grid_stride;
+    // the window row-major and its even / odd column planes (v_perm_b32 byte gathers) for 8 cells of tile row y
+    auto store8 = [&](int y, uint32_t p0, uint32_t p1) {
+        if (ty0 + y < a.g.win_w) {
+            *reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8) = make_uint2(p0, p1);
+            uint8_t *pl = planes + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
+            *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+            *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
+        }
+    };
+    auto zero_tile = [&]() {
+        for (int y = y0; y < TH; y += NT / LPR) store8(y, 0u, 0u);
+    };
+    uint8_t *tz = a.tile_zero + ((size_t)b * a.tiles_y + tiy) * a.tiles_x + tix;
+    __shared__ int s_hits[256];
+    __shared__ int s_nhits;
+    if (entry & 0x8000u) { // no chunk reaches this tile, but its memory still holds an earlier call's bytes
+        zero_tile();
+        if (tid == 0) *tz = 1;
+        return;
+    }
+    if (tid == 0) s_nhits = 0;
+    if (!listed) { // decide "no box at all" before touching LDS
+        int my_hits = 0;
+        for (int c = tid; c < n_boxes; c += NT) {
+            const int4 bb = bbox[c];
+            my_hits += (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) ? 1 : 0;
+        }
+        if (__syncthreads_or(my_hits) == 0) {
+            // empty tile: zeros -- unless this memory is already known to be zero from an earlier call
+            if (*tz == 0) {
+                zero_tile();
+                __syncthreads();
+                if (tid == 0) *tz = 1;
+            }
+            return;
+        }
+    } else {
+        __syncthreads();
+    }
+    // chunks whose box touches tile + halo, compacted so that the cell loads of several chunks are in flight together
+    for (int c = tid; c < n_boxes; c += NT) {
+        const int4 bb = bbox[c];
+        if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
+            const int at = atomicAdd(&s_nhits, 1);
+            if (at < 256) s_hits[at] = c;
+        }
+    }
+    for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
+    for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
+    __syncthreads();
+    const int nhits = s_nhits;
+    const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
+    unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
+    int any = 0;
+    if (nhits <= 256) {
+        // work item = (hit chunk, cell of the chunk); 4 items per thread in flight
+        const int nwork = nhits * 64;
+        for (int w0 = 0; w0 < nwork; w0 += 4 * NT) {
+            int2 cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = w0 + u * NT + tid;
+                cc[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+                if (w < nwork) {
+                    const int chunk = s_hits[w >> 6];
+                    const int slot = chunk / n_cchunks, i = (chunk - slot * n_cchunks) * 64 + (w & 63);
+                    if (i < a.max_n) cc[u] = cells[(size_t)slot * a.max_n + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int lx = cc[u].x - lo_x, ly = cc[u].y - lo_y;
+                if (cc[u].x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+                    atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
+                    any = 1;
+                }
+            }
+        }
+    } else {
+        // more hit chunks than the list holds: walk every box (rare)
+        for (int c0 = 0; c0 < n_boxes; c0 += NT) {
+            const int c = c0 + tid;
+            bool hit = false;
+            if (c < n_boxes) {
+                const int4 bb = bbox[c];
+                hit = bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y;
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int bit = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int chunk = c0 + (tid & ~63) + bit; // wave-uniform
+                const int slot = chunk / n_cchunks, ci = chunk - slot * n_cchunks;
+                const int i = ci * 64 + (tid & 63);
+                if (i < a.max_n) {
+                    const int2 c2 = cells[(size_t)slot * a.max_n + i];
+                    const int lx = c2.x - lo_x, ly = c2.y - lo_y;
+                    if (c2.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+                        atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
+                        any = 1;
+                    }
+                }
+            }
+        }
+    }
+    any = __syncthreads_or(any);
+    YM_STAMP(a, 5);
+    if (!any) {
+        if (*tz == 0) {
+            zero_tile();
+            __syncthreads();
+            if (tid == 0) *tz = 1;
+        }
+        return;
+    }
+    if (tid == 0) *tz = 0;
+    // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
+    // Work item = 8 consecutive cells of one (halo) row.  Walls are thin: most 8-cell groups see no bit within
+    // reach at all and leave after one test.
+    const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
+    const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
+    for (int i = tid; i < OH * LPR; i += NT) {
+        const int ry = i / LPR, rx = (i % LPR) * 8;
+        const int w = rx >> 6, sft = rx & 63;
+        const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
+        const unsigned long long sw = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask; // bits rx .. rx + 7 + 2h
+        uint32_t out[2] = {0xffffffffu, 0xffffffffu};
+        if (sw) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const unsigned long long win = (sw >> q) & wmask;
+                if (win) {
+                    const unsigned long long right = win >> h, left = win & lmask;
+                    const int dr = right ? (__ffsll((long long)right) - 1) : 255;
+                    const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
+                    const unsigned g = (unsigned)(dr < dl ? dr : dl);
+                    out[q >> 2] = (out[q >> 2] & ~(0xffu << (8 * (q & 3)))) | (g << (8 * (q & 3)));
+                }
+            }
+        }
+        *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+    }
+    __syncthreads();
+    YM_STAMP(a, 6);
+    // column pass: 8 cells per lane as four pairs of 16-bit lanes (cells 0|2, 1|3, 4|6, 5|7): the candidate
+    // g*g + dy*dy is at most 255^2 + h^2 < 65536, so one v_pk_mad_u16 + one v_pk_min_u16 serve two cells.
+    // A row whose 8 distances are all "none" contributes nothing.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const unsigned max_d2 = (unsigned)(2 * h * h);
+    for (int y = y0; y < TH; y += NT / LPR) {
+        us2 mn2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
+        for (int dy = -h; dy <= h; dy++) {
+            const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + h + dy) * TW + x8]);
+            if ((gg.x & gg.y) == 0xffffffffu) continue;
+            const unsigned short d2 = (unsigned short)(dy * dy);
+            const us2 dd = (us2){d2, d2};
+            const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                us2 gq;
+                __builtin_memcpy(&gq, &u[q], 4);
+                mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 (none) is larger than any real distance
+            }
+        }
+        unsigned mn[8];
+        mn[0] = mn2[0].x; mn[2] = mn2[0].y; mn[1] = mn2[1].x; mn[3] = mn2[1].y;
+        mn[4] = mn2[2].x; mn[6] = mn2[2].y; mn[5] = mn2[3].x; mn[7] = mn2[3].y;
+        uint32_t packed[2] = {0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned v = mn[q] <= max_d2 ? lut[mn[q]] : 0u;
+            packed[q >> 2] |= v << (8 * (q & 3));
+        }
+        store8(y, packed[0], packed[1]);
+    }
+    YM_STAMP(a, 7);
+}
+
+}  // namespace ym

@@ -1,0 +1,237 @@
+// ym_k_yagpy.hpp -- the reference's Python matcher ("yagpy" semantics): yag_setup / yag_score / yag_reduce kernels.
+// Part of ym_kernels.hpp (include that, not this file).
+#pragma once
+
+namespace ym {
+
+// ================================================================== "yagpy" semantics
+// The reference's in-tree Python matcher (/root/reference/yag_slam/helpers.py:156-295 find_best_pose,
+// scan_matching.py:175-222).  Unlike Karto it rounds every (hypothesis, point) pair separately
+// (helpers.py:149-153), so the gather address is recomputed in fp64 per pair; this path exists for
+// parity with the reference-generated golden vectors, not for speed.
+struct YagArgs {
+    YmGeom g;
+    int32_t pass;        // 0 coarse, 1 fine
+    int32_t penalize;
+    int32_t last;        // this pass produces the final result
+    int32_t refine;
+    double search_xy, step_xy, search_t, step_t; // find_best_pose arguments
+    double coarse_angle_res;                     // for th = 4*angle_res when the fine pass is skipped
+    YmItemState *states;
+    YmItemState *host_out;
+    const double2 *qlocal;
+    double *axes;        // [B][3][YM_YAG_MAX_DIM] xvals, yvals, tvals
+    double2 *rot;        // [B][maxt][max_n] points rotated by tvals[k]
+    uint32_t *sums;      // [B][maxt][maxd][maxd] -> stored dense as [k][iy][ix] with the pass's nx, ny
+    double *out;         // same shape, fp64 scores
+    const uint8_t *grid;
+    size_t grid_stride;
+    size_t vol_stride;   // entries per item in sums/out
+    int32_t max_n, maxd, maxt;
+};
+
+// numpy.arange(start, stop, step) for float64: length and i-th value (DOUBLE_fill)
+__device__ __forceinline__ int yag_arange_len(double start, double stop, double step) {
+    const int n = (int)ceil((stop - start) / step);
+    return n < 0 ? 0 : n;
+}
+__device__ __forceinline__ double yag_arange_at(double start, double step, int i) {
+    if (i == 0) return start;
+    const double second = start + step;
+    if (i == 1) return second;
+    return start + i * (second - start);
+}
+
+// grid (maxt, B), 256 threads: block k rotates the points by tvals[k]; block 0 also writes the axes.
+__global__ __launch_bounds__(256) void yag_setup_kernel(YagArgs a) {
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    YmItemState &st = a.states[b];
+    const double cx = a.pass ? st.ybest[0][1] : st.pose[0];
+    const double cy = a.pass ? st.ybest[0][2] : st.pose[1];
+    const double ct = a.pass ? st.ybest[0][3] : st.pose[2];
+    const int nx = min(yag_arange_len(-a.search_xy + cx, a.search_xy + cx, a.step_xy), a.maxd);
+    const int ny = min(yag_arange_len(-a.search_xy + cy, a.search_xy + cy, a.step_xy), a.maxd);
+    const int nt = min(yag_arange_len(-a.search_t + ct, a.search_t + ct, a.step_t), a.maxt);
+    double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
+    if (k == 0) {
+        if (tid == 0) { st.ydims[a.pass][0] = nx; st.ydims[a.pass][1] = ny; st.ydims[a.pass][2] = nt; }
+        for (int i = tid; i < nx; i += 256) ax[i] = yag_arange_at(-a.search_xy + cx, a.step_xy, i);
+        for (int i = tid; i < ny; i += 256) ax[YM_YAG_MAX_DIM + i] = yag_arange_at(-a.search_xy + cy, a.step_xy, i);
+        for (int i = tid; i < nt; i += 256) ax[2 * YM_YAG_MAX_DIM + i] = yag_arange_at(-a.search_t + ct, a.step_t, i);
+    }
+    if (k >= nt) return;
+    const double t = yag_arange_at(-a.search_t + ct, a.step_t, k);
+    const double c = cos(t), s = sin(t);
+    const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+    double2 *rot = a.rot + ((size_t)b * a.maxt + k) * a.max_n;
+    for (int l = tid; l < st.nq; l += 256) { // helpers.py:76-78 _rotate_points
+        const double2 p = ql[l];
+        rot[l] = make_double2(p.x * c - p.y * s, p.y * c + p.x * s);
+    }
+}
+
+// grid (ceil(maxd*maxd/256), maxt, B): one thread per hypothesis (ix, iy) of angle k.
+// helpers.py:134-153: per point rint((p - o)/res), bounds check, int(100*cell) accumulate.
+__global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
+    const int b = blockIdx.z, k = blockIdx.y;
+    const YmItemState &st = a.states[b];
+    const int nx = st.ydims[a.pass][0], ny = st.ydims[a.pass][1], nt = st.ydims[a.pass][2];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nt || c >= nx * ny) return;
+    const int iy = c / nx, ix = c - iy * nx;
+    const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
+    const double xv = ax[ix], yv = ax[YM_YAG_MAX_DIM + iy], tv = ax[2 * YM_YAG_MAX_DIM + k];
+    const double ox = st.off_x, oy = st.off_y, res = a.g.res;
+    const int G = a.g.roi_w, w0 = a.g.win_origin, ww = a.g.win_w, pitch = a.g.pitch;
+    const double2 *__restrict__ rot = a.rot + ((size_t)b * a.maxt + k) * a.max_n;
+    const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+    const int np = st.nq;
+    unsigned sum = 0;
+#pragma unroll 4
+    for (int l = 0; l < np; l++) {
+        const double2 p = rot[l];
+        const double x = xv + p.x, y = yv + p.y;
+        const double gx = rint((x - ox) / res), gy = rint((y - oy) / res);
+        const int _x = (int)gx, _y = (int)gy;
+        if (_x >= 0 && _x < G && _y >= 0 && _y < G) {
+            const int wx = _x - w0, wy = _y - w0;
+            // cells outside the device window are provably empty
+            if (wx >= 0 && wx < ww && wy >= 0 && wy < ww) sum += grid[wy * pitch + wx];
+        }
+    }
+    double penalty_val = 1.0;
+    if (a.penalize) {
+        const double ct = a.pass ? st.ybest[0][3] : st.pose[2];
+        const double sx_ = ox + G * res / 2, sy_ = oy + G * res / 2;
+        const double sd = (xv - sx_) * (xv - sx_) + (yv - sy_) * (yv - sy_);
+        const double dist_penalty = 1.0 - 0.2 * sd / (0.5 * res);
+        const double sa = (tv - ct) * (tv - ct);
+        const double ang_penalty = 1.0 - 0.2 * sa / (1.0 * res);
+        penalty_val = dist_penalty * ang_penalty;
+    }
+    const size_t at = (size_t)b * a.vol_stride + ((size_t)k * ny + iy) * nx + ix;
+    a.sums[at] = sum;
+    a.out[at] = (double)sum / np * penalty_val / 100.0;
+}
+
+// grid (B), 1024 threads: np.argmax (first maximum in the reference's [ix][iy][k] order), mean of
+// all scores >= best - 1e-8, the +-5 covariance windows (helpers.py:214-295).
+__global__ __launch_bounds__(1024) void yag_reduce_kernel(YagArgs a) {
+    constexpr int NT = 1024;
+    __shared__ double scratch[16 * 5];
+    __shared__ double s_v[16];
+    __shared__ int s_f[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    YmItemState &st = a.states[b];
+    const int nx = st.ydims[a.pass][0], ny = st.ydims[a.pass][1], nt = st.ydims[a.pass][2];
+    const int nxy = nx * ny, nh = nxy * nt;
+    const double *out = a.out + (size_t)b * a.vol_stride;
+    const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
+    int status = st.status;
+    if (nh == 0 || st.nq == 0) status = -1; // the reference raises (empty lattice / division by zero points)
+    // ---- arg-max, ties to the lowest index in the reference's flat order f = (ix*ny + iy)*nt + k
+    double bv = -INFINITY;
+    int bf = 0x7fffffff;
+    for (int h = tid; h < nh; h += NT) {
+        const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+        const int f = (ix * ny + iy) * nt + k;
+        const double v = out[h];
+        if (v > bv || (v == bv && f < bf)) { bv = v; bf = f; }
+    }
+    {
+        const double wv = wave_reduce(bv, OpMaxD());
+        const int wf = wave_reduce(bv == wv ? bf : 0x7fffffff, OpMinI());
+        __syncthreads();
+        if (lane == 0) { s_v[wave] = wv; s_f[wave] = wf; }
+        __syncthreads();
+        bv = s_v[0]; bf = s_f[0];
+        for (int w = 1; w < NT / 64; w++)
+            if (s_v[w] > bv || (s_v[w] == bv && s_f[w] < bf)) { bv = s_v[w]; bf = s_f[w]; }
+    }
+    const double response = bv;
+    int ii = 0, jj = 0, kk = 0;
+    if (nh > 0 && bf != 0x7fffffff) { ii = bf / (ny * nt); jj = (bf % (ny * nt)) / nt; kk = (bf % (ny * nt)) % nt; }
+    // ---- mean of the near-maximal hypotheses.  The reference adds them one by one in C order of
+    // out[ix][iy][k] (helpers.py:229-244) and the fine lattice's np.arange LENGTH depends on the last
+    // bits of that mean, so the additions are done in exactly that order: flags in parallel, one
+    // thread walks the set bits.
+    __shared__ unsigned s_bits[8192];
+    __shared__ double s_mean[4];
+    double acc[4] = {0, 0, 0, 0};
+    if (nh <= 8192 * 32) {
+        for (int w = tid; w < (nh + 31) / 32; w += NT) s_bits[w] = 0u;
+        __syncthreads();
+        for (int f = tid; f < nh; f += NT) {
+            const int ix = f / (ny * nt), iy = (f % (ny * nt)) / nt, k = f % nt;
+            if (out[((size_t)k * ny + iy) * nx + ix] >= response - 0.00000001) atomicOr(&s_bits[f >> 5], 1u << (f & 31));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 0; w < (nh + 31) / 32; w++) {
+                unsigned bits = s_bits[w];
+                while (bits) {
+                    const int f = w * 32 + __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    const int ix = f / (ny * nt), iy = (f % (ny * nt)) / nt, k = f % nt;
+                    acc[0] += ax[ix]; acc[1] += ax[YM_YAG_MAX_DIM + iy]; acc[2] += ax[2 * YM_YAG_MAX_DIM + k]; acc[3] += 1.0;
+                }
+            }
+            for (int j = 0; j < 4; j++) s_mean[j] = acc[j];
+        }
+        __syncthreads();
+        for (int j = 0; j < 4; j++) acc[j] = s_mean[j];
+    } else {
+        for (int h = tid; h < nh; h += NT)
+            if (out[h] >= response - 0.00000001) {
+                const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
+                acc[0] += ax[ix]; acc[1] += ax[YM_YAG_MAX_DIM + iy]; acc[2] += ax[2 * YM_YAG_MAX_DIM + k]; acc[3] += 1.0;
+            }
+        block_sum_vec<4>(acc, scratch);
+    }
+    const double bx = acc[0] / acc[3], by = acc[1] / acc[3], bt = acc[2] / acc[3];
+    // ---- +-5 windows
+    const int xs = max(0, ii - 5), ys = max(0, jj - 5), xe = min(nx - 1, ii + 6), ye = min(ny - 1, jj + 6);
+    const int ts = max(0, kk - 5), te = min(nt - 1, kk + 6);
+    double cv[5] = {0, 0, 0, 0, 0}; // XX, YY, XY, norm ; TH handled below
+    const int wxn = max(0, xe - xs), wyn = max(0, ye - ys);
+    for (int w = tid; w < wxn * wyn; w += NT) {
+        const int i_ = xs + w / wyn, j_ = ys + w % wyn;
+        const double r_ = out[((size_t)kk * ny + j_) * nx + i_];
+        const double x_ = ax[i_], y_ = ax[YM_YAG_MAX_DIM + j_];
+        cv[3] += r_;
+        cv[0] += r_ * ((x_ - bx) * (x_ - bx));
+        cv[1] += r_ * ((y_ - by) * (y_ - by));
+        cv[2] += (x_ - bx) * (y_ - by) * r_;
+    }
+    double tw[2] = {0, 0};
+    for (int k_ = ts + tid; k_ < te; k_ += NT) {
+        const double r_ = out[((size_t)k_ * ny + jj) * nx + ii];
+        const double t_ = ax[2 * YM_YAG_MAX_DIM + k_];
+        tw[1] += r_;
+        tw[0] += r_ * ((t_ - bt) * (t_ - bt));
+    }
+    cv[4] = tw[0];
+    block_sum_vec<5>(cv, scratch);
+    double thn[1] = {tw[1]};
+    block_sum_vec<1>(thn, scratch);
+    if (tid == 0) {
+        double *o = st.ybest[a.pass];
+        o[0] = response; o[1] = bx; o[2] = by; o[3] = bt;
+        o[4] = cv[0] / cv[3] / response; o[5] = cv[1] / cv[3] / response; o[6] = cv[2] / cv[3] / response;
+        o[7] = cv[4] / thn[0];
+        st.status = status;
+        if (a.last) {
+            const double *co = st.ybest[0];
+            const double th = a.refine ? o[7] : 4 * a.coarse_angle_res;
+            st.response = o[0];
+            st.coarse_response = 1.0; // no response expansion in the Python path
+            st.mean[0] = o[1]; st.mean[1] = o[2]; st.mean[2] = o[3];
+            st.cov[0] = co[4]; st.cov[1] = co[6]; st.cov[2] = 0.0;
+            st.cov[3] = co[6]; st.cov[4] = co[5]; st.cov[5] = 0.0;
+            st.cov[6] = 0.0; st.cov[7] = 0.0; st.cov[8] = th;
+            if (a.host_out) a.host_out[b] = st;
+        }
+    }
+}
+
+}  // namespace ym
