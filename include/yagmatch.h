@@ -141,7 +141,10 @@ int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *sc
  * poses are read from the scans at every run.  If dev_best_out (nullable, DEVICE pointer to 8
  * doubles) is given, {response, chain_id_base + best chain, x, y, heading, cov_xx, cov_yy, cov_tt} of
  * the best chain is also left on the device, stream-ordered, as the payload of a cross-rank
- * arg-max (RCCL all-gather of one such record per rank). */
+ * arg-max (RCCL all-gather of one such record per rank).  That record is written before Karto's
+ * response expansion (a host-side re-run of the items whose coarse response is 0): when an
+ * expansion took place, ym_batch_wait rewrites it from the final results, so a caller that needs
+ * the post-expansion record waits for the slot before it gathers. */
 typedef struct ym_batch ym_batch;
 ym_batch *ym_batch_create(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans,
                           const int32_t *chain_offsets, int n_chains);

@@ -602,3 +602,59 @@ def test_distinct_matchers_in_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def _sector_scan(scene, pose, index, lo_deg, hi_deg):
+    """a scan that only sees the sector [lo, hi] degrees (sensor frame): every other beam is over-range"""
+    from yag_slam_amd import synth
+    r = scene.scan_ranges(pose, index=index)
+    ang = np.degrees(synth.MIN_ANGLE + np.arange(r.shape[0]) * synth.ANGLE_INCREMENT)
+    r[(ang < lo_deg) | (ang > hi_deg)] = synth.MAX_RANGE + 1.0
+    return _mk_native(PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 20.0, pose))
+
+
+def test_stale_window_bytes_do_not_survive_a_smaller_batch():
+    """Round-1 advisor finding: a call only rasterises (and cleans) items 0..B-1 of the workspace.  Three chains that
+    stamp the EAST of the window, then ONE chain, then three chains that stamp the WEST with the same window geometry:
+    items 1 and 2 still hold the first call's stamps, outside the rectangle the third call's chains can reach.  Every
+    item's grid must equal a fresh matcher's."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    q, _ = cfg2_scans()
+    nq = _mk_native(q)
+    east = [[_sector_scan(scene, (3.0 + 0.05 * i, 3.0 + 0.02 * c, 0.0), 900 + 10 * c + i, -20, 20) for i in range(3)] for c in range(3)]
+    west = [[_sector_scan(scene, (3.0 + 0.05 * i, 3.0 - 0.02 * c, np.pi), 950 + 10 * c + i, -20, 20) for i in range(3)] for c in range(3)]
+    for n_mid in (1, 2):
+        m = ScanMatcher()
+        m.match_scan_batch(nq, east, True, True)
+        m.match_scan_batch(nq, west[:n_mid], True, True) if n_mid > 1 else m.match_scan(nq, west[0], True, True)
+        got = m.match_scan_batch(nq, west, True, True)[0]
+        for i, ch in enumerate(west):
+            fresh = ScanMatcher()
+            want = fresh.match_scan(nq, ch, True, True)
+            g, _ = m.debug_grid(i)
+            fg, _ = fresh.debug_grid(0)
+            assert np.array_equal(g, fg), (n_mid, i, int((g != fg).sum()))
+            assert got[i].response == want.response and got[i].covariance == want.covariance
+            fresh.close()
+        m.close()
+
+
+def test_query_reading_beyond_the_matcher_threshold_is_refused():
+    """Round-1 advisor finding: the device window is cut from Karto's grid, which is sized from the MATCHER's
+    range_threshold.  A query whose own threshold lets a longer reading through points outside it; the fast kernels
+    have no bounds test, so the call must fail loudly (YM_ERR_UNSUPPORTED), never read a neighbour's window."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd._capi import YmError
+    q, base = cfg2_scans()
+    m = ScanMatcher(dict(range_threshold=4.0))
+    far_q = _mk_native(PlainScan(q.ranges, q.min_angle, q.angle_increment, q.min_range, 20.0, (3.0, 3.0, 0.0)))
+    assert np.nanmax(q.ranges) > 4.0
+    nb = [_mk_native(b) for b in base[:3]]
+    with pytest.raises(YmError) as e:
+        m.match_scan(far_q, nb, True, True)
+    assert e.value.code == -4
+    # the same readings gated by the scan's own threshold are fine and match the oracle
+    ok_q = PlainScan(q.ranges, q.min_angle, q.angle_increment, q.min_range, 4.0, (3.0, 3.0, 0.0))
+    compare(dict(range_threshold=4.0), ok_q, base[:3], True, True)

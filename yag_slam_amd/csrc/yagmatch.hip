@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +47,25 @@ bool kt_double_equal_h(double a, double b) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int kAsyncSlots = 64;
+
+// Makes `device` current for the lifetime of the guard and puts the caller's device back afterwards (the caller's
+// thread may be torch code with another current device).
+struct DevGuard {
+    int prev = -1, dev;
+    bool ok = true;
+    explicit DevGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
+#define DEV_GUARD(d)                                                                     \
+    DevGuard dev_guard_(d);                                                              \
+    if (!dev_guard_.ok) return set_err(YM_ERR_HIP, "cannot make device %d current", (d))
 
 template <typename T>
 struct DevBuf {
@@ -123,6 +143,7 @@ struct Slot {
     int n_items = 0;
     int64_t chain_id_base = 0;
     void *dev_best_out = nullptr; // optional device buffer (8 doubles) for the cross-rank arg-max
+    void *dev_best_user = nullptr; // the same pointer, kept until the slot is collected (rewritten after a response expansion)
 };
 
 struct ProfEvents {
@@ -167,8 +188,12 @@ struct ym_matcher {
     DevBuf<uint8_t> grid;
     DevBuf<uint8_t> planes;    // even/odd column planes of every window
     DevBuf<uint8_t> tile_zero; // per raster tile: window memory known to be zero (skips rewriting empty tiles)
-    size_t tz_sig[6] = {0, 0, 0, 0, 0, 0}; // memory/geometry the flags are valid for
-    int dirty_rect[4] = {0, 0, -1, -1};     // tile rectangle (x0, y0, x1, y1) outside which every window is known to be zero
+    size_t tz_sig[5] = {0, 0, 0, 0, 0}; // memory/geometry the flags are valid for
+    // per workspace item: tile rectangle (x0, y0, x1, y1) outside which the item's window memory is known to be zero.
+    // Items [0, tz_covered) have valid flags and rectangles; a call only rasterises (and cleans) items [0, B), so the
+    // state of the items past B must survive it.
+    std::vector<std::array<int, 4>> item_dirty;
+    int tz_covered = 0;
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
@@ -425,6 +450,12 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     }
     for (const CallScan &s : call.scans) P.max_n = std::max(P.max_n, s.n);
     const int max_n = P.max_n, max_base = P.max_base;
+    // Karto sizes its grid from the MATCHER's range threshold; a query reading beyond it points outside that grid,
+    // where GetResponse's linear-index test wraps around Karto's own row pitch.  The fast kernels do no bounds test
+    // (inside the grid none is needed), so such a call is refused instead of answered differently.
+    if (g.semantics == YM_SEM_KARTO && rq > m->cfg.range_threshold)
+        return set_err(YM_ERR_UNSUPPORTED, "query scan holds a valid reading of %g m, beyond the matcher's range_threshold %g", rq,
+                       m->cfg.range_threshold);
     if (max_n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", max_n, YM_MAX_BEAMS);
 
     const bool yag = P.yag = g.semantics == YM_SEM_YAGPY;
@@ -577,24 +608,23 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     int rc;
     // the "tile is already zero" flags describe window MEMORY: they survive from call to call while the buffers and
     // the tiling stay the same, otherwise they are cleared
-    const size_t ntiles = (size_t)B * tiles_x * tiles_y;
-    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, ntiles};
+    const size_t per_item = (size_t)tiles_x * tiles_y, ntiles = (size_t)B * per_item;
+    const size_t sig[5] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w};
     const bool tz_grow = ntiles > m->tile_zero.cap;
     if ((rc = m->tile_zero.ensure(ntiles))) return rc;
     if (tz_grow || std::memcmp(sig, m->tz_sig, sizeof sig) != 0) {
-        // a smaller batch inside the same buffers keeps valid flags for the items it covers; anything else: reset
-        const bool shrink_only = !tz_grow && std::memcmp(sig, m->tz_sig, 5 * sizeof(size_t)) == 0 && ntiles <= m->tz_sig[5];
-        if (!shrink_only) {
-            HIP_TRY(hipMemsetAsync(m->tile_zero.p, 0, m->tile_zero.cap, m->stream));
-            std::memcpy(m->tz_sig, sig, sizeof sig);
-            m->dirty_rect[0] = m->dirty_rect[1] = 0; // unknown memory: next launch covers every tile
-            m->dirty_rect[2] = tiles_x - 1; m->dirty_rect[3] = tiles_y - 1;
-        }
+        std::memcpy(m->tz_sig, sig, sizeof sig);
+        m->tz_covered = 0;
+    }
+    if (B > m->tz_covered) { // items this geometry has not seen yet: unknown memory, every tile is launched once
+        HIP_TRY(hipMemsetAsync(m->tile_zero.p + (size_t)m->tz_covered * per_item, 0, (size_t)(B - m->tz_covered) * per_item, m->stream));
+        m->item_dirty.resize(B);
+        for (int i = m->tz_covered; i < B; i++) m->item_dirty[i] = {0, 0, tiles_x - 1, tiles_y - 1};
+        m->tz_covered = B;
     }
     // Tiles a base point can stamp: rotate every base scan's sensor-frame box into the world, take the union over
-    // the call, convert to window tiles (+ smear halo, + 1 tile of hysteresis).  Only that sub-grid is launched;
-    // it always contains the rectangle that may still hold old non-zero bytes (dirty_rect), otherwise the whole
-    // tiling is launched once.
+    // the call, convert to window tiles (+ smear halo, + 1 tile of hysteresis).  Only that sub-grid is launched,
+    // extended to the rectangles that may still hold old non-zero bytes in any of this call's items.
     int want[4] = {tiles_x, tiles_y, -1, -1};
     for (const CallItem &it : call.items) {
         const CallScan &q = call.scans[it.query];
@@ -618,18 +648,17 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     }
     want[0] = std::max(want[0], 0); want[1] = std::max(want[1], 0);
     want[2] = std::min(want[2], tiles_x - 1); want[3] = std::min(want[3], tiles_y - 1);
+    if (want[2] < want[0] || want[3] < want[1]) { want[0] = tiles_x; want[1] = tiles_y; want[2] = want[3] = -1; } // nothing can be stamped
     int *launch = P.launch;
-    const bool dirty_empty = m->dirty_rect[2] < m->dirty_rect[0] || m->dirty_rect[3] < m->dirty_rect[1];
-    if (want[2] < want[0] || want[3] < want[1]) { // nothing can be stamped: only clean what may be dirty
-        for (int k = 0; k < 4; k++) launch[k] = m->dirty_rect[k];
-    } else if (dirty_empty) {
-        for (int k = 0; k < 4; k++) launch[k] = want[k];
-    } else { // union: covers both the new stamps and the old leftovers
-        launch[0] = std::min(want[0], m->dirty_rect[0]); launch[1] = std::min(want[1], m->dirty_rect[1]);
-        launch[2] = std::max(want[2], m->dirty_rect[2]); launch[3] = std::max(want[3], m->dirty_rect[3]);
+    for (int k = 0; k < 4; k++) launch[k] = want[k];
+    for (int i = 0; i < B; i++) {
+        const std::array<int, 4> &d = m->item_dirty[i];
+        if (d[2] < d[0] || d[3] < d[1]) continue;
+        launch[0] = std::min(launch[0], d[0]); launch[1] = std::min(launch[1], d[1]);
+        launch[2] = std::max(launch[2], d[2]); launch[3] = std::max(launch[3], d[3]);
     }
-    // after this launch only `want` can hold non-zero bytes
-    for (int k = 0; k < 4; k++) m->dirty_rect[k] = want[k];
+    // after this launch only `want` can hold non-zero bytes in the items it covered
+    for (int i = 0; i < B; i++) m->item_dirty[i] = {want[0], want[1], want[2], want[3]};
     if (m->full_raster) { launch[0] = launch[1] = 0; launch[2] = tiles_x - 1; launch[3] = tiles_y - 1; }
     P.ltx = std::max(0, launch[2] - launch[0] + 1);
     P.lty = std::max(0, launch[3] - launch[1] + 1);
@@ -793,7 +822,7 @@ void enqueue_score_and_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
 }
 
 int launch_call(ym_matcher *m, Slot &slot) {
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     CallPlan P;
     int rc;
     if ((rc = plan_sizes(m, slot, P))) return rc;
@@ -882,6 +911,7 @@ int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */)
     // pipeline for the affected items with the wider coarse angle range (rare path).
     const Call base_call = slot.call;
     const int64_t nxy = (int64_t)slot.coarse.nx * slot.coarse.ny;
+    const bool any_redo = !redo.empty();
     double off = m->cfg.coarse_search_angle_offset;
     for (int attempt = 1; attempt <= 3 && !redo.empty(); attempt++) {
         const int64_t prev_hyp = nxy * (int64_t)(kt_round_h(off * 2.0 / m->cfg.coarse_angle_resolution) + 1);
@@ -910,6 +940,18 @@ int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */)
         }
         redo.swap(still);
     }
+    if (any_redo && slot.dev_best_user) {
+        // the record argbest_kernel left on the device predates the expansion: rewrite it from the final results
+        int bi = 0;
+        for (int i = 1; i < B; i++)
+            if (out[i].response > out[bi].response) bi = i;
+        const ym_result &r = out[bi];
+        const double rec[8] = {r.response, (double)(slot.chain_id_base + bi), r.pose[0], r.pose[1], r.pose[2], r.cov[0], r.cov[4], r.cov[8]};
+        DEV_GUARD(m->device);
+        HIP_TRY(hipMemcpyAsync(slot.dev_best_user, rec, sizeof rec, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    slot.dev_best_user = nullptr;
     return YM_OK;
 }
 
@@ -1005,7 +1047,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     m->device = device;
     m->own_stream = nullptr;
     if (build_geometry(m) != YM_OK) { delete m; return nullptr; }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    DevGuard guard(device);
+    if (!guard.ok || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot create a stream on device %d", device);
         delete m;
         return nullptr;
@@ -1029,7 +1072,7 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
 
 void ym_destroy(ym_matcher *m) {
     if (!m) return;
-    (void)hipSetDevice(m->device);
+    DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
@@ -1054,7 +1097,7 @@ int ym_get_config(const ym_matcher *m, ym_config *out) {
 
 int ym_set_stream(ym_matcher *m, void *hip_stream) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->own_stream;
     return YM_OK;
@@ -1062,7 +1105,7 @@ int ym_set_stream(ym_matcher *m, void *hip_stream) {
 
 int ym_synchronize(ym_matcher *m) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     return YM_OK;
 }
@@ -1082,7 +1125,8 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     s->d_ranges = nullptr;
     max_valid_ranges(d->ranges, d->n, d->min_range, d->range_threshold, &s->max_valid_karto, &s->max_valid_yagpy);
     local_bbox(d->ranges, d->n, d->min_angle, d->angle_increment, d->range_threshold, s->lbox);
-    if (hipSetDevice(device) != hipSuccess ||
+    DevGuard guard(device);
+    if (!guard.ok ||
         hipMalloc(reinterpret_cast<void **>(&s->d_ranges), sizeof(double) * std::max(1, d->n)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot allocate device ranges");
         delete s;
@@ -1113,7 +1157,7 @@ int ym_scan_size(const ym_scan *s) { return s ? s->n : YM_ERR_INVALID; }
 
 void ym_scan_destroy(ym_scan *s) {
     if (!s) return;
-    (void)hipSetDevice(s->device);
+    DevGuard guard(s->device);
     if (s->d_ranges) (void)hipFree(s->d_ranges);
     delete s;
 }
@@ -1143,7 +1187,7 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
         if ((rc = check_desc(&base[i]))) return rc;
         total += (size_t)base[i].n;
     }
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     // the staging buffers may still feed an earlier async copy on this stream
     HIP_TRY(hipStreamSynchronize(m->stream));
     if ((rc = m->tmp_ranges.ensure(total + 1))) return rc;
@@ -1247,6 +1291,7 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     call.coarse_angle_off = m->cfg.coarse_search_angle_offset;
     slot.chain_id_base = chain_id_base;
     slot.dev_best_out = dev_best_out;
+    slot.dev_best_user = dev_best_out;
     rc = launch_call(m, slot);
     slot.dev_best_out = nullptr; // a response-expansion re-run must not overwrite the caller's buffer
     return rc;
@@ -1294,7 +1339,7 @@ int ym_debug_grid_info(ym_matcher *m, int item, ym_grid_info *info) {
     info->storage_w = g.storage_w; info->storage_h = g.storage_w;
     info->roi_x = g.border; info->roi_y = g.border; info->roi_w = g.roi_w; info->roi_h = g.roi_w;
     YmItemState s;
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(&s, m->states.p + item, sizeof s, hipMemcpyDeviceToHost));
     info->offset_x = s.off_x; info->offset_y = s.off_y;
@@ -1306,7 +1351,7 @@ int ym_debug_grid(ym_matcher *m, int item, uint8_t *out, int64_t out_bytes) {
     if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
     const int64_t need = (int64_t)m->last_geom.pitch * m->last_geom.win_w;
     if (out_bytes < need) return set_err(YM_ERR_INVALID, "grid buffer too small: need %lld bytes", (long long)need);
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(out, m->grid.p + (size_t)item * m->last_grid_stride, (size_t)need, hipMemcpyDeviceToHost));
     return YM_OK;
@@ -1320,7 +1365,7 @@ int ym_debug_sums(ym_matcher *m, int item, int pass, uint32_t *out, int64_t out_
     const size_t ncopy = std::min(n, (size_t)out_count); // a pass's volume is stored dense from the start of its slot
     if (m->cfg.semantics == YM_SEM_KARTO && (size_t)out_count < n)
         return set_err(YM_ERR_INVALID, "sums buffer too small: need %zu entries", n);
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(out, m->sums.p + m->sums_pass_offset[pass] + (size_t)item * n, ncopy * sizeof(uint32_t),
                       hipMemcpyDeviceToHost));
@@ -1331,7 +1376,7 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
     if (!m || !out_xy || !n) return set_err(YM_ERR_INVALID, "null argument");
     if (!m->last_valid || item < 0 || item >= m->last_B) return set_err(YM_ERR_INVALID, "no such item in the last call");
     YmItemState s;
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(&s, m->states.p + item, sizeof s, hipMemcpyDeviceToHost));
     *n = s.nq;
@@ -1348,7 +1393,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
     const size_t per = (size_t)m->last_max_base * m->last_max_n;
     if (!out) return YM_OK;
     if ((size_t)out_count < per * 2) return set_err(YM_ERR_INVALID, "buffer too small: need %zu ints", per * 2);
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(out, m->cells.p + (size_t)item * per, sizeof(int2) * per, hipMemcpyDeviceToHost));
     return YM_OK;
@@ -1368,7 +1413,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
 
 int ym_debug_stamps(ym_matcher *m, int enable, uint64_t *out, int32_t count) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (out && count > 0)
         HIP_TRY(hipMemcpy(out, m->stamps.p, sizeof(uint64_t) * std::min(count, 32), hipMemcpyDeviceToHost));
@@ -1385,7 +1430,7 @@ int ym_profile_enable(ym_matcher *m, int on) {
 
 int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launches, int reset) {
     if (!m || which < 0 || which > 2) return set_err(YM_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(m->device));
+    DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
     int rc = prof_collect(m);
     if (rc) return rc;

@@ -50,16 +50,29 @@ def all_gather_best(local_record, group=None):
 
 
 class ShardedLoopMatcher(object):
-    """Each rank owns a ScanMatcher on its GPU and a contiguous shard of the candidate chains."""
+    """Each rank owns a ScanMatcher on its GPU and a contiguous shard of the candidate chains.
 
-    def __init__(self, matcher, query, chains, rank, world):
+    The matcher is moved onto torch's current stream: RCCL collectives are ordered against that stream, so the
+    record the arg-best kernel writes is complete before the all-gather reads it (the matcher's own stream is
+    non-blocking and would not be ordered with it).  `stream=False` keeps the matcher's stream (CPU tests with a
+    stand-in matcher)."""
+
+    def __init__(self, matcher, query, chains, rank, world, stream=None):
         self.matcher = matcher
         self.rank, self.world = rank, world
+        self.n_chains = len(chains)
         self.lo, self.hi = shard_range(len(chains), rank, world)
+        if stream is not False:
+            if stream is None:
+                import torch
+                stream = torch.cuda.current_stream().cuda_stream
+            matcher.set_stream(stream)
         self.batch = matcher.make_batch(query, chains[self.lo:self.hi]) if self.hi > self.lo else None
 
     def run_async(self, record, penalty=False, do_fine=False, slot=0):
-        """Enqueue the local shard; `record` (torch float64[RECORD] on this GPU) receives the shard's best."""
+        """Enqueue the local shard; `record` (torch float64[RECORD] on this GPU) receives the shard's best.
+        The record is the one written BEFORE Karto's response expansion (see include/yagmatch.h); `match` below
+        is the form that is exact in that case too."""
         if self.batch is None:
             record.fill_(-1.0)
             return
@@ -67,3 +80,13 @@ class ShardedLoopMatcher(object):
 
     def reduce(self, record, group=None):
         return all_gather_best(record, group)
+
+    def match(self, record, penalty=False, do_fine=False, slot=0, group=None):
+        """The whole loop-closure step: local shard, wait (so that a response expansion has rewritten the record),
+        cross-rank arg-max.  Returns (winner record, gathered records, local per-chain results or None)."""
+        self.run_async(record, penalty, do_fine, slot)
+        per = None
+        if self.batch is not None:
+            per, _, _ = self.batch.wait(slot)
+        win, allrec = self.reduce(record, group)
+        return win, allrec, per

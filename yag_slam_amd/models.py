@@ -82,21 +82,26 @@ class LocalizedRangeScan:
     def _scan(self):
         return self.native(self._native_device or 0)
 
-    # ---- serialisation hooks used by yag-slam's serde (models.py:41-53) -------------------
-    @classmethod
-    def deserialize(cls, args):
-        return cls._deserialize(**args)
+    # ---- map-file hooks: yag-slam's serde rebuilds a scan from its tagged dict (models.py:41-53) ------------
+    _SENSOR_KEYS = ("min_angle", "max_angle", "angle_increment", "min_range", "max_range", "range_threshold")
+
+    @staticmethod
+    def _pose_from_tagged(d):
+        """Transform from a serde dict; the `___name` class tag serde adds is not a constructor argument"""
+        return Transform(**{k: v for k, v in d.items() if not k.startswith("___")})
 
     @classmethod
-    def _deserialize(cls, ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold,
-                     odom_pose, corrected_pose, num):
-        out = cls(ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold, 0, 0, 0)
-        odom_pose = {k: v for k, v in odom_pose.items() if k != "___name"}
-        corrected_pose = {k: v for k, v in corrected_pose.items() if k != "___name"}
-        out.odom_pose = Transform(**odom_pose)
-        out.corrected_pose = Transform(**corrected_pose)
-        out.num = num
-        return out
+    def deserialize(cls, args):
+        sensor = [args[k] for k in cls._SENSOR_KEYS]
+        scan = cls(args["ranges"], *sensor, 0, 0, 0)
+        scan.odom_pose = cls._pose_from_tagged(args["odom_pose"])
+        scan.corrected_pose = cls._pose_from_tagged(args["corrected_pose"])
+        scan.num = args["num"]
+        return scan
+
+    @classmethod
+    def _deserialize(cls, **args):
+        return cls.deserialize(args)
 
     @property
     def num(self):
@@ -145,14 +150,8 @@ class LocalizedRangeScan:
         return point_readings(self.ranges, x, y, t, self.min_angle, self.angle_increment, self.range_threshold)
 
     def copy(self):
-        p = self.corrected_pose
-        return LocalizedRangeScan(self.ranges.copy(), self.min_angle, self.max_angle, self.angle_increment,
-                                  self.min_range, self.max_range, self.range_threshold, p.x, p.y, p.euler[-1])
-
-    @classmethod
-    def from_json(cls, d, x, y, t, invert=True):
-        ranges = d['ranges']
-        if invert:
-            ranges = ranges[::-1]
-        return cls(ranges, d['angle_min'], d['angle_max'], d['angle_increment'], d['range_min'], d['range_max'],
-                   d['range_max'] * 0.9, x, y, t)
+        """A detached scan with the same readings at the corrected pose (graph_slam.py:233 matches a moved copy);
+        it gets its own device twin on first use."""
+        pose = self.corrected_pose
+        sensor = [getattr(self, k) for k in self._SENSOR_KEYS]
+        return type(self)(self.ranges, *sensor, pose.x, pose.y, pose.euler[-1])

@@ -59,9 +59,14 @@ _RESULT_DTYPE = np.dtype([("response", "<f8"), ("pose", "<f8", (3,)), ("cov", "<
 assert _RESULT_DTYPE.itemsize == C.sizeof(_capi.YmResult)
 
 
-def _results(per):
-    """list of ScanMatcherResult from a ctypes array of YmResult, converted column-wise"""
+def _results(per, check=False):
+    """list of ScanMatcherResult from a ctypes array of YmResult, converted column-wise.  check: raise like
+    match_scan does when any chain reports Karto's "unable to find best position / index out of range"."""
     a = np.frombuffer(per, dtype=_RESULT_DTYPE)
+    if check and a["status"].any():
+        bad = int(np.flatnonzero(a["status"])[0])
+        raise _capi.YmError(int(a["status"][bad]), "Mapper FATAL ERROR - unable to find best position / index out of range "
+                            "(chain %d)" % bad)
     resp, pose, cov = a["response"].tolist(), a["pose"].tolist(), a["cov"].reshape(-1, 3, 3).tolist()
     cresp, hyp = a["coarse_response"].tolist(), a["hypotheses"].tolist()
     cd, fd = a["coarse_dims"].tolist(), a["fine_dims"].tolist()
@@ -149,7 +154,7 @@ class ScanMatcher(object):
         bi = C.c_int32(-1)
         _capi.check(self._lib.ym_match_batch(self._m, hq, hs, co, len(chains), int(bool(penalty)), int(bool(do_fine)),
                                              per, C.byref(best), C.byref(bi)))
-        return _results(per), int(bi.value)
+        return _results(per, check=True), int(bi.value)
 
     def make_batch(self, query, chains):
         """Reusable (query, chains) batch for the pipelined loop-closure path."""
@@ -281,7 +286,7 @@ class MatchBatch(object):
         best = _capi.YmResult()
         bi = C.c_int32(-1)
         _capi.check(self.m._lib.ym_batch_wait(self.m._m, int(slot), per, C.byref(best), C.byref(bi)))
-        return (_results(per) if per_chain else None), _result(best), int(bi.value)
+        return (_results(per, check=True) if per_chain else None), _result(best), int(bi.value)
 
 
 # names the reference exports (scan_matching.py:32,224)
