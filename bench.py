@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- pose hypotheses/sec of the MI355X correlative scan matcher.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "cfg2"): 1081-beam synthetic scans, search 0.5 m / 0.349 rad,
-resolution 0.01 m, coarse + fine pass with the odometry penalty.  One STEP = one enqueue of a batch
-of `--batch` independent single-match problems of that exact configuration (one query against
-`--batch` candidate 10-scan chains, each with its own correlation grid, coarse + fine search,
-covariances), all inputs resident in HBM.  With N GPUs every rank runs its own shard of
-`--batch` chains per step (weak scaling) and the ranks exchange their best (response, pose) with one
-RCCL all-gather per step.  `value` = lattice points scored by all ranks / wall time of K steps.
+With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, as a child process, before anything here
+touches the GPU) and relays rank 0's JSON line; under torch.distributed.run it is a rank.
+
+The metric line (BASELINE.json configs[1], "cfg2"): 1081-beam synthetic scans, search 0.5 m / 0.349 rad,
+resolution 0.01 m, coarse + fine pass with the odometry penalty, Karto semantics.  One STEP = one pass of the hot
+path over a batch of `--batch` independent single-match problems of that exact configuration (one query against
+`--batch` distinct candidate 10-scan chains, each with its own correlation grid, coarse + fine search, covariances),
+issued as enqueues of `--launch-batch` problems, all inputs resident in HBM.  With N GPUs every rank runs its own
+batch per step (weak scaling) and the ranks exchange their best (response, pose) records with one RCCL all-gather
+per step.  `value` = lattice points scored by all ranks / wall time of K steps.
+
+`config.by_config` carries the other BASELINE configs measured in the same run: cfg1 (CPU oracle), cfg2 as ONE
+unbatched match_scan call, cfg3 (2000-scan sequential mapping), cfg4 (1 query vs 4096 distinct chains, the chains
+sharded over the ranks = strong scaling, RCCL arg-max), cfg5 (stress lattice).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,32 +32,56 @@ sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STRESS_CONFIG = dict(search_size=2.0, resolution=0.005, coarse_search_angle_offset=0.785)  # BASELINE configs[4]
+CFG3_SCANS = 2000
+CFG4_CHAINS = 4096
 
 
-def build_inputs(batch, rank):
-    """cfg2 scans: one query at the odometry prior, `batch` chains of 10 base scans.  Chain c uses
-    the cfg2 poses with its own noise seeds so every item rasterises a different grid."""
-    from yag_slam_amd import synth
-    from yag_slam_amd.models import LocalizedRangeScan
-    scene = synth.Scene()
-    base_poses, q_truth, q_prior = synth.single_match_poses()
-    mk = lambda r, p: LocalizedRangeScan(r, synth.MIN_ANGLE, synth.MAX_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE,
-                                         synth.MAX_RANGE, synth.RANGE_THRESHOLD, p[0], p[1], p[2])
-    query = mk(scene.scan_ranges(q_truth, index=10), q_prior)
-    exact = [scene.cast(*p) for p in base_poses]
-    chains = []
-    for c in range(batch):
-        rng = np.random.default_rng(100000 * (rank + 1) + c)
-        chains.append([mk(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
-    return query, chains
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8192, help="independent cfg2 matches per step per GPU")
+    ap.add_argument("--launch-batch", type=int, default=256, help="matches per enqueue (workspace size)")
+    ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg4-chains", type=int, default=CFG4_CHAINS)
+    ap.add_argument("--cfg3-scans", type=int, default=CFG3_SCANS)
+    ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
+    ap.add_argument("--corr-chunks", type=int, default=0, help="development: beam chunks per angle in the correlate kernel")
+    ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
+    ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
+    return ap.parse_args(argv)
 
 
-def traffic_bytes(batch):
-    """HBM bytes per correlate launch from the PMC pass recorded under profiles/ (FETCH_SIZE with the gfx950
-    x2 correction of MI355X_MICROARCH.md); only valid for the batch size it was measured at."""
+def self_launch(args):
+    """`python bench.py --gpus N` as a plain command: run the N ranks as a CHILD process (this process has not touched
+    the GPU, and never will), relay the JSON line, return the child's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return p.returncode if line is not None or p.returncode != 0 else 1
+
+
+def profile_json(name):
     try:
-        t = json.load(open(os.path.join(REPO, "profiles", "traffic_correlate.json")))
-        return t["hbm_bytes_per_launch"] if int(t["batch"]) == int(batch) else None
+        return json.load(open(os.path.join(REPO, "profiles", name)))
     except Exception:
         return None
 
@@ -85,36 +117,215 @@ def cpu_baseline(seconds=6.0):
         arr = [b[0] for b in bs]
         r = o.match_raw(qs, arr, True, True)
         n, t0 = 0, time.perf_counter()
+        serial = 0.0
         while time.perf_counter() - t0 < seconds:
             o.match_raw(qs, arr, True, True)
+            serial += o.last_serial_seconds()
             n += 1
         dt = time.perf_counter() - t0
-        out[label] = dict(hyp_per_s=n * r.hypotheses / dt, matches=n, seconds=dt, threads=threads)
+        out[label] = dict(hyp_per_s=n * r.hypotheses / dt, matches=n, seconds=dt, threads=threads,
+                          serial_fraction=serial / dt, ms_per_match=dt / n * 1e3)
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="independent cfg2 matches per step per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
-    ap.add_argument("--corr-chunks", type=int, default=0, help="development: beam chunks per angle in the correlate kernel")
-    ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
-    ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ inputs
+def generate_inputs(args, rank, world, legs):
+    """Every range array the run needs, generated on the host BEFORE the GPU is touched (fork pool)."""
+    from yag_slam_amd import dist as ymdist
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    workers = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
+    out = {"scene": scene}
+    if "cfg2x" in legs or "single" in legs:
+        base_poses, q_truth, q_prior = synth.single_match_poses()
+        exact = [scene.cast(*p) for p in base_poses]
+        n = args.batch if "cfg2x" in legs else 1
+        noisy = []
+        for c in range(n):  # chain c: the cfg2 poses with its own noise seeds, so every item rasterises a different grid
+            rng = np.random.default_rng(100000 * (rank + 1) + c)
+            noisy.append([e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape) for e in exact])
+        out["cfg2"] = (scene.scan_ranges(q_truth, index=10), q_prior, base_poses, noisy)
+    if "cfg3" in legs and rank == 0:
+        out["cfg3"] = synth.scan_ranges_many(synth.trajectory_jobs(args.cfg3_scans), scene, workers)
+    if "cfg4" in legs:
+        lo, hi = ymdist.shard_range(args.cfg4_chains, rank, world)
+        out["cfg4"] = (lo, hi, synth.scan_ranges_many(synth.loop_batch_jobs(args.cfg4_chains, lo, hi, scene=scene), scene, workers))
+    return out
 
-    import torch
+
+# ------------------------------------------------------------------------------------------------ legs
+def leg_single(m, query, chain, hyp_per_match):
+    """cfg2 as the reference runs it: ONE match_scan call, no batching"""
+    n1 = 300
+    for _ in range(20):
+        m.match_scan(query, chain, True, True)
+    t1 = time.perf_counter()
+    for _ in range(n1):
+        m.match_scan(query, chain, True, True)
+    sync_s = (time.perf_counter() - t1) / n1
+    t1 = time.perf_counter()
+    for i in range(n1):
+        if i >= 8:
+            m.wait(i % 8)
+        m.match_scan_async(query, chain, True, True, slot=i % 8)
+    for sl in range(8):
+        m.wait(sl)
+    pipe_s = (time.perf_counter() - t1) / n1
+    return {"lattice": "26x26x21 + 3x3x11", "hypotheses_per_match": hyp_per_match,
+            "sync_us_per_match": sync_s * 1e6, "pipelined_us_per_match": pipe_s * 1e6,
+            "scan_matches_per_s": 1.0 / sync_s, "hypotheses_per_s": hyp_per_match / sync_s,
+            "scan_matches_per_s_pipelined": 1.0 / pipe_s, "hypotheses_per_s_pipelined": hyp_per_match / pipe_s}
+
+
+def leg_cfg3(m, ranges, n):
+    """BASELINE configs[2]: n scans through the call pattern of GraphSlam.process_scan (running chain of 10, grid
+    rebuilt at every step), every scan resident; wall time includes the Python driver."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    truth, scans = synth.trajectory_scans(n, ranges=ranges)
+    for s in scans:
+        s.native(m.device)
+    mapper = SequentialMapper(m)
+    hyp = 0
+    t0 = time.perf_counter()
+    for s in scans:
+        res = mapper.process_scan(s)
+        if res is not None:
+            hyp += res.meta["hypotheses"]
+    dt = time.perf_counter() - t0
+    err = np.array([[s.corrected_pose.x - t[0], s.corrected_pose.y - t[1]] for s, t in zip(scans, truth)])
+    return {"scans": n, "seconds": dt, "scan_matches_per_s": (n - 1) / dt, "hypotheses_per_s": hyp / dt,
+            "hypotheses": hyp, "max_position_error_m": float(np.hypot(err[:, 0], err[:, 1]).max())}
+
+
+def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
+    """BASELINE configs[3]: one query against 4096 distinct candidate chains (loop config, penalty off, coarse only,
+    /root/reference/yag_slam/graph_slam.py:217-220), the chains sharded over the ranks, RCCL arg-max of the best."""
+    from yag_slam_amd import dist as ymdist
+    from yag_slam_amd import synth
+    lo, hi, ranges = gen["cfg4"]
+    query, chains = synth.loop_batch_scans(args.cfg4_chains, lo, hi, scene=gen["scene"], ranges=ranges)
+    for ch in chains:
+        for s in ch:
+            s.native(loop_m.device)
+    sh = ymdist.ShardedLoopMatcher.from_local_shard(loop_m, query, chains, lo, args.cfg4_chains, rank, world)
+    reps = 6
+    records = torch.zeros((reps, ymdist.RECORD), dtype=torch.float64, device="cuda")
+    gathered = torch.zeros((reps, world * ymdist.RECORD), dtype=torch.float64, device="cuda")
+
+    def once(r):
+        sh.run_async(records[r], False, False, slot=r)
+        if dist is not None:
+            return dist.all_gather_into_tensor(gathered[r], records[r], async_op=True)
+        gathered[r].copy_(records[r])
+        return None
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # exact form once (per-chain results, response expansion folded in), for the check and the one-shot latency
+    sync()
+    t0 = time.perf_counter()
+    win, allrec, per = sh.match(records[0], False, False, slot=0)
+    sync()
+    one_shot = time.perf_counter() - t0
+    hyp_local = sum(p.meta["hypotheses"] for p in per) if per else 0
+    local_best = None
+    if per:
+        resp = np.array([p.response for p in per])
+        local_best = (float(resp.max()), lo + int(np.argmax(resp)))
+    # pipelined repetitions
+    w = once(0)
+    if sh.batch is not None:
+        sh.batch.wait(0, per_chain=False)
+    if w is not None:
+        w.wait()
+    sync()
+    t0 = time.perf_counter()
+    works = [once(r) for r in range(reps)]
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    for r in range(reps):
+        if sh.batch is not None:
+            sh.batch.wait(r, per_chain=False)
+        if works[r] is not None:
+            works[r].wait()
+    t = torch.tensor([dt, float(hyp_local)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, hyp_total = float(tmax[0].item()), float(t[1].item())
+    else:
+        hyp_total = float(hyp_local)
+    g = gathered[reps - 1].view(world, ymdist.RECORD).cpu().numpy()
+    wi = ymdist.pick_best(g)
+    winner = {"chain": int(g[wi, 1]), "response": float(g[wi, 0]), "pose": [float(v) for v in g[wi, 2:5]]}
+    if local_best is not None and world == 1:
+        assert winner["chain"] == local_best[1] and winner["response"] == local_best[0], (winner, local_best)
+    assert float(win[1].item()) == g[wi, 1]
+    return {"chains": args.cfg4_chains, "chains_per_gpu": hi - lo, "lattice": "41x41x21", "scaling": "strong",
+            "ms_per_query": dt * 1e3, "one_shot_ms_incl_results": one_shot * 1e3,
+            "chain_matches_per_s": args.cfg4_chains / dt, "hypotheses_per_s": hyp_total / dt,
+            "hypotheses": hyp_total, "winner": winner,
+            "collective": "all_gather of one 64-byte best record per rank" if world > 1 else "none"}
+
+
+def leg_cfg5(device, query, chain):
+    """BASELINE configs[4]: the stress lattice (search 2.0 m at 0.005 m, +-0.785 rad) as one match"""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    m = ScanMatcher(STRESS_CONFIG, device=device)
+    r = m.match_scan(query, chain, True, True)
+    for _ in range(3):
+        m.match_scan(query, chain, True, True)
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.match_scan(query, chain, True, True)
+    dt = (time.perf_counter() - t0) / n
+    m.profile(True)
+    for _ in range(10):
+        m.match_scan(query, chain, True, True)
+    corr_ms, corr_n = m.profile_read(0)
+    m.profile(False)
+    cd, nq = r.meta["coarse_dims"], r.meta["n_query_points"]
+    corr_s = corr_ms / max(corr_n, 1) * 1e-3
+    alg = cd[0] * cd[1] * cd[2] * nq
+    out = {"lattice": "%dx%dx%d + %dx%dx%d" % (tuple(cd) + tuple(r.meta["fine_dims"])),
+           "hypotheses_per_match": r.meta["hypotheses"], "us_per_match": dt * 1e6, "scan_matches_per_s": 1.0 / dt,
+           "hypotheses_per_s": r.meta["hypotheses"] / dt, "correlate_kernel_us": corr_s * 1e6,
+           "correlate_algorithmic_GBps": alg / corr_s / 1e9, "correlate_frac_of_hbm_peak": alg / corr_s / 1e9 / HBM_PEAK_GBS}
+    m.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    legs = set(args.only.split(",")) if args.only else {"cfg2x", "single", "cfg3", "cfg4", "cfg5", "cpu"}
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
+    args.batch = max(args.launch_batch, args.batch // args.launch_batch * args.launch_batch)
+
+    gen = generate_inputs(args, rank, world, legs)  # host only; fork pool; nothing has touched the GPU yet
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libyagmatch has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # one explicit stream for everything (matcher launches, RCCL, copies).  Not torch's default stream: that is the null
+    # stream, whose handle (0) means "the matcher's own stream" to ym_set_stream.
+    torch.cuda.set_stream(torch.cuda.Stream())
     dist = None
     if world > 1 or os.environ.get("YM_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path with one rank
         import torch.distributed as dist
@@ -122,6 +333,7 @@ def main():
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline leg: no spinning OpenMP workers
     from yag_slam_amd import dist as ymdist
+    from yag_slam_amd import synth
     from yag_slam_amd.scan_matching import ScanMatcher
 
     m = ScanMatcher(None, device=local_rank)
@@ -135,28 +347,6 @@ def main():
         m.debug_option(5, args.corr_chunks)
     if args.corr_pad_lds:
         m.debug_option(4, args.corr_pad_lds)
-    query, chains = build_inputs(args.batch, rank)
-    batch = m.make_batch(query, chains)
-    nslots = 8  # result slots cycled by the pipelined loop (all touched during warm-up)
-    records = torch.zeros((nslots, ymdist.RECORD), dtype=torch.float64, device="cuda")
-    gathered = torch.zeros((nslots, world * ymdist.RECORD), dtype=torch.float64, device="cuda")
-    works = [None] * nslots
-
-    def step(i):
-        s = i % nslots
-        if i >= nslots:
-            batch.wait(s, per_chain=False)  # recycle the slot (long since finished)
-        if works[s] is not None:
-            works[s].wait()                 # its gathered records are about to be overwritten
-        batch.run_async(True, True, slot=s, chain_id_base=rank * args.batch, dev_best_out=records[s].data_ptr())
-        if dist is not None:
-            # cross-rank arg-max payload: one 64-byte record per rank.  Asynchronous: RCCL's stream waits for this
-            # step's record, the launch stream goes straight on to the next step
-            works[s] = dist.all_gather_into_tensor(gathered[s], records[s], async_op=True)
-
-    def drain(n):
-        for s in range(min(n, nslots)):
-            batch.wait(s, per_chain=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -164,116 +354,169 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # correctness of what is timed: first step against the single-call path
-    per, best, bi = (batch.run_async(True, True, slot=0) or batch.wait(0))
-    hyp_per_match = per[0].meta["hypotheses"]
-    hyp_step = sum(p.meta["hypotheses"] for p in per)
-    ref = m.match_scan(query, chains[0], True, True)
-    assert ref.response == per[0].response and ref.covariance == per[0].covariance
+    line = {"metric": "pose hypotheses/sec", "value": None, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic", "config": {}, "roofline": None}
+    by_config = {}
 
-    for i in range(args.warmup):
-        step(i)
-    drain(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    drain(args.steps)
-    if dist is not None:  # the last step's gather carries this rank's own record in its place
-        s_last = (args.steps - 1) % nslots
-        assert torch.equal(gathered[s_last].view(world, ymdist.RECORD)[rank], records[s_last])
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    query = chains = None
+    if "cfg2" in gen:
+        q_ranges, q_prior, base_poses, noisy = gen["cfg2"]
+        query = synth.resident_scan(q_ranges, q_prior)
+        chains = [[synth.resident_scan(r, p) for r, p in zip(ch, base_poses)] for ch in noisy]
+        for ch in chains:
+            for s in ch:
+                s.native(local_rank)
 
-    # roofline of the dominant kernel (coarse correlate): HIP events on the launch stream, second pass
-    m.profile(True)
-    for i in range(min(args.steps, 50)):
-        step(i)
-    drain(min(args.steps, 50))
-    corr_ms, corr_n = m.profile_read(0)
-    call_ms, call_n = m.profile_read(2)
-    m.profile(False)
+    # ---------------------------------------------------------------- the metric line: cfg2 x batch
+    if "cfg2x" in legs:
+        LB = args.launch_batch
+        E = args.batch // LB  # enqueues per step
+        batches = [m.make_batch(query, chains[e * LB:(e + 1) * LB]) for e in range(E)]
+        nslots = min(64, 2 * E)
+        nbuf = 2
+        records = torch.zeros((nbuf, E, ymdist.RECORD), dtype=torch.float64, device="cuda")
+        gathered = torch.zeros((nbuf, world * E * ymdist.RECORD), dtype=torch.float64, device="cuda")
+        works = [None] * nbuf
+        used = [None] * nslots  # which batch object a slot's call belongs to
+        counter = [0]
 
-    # the same problem as ONE match_scan call (BASELINE configs[1] as the reference runs it: no batching), for reference
-    single = None
-    if rank == 0:
-        torch.cuda.synchronize()
-        n1 = 300
-        for _ in range(20):
-            m.match_scan(query, chains[0], True, True)
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            m.match_scan(query, chains[0], True, True)
-        sync_s = (time.perf_counter() - t1) / n1
-        t1 = time.perf_counter()
-        for i in range(n1):
-            if i >= 8:
-                m.wait(i % 8)
-            m.match_scan_async(query, chains[0], True, True, slot=i % 8)
-        for sl in range(8):
-            m.wait(sl)
-        pipe_s = (time.perf_counter() - t1) / n1
-        single = {"sync_us_per_match": sync_s * 1e6, "pipelined_us_per_match": pipe_s * 1e6,
-                  "hypotheses_per_s_sync": hyp_per_match / sync_s, "hypotheses_per_s_pipelined": hyp_per_match / pipe_s}
+        def step(i):
+            b = i % nbuf
+            if works[b] is not None:
+                works[b].wait()  # its gathered records are about to be overwritten
+                works[b] = None
+            for e in range(E):
+                s = counter[0] % nslots
+                counter[0] += 1
+                if used[s] is not None:
+                    used[s].wait(s, per_chain=False)  # recycle the slot (long since finished)
+                batches[e].run_async(True, True, slot=s, chain_id_base=rank * args.batch + e * LB,
+                                     dev_best_out=records[b, e].data_ptr())
+                used[s] = batches[e]
+            if dist is not None:
+                # cross-rank arg-max payload: E 64-byte records per rank.  Asynchronous: RCCL's stream waits for this
+                # step's records, the launch stream goes straight on to the next step
+                works[b] = dist.all_gather_into_tensor(gathered[b], records[b].view(-1), async_op=True)
 
-    if rank == 0:
+        def drain():
+            for s in range(nslots):
+                if used[s] is not None:
+                    used[s].wait(s, per_chain=False)
+                    used[s] = None
+            for b in range(nbuf):
+                if works[b] is not None:
+                    works[b].wait()
+                    works[b] = None
+
+        # correctness of what is timed: first enqueue against the single-call path
+        per, best, bi = (batches[0].run_async(True, True, slot=0) or batches[0].wait(0))
+        hyp_per_match = per[0].meta["hypotheses"]
+        assert all(p.meta["hypotheses"] == hyp_per_match for p in per)
+        hyp_step = hyp_per_match * args.batch
+        ref = m.match_scan(query, chains[0], True, True)
+        assert ref.response == per[0].response and ref.covariance == per[0].covariance
+
+        for i in range(args.warmup):
+            step(i)
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:  # the last step's gather carries this rank's own records in their place
+            b_last = (args.steps - 1) % nbuf
+            works[b_last].wait()
+            got = gathered[b_last].view(world, E, ymdist.RECORD)[rank]
+            assert torch.equal(got, records[b_last])
+        drain()
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+        # roofline of the dominant kernel (coarse correlate): HIP events on the launch stream, second pass
+        m.profile(True)
+        for i in range(min(args.steps, 4)):
+            step(i)
+        drain()
+        corr_ms, corr_n = m.profile_read(0)
+        call_ms, call_n = m.profile_read(2)
+        m.profile(False)
+
         nq = per[0].meta["n_query_points"]
         cd = per[0].meta["coarse_dims"]
-        coarse_hyp_launch = args.batch * cd[0] * cd[1] * cd[2]
-        alg_bytes = coarse_hyp_launch * nq  # 1 grid byte per valid beam per hypothesis
+        alg_bytes = LB * cd[0] * cd[1] * cd[2] * nq  # 1 grid byte per valid beam per coarse hypothesis
         corr_s = corr_ms / max(corr_n, 1) * 1e-3
         achieved = alg_bytes / corr_s / 1e9
-        total_hyp = hyp_step * world * args.steps
-        line = {
-            "metric": "pose hypotheses/sec",
-            "value": total_hyp / dt,
-            "unit": "hypotheses/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": "cfg2 x batch: %d independent single-match problems per step per GPU (1081-beam query vs "
-                            "10-scan chain, search 0.5 m / 0.349 rad, resolution 0.01, coarse 26x26x21 + fine 3x3x11, "
-                            "penalty on), Karto semantics" % args.batch,
-                "batch_per_gpu": args.batch,
-                "hypotheses_per_match": hyp_per_match,
-                "scan_matches_per_s": args.batch * world * args.steps / dt,
-                "collective": "all_gather of one 64-byte best record per rank per step" if world > 1 else "none",
-                "single_match": single,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "ym::correlate_kernel<2, 16>",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_bytes(args.batch),
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_us": corr_s * 1e6,
-                "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
-            },
+        ms_per_step = dt / args.steps * 1e3
+        line["value"] = hyp_step * world * args.steps / dt
+        line["ms_per_step"] = ms_per_step
+        line["config"] = {
+            "workload": "cfg2 x batch: %d independent single-match problems per step per GPU (1081-beam query vs distinct "
+                        "10-scan chains, search 0.5 m / 0.349 rad, resolution 0.01, coarse 26x26x21 + fine 3x3x11, penalty "
+                        "on), Karto semantics, issued as %d enqueues of %d" % (args.batch, E, LB),
+            "batch_per_gpu": args.batch, "launch_batch": LB, "hypotheses_per_match": hyp_per_match,
+            "scan_matches_per_s": args.batch * world * args.steps / dt,
+            "timed_seconds": dt,
+            "collective": "all_gather of %d 64-byte best records per rank per step" % E if world > 1 else "none",
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run item
-            cb = cpu_baseline()
-            line["cpu_baseline"] = {
-                "value": cb["single"]["hyp_per_s"], "unit": "hypotheses/s", "cores": 1, "kind": "port",
-                "sample": "%d cfg2 matches (coarse+fine, penalty) in %.1f s, oracle/ym_oracle.c karto semantics, "
-                          "-O3 -march=native, 1 thread" % (cb["single"]["matches"], cb["single"]["seconds"]),
-                "host": {"cpu_model": cpu_model(), "logical_cpus": os.cpu_count() or 1},
-                "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
-                              "sample": "%d matches in %.1f s, OpenMP over the coarse lattice (grid clear and rasterisation stay serial, as in Karto), host has %d cores" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
-            }
+        traffic = profile_json("traffic_correlate.json")
+        l1 = profile_json("l1_correlate.json")
+        step_alg = hyp_step * nq  # coarse + fine lattice points x one byte per valid beam
+        line["roofline"] = {
+            "bound": "hbm", "kernel": "ym::correlate_kernel<2, 16>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic and int(traffic.get("batch", 0)) == LB else None,
+            "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": corr_s * 1e6,
+            "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
+            # the whole step against the same roof: every kernel of the call, launch gaps and host work included
+            "frac_step": step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # what actually binds the kernel (its grid bands live in L2): the vector L1's lane-access rate
+            "l1_lane_access_rate": l1,
+        }
+        del batches
+
+    if dist is not None:
+        dist.barrier()
+
+    # ---------------------------------------------------------------- the other BASELINE configs, same run
+    if "single" in legs and rank == 0:
+        r1 = m.match_scan(query, chains[0], True, True)
+        by_config["cfg2_single_match"] = leg_single(m, query, chains[0], r1.meta["hypotheses"])
+    if "cfg3" in legs and rank == 0:
+        by_config["cfg3_sequential_mapping"] = leg_cfg3(m, gen["cfg3"], args.cfg3_scans)
+    if "cfg5" in legs and rank == 0:
+        q5, b5 = synth.single_match_scans(gen["scene"])
+        by_config["cfg5_stress"] = leg_cfg5(local_rank, q5, b5)
+    if "cfg4" in legs:
+        loop_m = ScanMatcher(None, loop=True, device=local_rank)
+        c4 = leg_cfg4(loop_m, gen, args, rank, world, torch, dist)
+        if rank == 0:
+            by_config["cfg4_loop_closure_batch"] = c4
+        loop_m.close()
+    if "cpu" in legs and rank == 0 and world == 1:  # the CPU baseline is a single-GPU-run item
+        cb = cpu_baseline()
+        line["cpu_baseline"] = {
+            "value": cb["single"]["hyp_per_s"], "unit": "hypotheses/s", "cores": 1, "kind": "port",
+            "sample": "%d cfg2 matches (coarse+fine, penalty) in %.1f s, oracle/ym_oracle.c karto semantics, "
+                      "-O3 -march=native, 1 thread" % (cb["single"]["matches"], cb["single"]["seconds"]),
+            "host": {"cpu_model": cpu_model(), "logical_cpus": os.cpu_count() or 1},
+            "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
+                          "serial_fraction": cb["all"]["serial_fraction"],
+                          "sample": "%d matches in %.1f s, OpenMP over the coarse lattice; grid clear and rasterisation "
+                                    "stay serial as in Karto (serial_fraction = their share of the wall time), host has "
+                                    "%d logical cpus" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
+        }
+        by_config["cfg1_cpu_single_match"] = {
+            "ms_per_match": cb["single"]["ms_per_match"], "scan_matches_per_s": 1e3 / cb["single"]["ms_per_match"],
+            "hypotheses_per_s": cb["single"]["hyp_per_s"], "what": "oracle/ym_oracle.c, karto semantics, 1 thread"}
+    if rank == 0:
+        line["config"]["by_config"] = by_config
+        if line["value"] is None:  # a development run of single legs: not a metric line
+            line["metric"] = "partial run (--only %s)" % args.only
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

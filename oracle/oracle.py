@@ -114,6 +114,8 @@ def load(path=None):
     lib.orc_responses.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
     lib.orc_raster_points.restype = C.POINTER(C.c_double)
     lib.orc_raster_points.argtypes = [C.c_void_p, ip]
+    lib.orc_last_serial_seconds.restype = C.c_double
+    lib.orc_last_serial_seconds.argtypes = [C.c_void_p]
     lib.orc_query_local.restype = C.POINTER(C.c_double)
     lib.orc_query_local.argtypes = [C.c_void_p, ip]
     dp = C.POINTER(C.c_double)
@@ -193,6 +195,9 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(self.lib.orc_last_error().decode())
         return res
+
+    def last_serial_seconds(self):
+        return float(self.lib.orc_last_serial_seconds(self.ctx))
 
     def match_scan(self, query, base_scans, penalty=True, do_fine=True):
         """Duck-typed scans in, dict out."""

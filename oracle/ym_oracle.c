@@ -8,12 +8,14 @@
  * "karto" functions cite the open_karto function they restate (source not in /root/reference;
  * reached by the reference through karto_scanmatcher==1.0.0, /root/reference/setup.py:46).
  */
+#define _POSIX_C_SOURCE 199309L
 #include "ym_oracle.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -25,6 +27,12 @@
 #define DISTANCE_PENALTY_GAIN 0.2
 #define ANGLE_PENALTY_GAIN 0.2
 #define GRID_OCCUPIED 100
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
 
 static char g_err[256];
 const char *orc_last_error(void) { return g_err; }
@@ -85,6 +93,7 @@ struct orc_ctx {
     /* points */
     double *raster_pts; int n_raster;
     double *qlocal;     int n_qlocal;
+    double serial_s; /* wall time of the last match's single-threaded part (grid clear + rasterisation) */
 };
 
 static void free_pass(orc_ctx *c, int p) {
@@ -602,7 +611,9 @@ static int k_match(orc_ctx *c, const orc_scan *query, const orc_scan *base, int 
     c->off_x = pose[0] - (0.5 * (c->roi_w - 1) * res);
     c->off_y = pose[1] - (0.5 * (c->roi_h - 1) * res);
 
+    double t_raster = now_s();
     k_add_scans(c, base, n_base, pose[0], pose[1]);
+    c->serial_s = now_s() - t_raster;
 
     double coarse_off = 0.5 * (c->side - 1) * res;
     double coarse_step = 2 * res;
@@ -914,6 +925,7 @@ const double *orc_raster_points(const orc_ctx *c, int *n) {
     if (n) *n = c->n_raster;
     return c->raster_pts;
 }
+double orc_last_serial_seconds(const orc_ctx *c) { return c->serial_s; }
 const double *orc_query_local(const orc_ctx *c, int *n) {
     if (n) *n = c->n_qlocal;
     return c->qlocal;

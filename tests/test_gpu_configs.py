@@ -1,0 +1,161 @@
+"""BASELINE.json configs[2] (sequential mapping, 2000 scans) and configs[3] (loop-closure batch, 4096 chains) on the
+GPU, checked against the CPU oracle.  Call patterns: /root/reference/yag_slam/graph_slam.py:306-339 (process_scan)
+and :217-236 (the per-chain loop of try_to_close_loop)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import PlainScan  # noqa: E402
+
+
+def _plain(scan):
+    p = scan.corrected_pose
+    return PlainScan(scan.ranges, scan.min_angle, scan.angle_increment, scan.min_range, scan.range_threshold,
+                     (p.x, p.y, p.euler[-1]))
+
+
+class LockstepMatcher(object):
+    """The matcher plugin SequentialMapper drives, with the oracle run beside every call on the SAME inputs (the scans
+    at the poses the mapper holds at that moment).  Returns the GPU result, so the next step's prior is the GPU's."""
+
+    def __init__(self, gpu, oracle, limit):
+        self.gpu, self.oracle, self.limit = gpu, oracle, limit
+        self.steps = 0
+        self.worst = [0.0, 0.0, 0.0]
+
+    def match_scan(self, query, base_scans, penalty=True, do_fine=False):
+        r = self.gpu.match_scan(query, base_scans, penalty, do_fine)
+        if self.steps < self.limit:
+            ro = self.oracle.match_scan(_plain(query), [_plain(b) for b in base_scans], penalty, do_fine)
+            bp = r.best_pose
+            dr = abs(r.response - ro["response"])
+            dp = float(np.abs(np.array([bp.x, bp.y, bp.euler[-1]]) - ro["pose"]).max())
+            assert dr <= 1e-12, (self.steps, r.response, ro["response"])
+            assert dp <= 1e-9, (self.steps, dp)
+            np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
+            assert r.meta["hypotheses"] == ro["hypotheses"] and r.meta["expansions"] == ro["expansions"]
+            self.worst = [max(self.worst[0], dr), max(self.worst[1], dp), 0.0]
+        self.steps += 1
+        return r
+
+
+def test_cfg3_sequential_mapping_lockstep_with_oracle_then_2000_scans():
+    """configs[2]: 2000 scans through SequentialMapper.  The first 250 steps run the oracle in lock-step (response
+    <= 1e-12, pose <= 1e-9, covariance 1e-9 relative, per step); the full run is then checked by its properties."""
+    from oracle import oracle as orc
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n = 2000
+    truth, scans = synth.trajectory_scans(n)
+    lock = LockstepMatcher(ScanMatcher(), orc.Oracle(None, "karto"), limit=250)
+    mapper = SequentialMapper(lock)
+    hyp = 0
+    for s in scans:
+        res = mapper.process_scan(s)
+        if res is not None:
+            hyp += res.meta["hypotheses"]
+            assert tuple(res.meta["coarse_dims"]) == (26, 26, 21) and tuple(res.meta["fine_dims"]) == (3, 3, 11)
+    assert lock.steps == n - 1
+    assert hyp == (n - 1) * 14295
+    assert len(mapper.running_scans) == 10 and [s.num for s in mapper.running_scans] == list(range(n - 10, n))
+    err = np.array([[s.corrected_pose.x - t[0], s.corrected_pose.y - t[1]] for s, t in zip(scans, truth)])
+    # dead reckoning on matches against the last 10 scans only (no loop closure here): the drift over 17 laps of the
+    # room stays a random walk of sub-cell steps, far below the odometry's own (0.03 m per step, uncorrelated)
+    assert np.hypot(err[:, 0], err[:, 1]).max() < 0.5
+    assert min(r.response for r in mapper.results) > 0.3
+
+
+def test_cfg4_loop_batch_4096_distinct_chains_against_oracle():
+    """configs[3] on one GPU: the cfg2 query against 4096 distinct 10-scan chains at seeded poses (chain 0 = the query's own
+    neighbourhood; every chain sees the same room, so it need not be the arg-best), loop config, penalty off, coarse only -- one match_scan_batch call.  A seeded sample of 96 chains
+    (plus chain 0 and the winner) is compared with the oracle; the arg-best with numpy."""
+    from oracle import oracle as orc
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n_chains = 4096
+    query, chains = synth.loop_batch_scans(n_chains)
+    m = ScanMatcher(None, loop=True)
+    per, best = m.match_scan_batch(query, chains, False, False)
+    assert len(per) == n_chains
+    resp = np.array([p.response for p in per])
+    assert best == int(np.argmax(resp))
+    assert resp[0] > 0.5                          # chain 0 is the query's own neighbourhood
+    assert all(tuple(p.meta["coarse_dims"]) == (41, 41, 21) and p.meta["fine_dims"][0] == 0 for p in per)
+    assert sum(p.meta["hypotheses"] for p in per) >= n_chains * 35301   # + response expansions, if any
+    o = orc.Oracle(None, "karto", loop=True)
+    rng = np.random.default_rng(4096)
+    sample = sorted(set([0, best] + rng.choice(n_chains, size=96, replace=False).tolist()))
+    pq = _plain(query)
+    for c in sample:
+        ro = o.match_scan(pq, [_plain(s) for s in chains[c]], False, False)
+        r = per[c]
+        assert abs(r.response - ro["response"]) <= 1e-12, (c, r.response, ro["response"])
+        bp = r.best_pose
+        np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], ro["pose"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
+        assert r.meta["hypotheses"] == ro["hypotheses"] and r.meta["expansions"] == ro["expansions"]
+    # the same call again on the same matcher, and as two half batches: identical bits (workspace reuse)
+    per2, best2 = m.match_scan_batch(query, chains, False, False)
+    assert best2 == best and all(a.response == b.response and a.covariance == b.covariance for a, b in zip(per, per2))
+    half, _ = m.match_scan_batch(query, chains[2048:], False, False)
+    assert all(a.response == b.response and a.covariance == b.covariance for a, b in zip(per[2048:], half))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_loop_matcher_one_rank_rccl():
+    """ShardedLoopMatcher end to end over a 1-rank RCCL group: stream-ordered record -> all-gather -> winner, against
+    the plain batch path; and the record after a response expansion (rewritten by the wait)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from yag_slam_amd import dist as ymdist
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        query, chains = synth.loop_batch_scans(24)
+        m = ScanMatcher(None, loop=True)
+        ref, ref_best = ScanMatcher(None, loop=True).match_scan_batch(query, chains, False, False)
+        sh = ymdist.ShardedLoopMatcher(m, query, chains, 0, 1)
+        rec = torch.zeros(ymdist.RECORD, dtype=torch.float64, device="cuda")
+        # asynchronous form: no host wait between the enqueue and the collective
+        sh.run_async(rec, False, False, slot=3)
+        win, allrec = sh.reduce(rec)
+        w = win.cpu().numpy()
+        assert int(w[1]) == ref_best and w[0] == ref[ref_best].response
+        bp = ref[ref_best].best_pose
+        assert (w[2], w[3], w[4]) == (bp.x, bp.y, bp.euler[-1])
+        cov = ref[ref_best].covariance
+        assert (w[5], w[6], w[7]) == (cov[0][0], cov[1][1], cov[2][2])
+        per, _, _ = sh.batch.wait(3)
+        assert all(a.response == b.response for a, b in zip(per, ref))
+        # exact form
+        win2, _, per2 = sh.match(rec, False, False, slot=0)
+        assert torch.equal(win2, win) and len(per2) == len(chains)
+        # from a local shard with a chain id base
+        sh2 = ymdist.ShardedLoopMatcher.from_local_shard(m, query, chains, 0, len(chains), 0, 1)
+        win3, _, _ = sh2.match(rec, False, False, slot=1)
+        assert torch.equal(win3, win)
+        # response expansion: a query that sees nothing of any chain -> coarse response 0 -> retries on the host; the
+        # record on the device must then be the post-expansion one
+        far = synth.resident_scan(query.ranges, (40.0, 40.0, 0.0))
+        sh3 = ymdist.ShardedLoopMatcher(m, far, chains[:9], 0, 1)
+        win4, _, per4 = sh3.match(rec, False, False, slot=2)
+        assert all(p.meta["expansions"] == 3 for p in per4)
+        w4 = win4.cpu().numpy()
+        assert w4[0] == max(p.response for p in per4) and int(w4[1]) == int(np.argmax([p.response for p in per4]))
+    finally:
+        dist.destroy_process_group()

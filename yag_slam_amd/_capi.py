@@ -98,6 +98,20 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """A process can hold ONE HSA runtime (the second one cannot open the GPU), and PyTorch-ROCm wheels bundle their own
+    libamdhip64 / libhsa-runtime64.  If torch is imported first, libyagmatch's `libamdhip64.so.7` dependency resolves to
+    the copy torch already loaded and both share it; the other way round torch loads a second runtime and then reports
+    "No HIP GPUs are available".  So when torch is installed it is imported before the library is loaded (dist.py and
+    bench.py use both in one process).  YM_SKIP_TORCH_PRELOAD=1 opts out for torch-free deployments."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("YM_SKIP_TORCH_PRELOAD"):
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def lib():
     """Load (building first if the .so is absent) and prototype the library."""
     global _lib
@@ -105,6 +119,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
     L.ym_version.restype = C.c_int

@@ -36,6 +36,9 @@ def all_gather_best(local_record, group=None):
     Returns (winner_record_tensor, gathered (world, RECORD) tensor)."""
     import torch
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):  # a single process: its record is the winner
+        out = local_record.contiguous().view(1, RECORD)
+        return out[0], out
     world = dist.get_world_size(group)
     flat = torch.empty(world * RECORD, dtype=torch.float64, device=local_record.device)
     dist.all_gather_into_tensor(flat, local_record.contiguous().view(-1), group=group)
@@ -52,34 +55,66 @@ def all_gather_best(local_record, group=None):
 class ShardedLoopMatcher(object):
     """Each rank owns a ScanMatcher on its GPU and a contiguous shard of the candidate chains.
 
-    The matcher is moved onto torch's current stream: RCCL collectives are ordered against that stream, so the
-    record the arg-best kernel writes is complete before the all-gather reads it (the matcher's own stream is
-    non-blocking and would not be ordered with it).  `stream=False` keeps the matcher's stream (CPU tests with a
-    stand-in matcher)."""
+    The matcher is moved onto a torch stream (`stream`, default: torch's current stream) and the collective is issued
+    under that stream: RCCL orders itself against it, so the record the arg-best kernel writes is complete before the
+    all-gather reads it (the matcher's own stream is non-blocking and would not be ordered with anything torch does).
+    `stream=False` keeps the matcher's stream (CPU tests with a stand-in matcher)."""
 
     def __init__(self, matcher, query, chains, rank, world, stream=None):
         self.matcher = matcher
         self.rank, self.world = rank, world
         self.n_chains = len(chains)
         self.lo, self.hi = shard_range(len(chains), rank, world)
+        self.torch_stream = None
         if stream is not False:
+            import torch
             if stream is None:
-                import torch
-                stream = torch.cuda.current_stream().cuda_stream
-            matcher.set_stream(stream)
+                stream = torch.cuda.current_stream()
+                if stream.cuda_stream == 0:
+                    # torch's default stream is the null stream: its handle (0) is how ym_set_stream spells "the matcher's
+                    # own stream".  Work on a side stream instead; reduce() makes the caller's stream wait for it.
+                    stream = torch.cuda.Stream()
+            self.torch_stream = stream
+            matcher.set_stream(stream.cuda_stream)
         self.batch = matcher.make_batch(query, chains[self.lo:self.hi]) if self.hi > self.lo else None
+
+    @classmethod
+    def from_local_shard(cls, matcher, query, local_chains, lo, n_chains, rank, world, stream=None):
+        """The same, for a rank that only holds ITS chains: local_chains = chains[lo:hi] of the n_chains candidates,
+        with (lo, hi) = shard_range(n_chains, rank, world)."""
+        lo_, hi_ = shard_range(n_chains, rank, world)
+        if lo != lo_ or lo + len(local_chains) != hi_:
+            raise ValueError("shard [%d, %d) is not rank %d's block [%d, %d)" % (lo, lo + len(local_chains), rank, lo_, hi_))
+        self = cls(matcher, query, [], rank, world, stream)
+        self.n_chains, self.lo, self.hi = n_chains, lo_, hi_
+        self.batch = matcher.make_batch(query, local_chains) if local_chains else None
+        return self
+
+    def _on_stream(self):
+        import contextlib
+        if self.torch_stream is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.torch_stream)
 
     def run_async(self, record, penalty=False, do_fine=False, slot=0):
         """Enqueue the local shard; `record` (torch float64[RECORD] on this GPU) receives the shard's best.
         The record is the one written BEFORE Karto's response expansion (see include/yagmatch.h); `match` below
         is the form that is exact in that case too."""
         if self.batch is None:
-            record.fill_(-1.0)
+            with self._on_stream():
+                record.fill_(-1.0)
             return
         self.batch.run_async(penalty, do_fine, slot, chain_id_base=self.lo, dev_best_out=record.data_ptr())
 
     def reduce(self, record, group=None):
-        return all_gather_best(record, group)
+        """all-gather of the ranks' records + arg-max, ordered after this rank's arg-best kernel"""
+        with self._on_stream():
+            out = all_gather_best(record, group)
+        if self.torch_stream is not None:
+            import torch
+            torch.cuda.current_stream().wait_stream(self.torch_stream)
+        return out
 
     def match(self, record, penalty=False, do_fine=False, slot=0, group=None):
         """The whole loop-closure step: local shard, wait (so that a response expansion has rewritten the record),

@@ -118,3 +118,87 @@ def chain_poses(n_chains, chain_len=10, seed=99, scene=None):
         y0 = rng.uniform(1.4, scene.height - 1.4)
         chains.append([(x0 + 0.1 * i, y0, 0.0) for i in range(chain_len)])
     return chains
+
+
+# ---- the BASELINE workloads as resident scans (bench.py and the -m gpu tests share these builders) ----------------
+def resident_scan(ranges, pose, range_threshold=RANGE_THRESHOLD):
+    """LocalizedRangeScan of the synthetic sensor at `pose` (x, y, heading)"""
+    from .models import LocalizedRangeScan
+    return LocalizedRangeScan(ranges, MIN_ANGLE, MAX_ANGLE, ANGLE_INCREMENT, MIN_RANGE, MAX_RANGE, range_threshold,
+                              float(pose[0]), float(pose[1]), float(pose[2]))
+
+
+def single_match_scans(scene=None):
+    """cfg1/cfg2: (query at the odometry prior, 10 base scans), noise seeds 1000 + scan index"""
+    scene = scene or Scene()
+    base_poses, q_truth, q_prior = single_match_poses()
+    base = [resident_scan(scene.scan_ranges(p, index=i), p) for i, p in enumerate(base_poses)]
+    return resident_scan(scene.scan_ranges(q_truth, index=10), q_prior), base
+
+
+def trajectory_jobs(n):
+    truth, _ = loop_trajectory(n)
+    return [(truth[i], i) for i in range(n)]
+
+
+def trajectory_scans(n, scene=None, ranges=None):
+    """cfg3: n scans along the seeded loop; every scan starts at the first pose and carries its odometry pose
+    (= truth + noise), the way yag-slam's node hands scans to GraphSlam.process_scan.  `ranges`: pre-generated
+    scan_ranges_many(trajectory_jobs(n)).  Returns (truth, scans)."""
+    from .transform import Transform
+    scene = scene or Scene()
+    truth, prior = loop_trajectory(n)
+    if ranges is None:
+        ranges = scan_ranges_many(trajectory_jobs(n), scene)
+    scans = []
+    for i in range(n):
+        s = resident_scan(ranges[i], truth[0])
+        s.odom_pose = Transform(prior[i][0], prior[i][1], 0.0, prior[i][2])
+        scans.append(s)
+    scans[0].odom_pose = Transform(truth[0][0], truth[0][1], 0.0, truth[0][2])
+    return truth, scans
+
+
+def loop_batch_scans(n_chains, lo=0, hi=None, chain_len=10, scene=None, ranges=None):
+    """cfg4: the cfg2 query against `n_chains` candidate chains of `chain_len` scans at seeded poses; chain 0 is the
+    query's true neighbourhood.  Only chains [lo, hi) are built (a rank's shard); scan (c, i) has noise seed
+    1000 + 100000 + c * chain_len + i whatever the shard.  `ranges`: what scan_ranges_many(loop_batch_jobs(...)) gave
+    for the same arguments, when they were generated ahead of time.  Returns (query, chains[lo:hi])."""
+    scene = scene or Scene()
+    hi = n_chains if hi is None else hi
+    jobs = loop_batch_jobs(n_chains, lo, hi, chain_len, scene)
+    if ranges is None:
+        ranges = scan_ranges_many(jobs, scene)
+    _, q_truth, q_prior = single_match_poses()
+    query = resident_scan(scene.scan_ranges(q_truth, index=10), q_prior)
+    scans = [resident_scan(r, j[0]) for r, j in zip(ranges, jobs)]
+    return query, [scans[k * chain_len:(k + 1) * chain_len] for k in range(hi - lo)]
+
+
+# ---- bulk generation: ray casting is ~1 ms of numpy per scan, the loop-closure workload has 40 960 of them ---------
+_JOB_SCENE = None
+
+
+def _ranges_job(job):
+    pose, index = job
+    return _JOB_SCENE.scan_ranges(pose, index=index)
+
+
+def scan_ranges_many(jobs, scene=None, workers=1):
+    """[(pose, noise index), ...] -> list of range arrays, optionally on a fork pool.  Call it with workers > 1 only
+    BEFORE the process touches the GPU (a forked child must not inherit an initialised HIP runtime)."""
+    global _JOB_SCENE
+    _JOB_SCENE = scene or Scene()
+    jobs = list(jobs)
+    if workers <= 1 or len(jobs) < 64:
+        return [_ranges_job(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_ranges_job, jobs, chunksize=max(1, len(jobs) // (8 * workers)))
+
+
+def loop_batch_jobs(n_chains, lo=0, hi=None, chain_len=10, scene=None):
+    """the (pose, noise index) list behind loop_batch_scans(...)'s chains, chain-major"""
+    hi = n_chains if hi is None else hi
+    poses = chain_poses(n_chains, chain_len=chain_len, scene=scene)
+    return [(poses[c][i], 100000 + c * chain_len + i) for c in range(lo, hi) for i in range(chain_len)]
