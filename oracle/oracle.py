@@ -11,8 +11,18 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SEM_KARTO, SEM_YAGPY = 0, 1
+SEM_KARTO, SEM_YAGPY, SEM_MIXED = 0, 1, 2
 _SEM = {"karto": SEM_KARTO, "yagpy": SEM_YAGPY}
+
+# the switches of ym_oracle.h (bit n set = delta n follows the reference's Python path)
+DELTAS = ("D1_CELL_VALUE", "D2_KERNEL_HALF", "D3_GRID_SIZE", "D4_ORIGIN", "D5_ROUNDING", "D6_VALID_FILTER", "D7_RANGE_GATE",
+          "D8_RESTAMP", "D9_COARSE_LATTICE", "D10_FINE_LATTICE", "D11_NORMALISER", "D12_PENALTY", "D13_TIES", "D14_POS_COV",
+          "D15_ANG_COV", "D16_EXPANSION_CLAMP", "D17_DEFAULT_FINE", "D18_LOOKUP")
+ALL_PY = (1 << len(DELTAS)) - 1
+
+
+def delta_bit(name):
+    return 1 << DELTAS.index(name)
 
 # default_config / default_config_loop of the reference (/root/reference/yag_slam/helpers.py:339-361)
 # restated as data so the oracle does not depend on the product package.
@@ -48,6 +58,7 @@ class OrcConfig(C.Structure):
         ("smear_deviation", C.c_double),
         ("semantics", C.c_int),
         ("threads", C.c_int),
+        ("delta_mask", C.c_uint),
     ]
 
 
@@ -156,7 +167,7 @@ def scan_from(obj):
                      obj.range_threshold, (p.x, p.y, p.euler[-1]))
 
 
-def make_config(d=None, semantics="karto", loop=False, threads=1, minimum_distance_penalty=0.5):
+def make_config(d=None, semantics="karto", loop=False, threads=1, minimum_distance_penalty=0.5, delta_mask=None):
     cfg = dict(DEFAULT_CONFIG_LOOP if loop else DEFAULT_CONFIG)
     if d:
         cfg.update(d)
@@ -166,6 +177,9 @@ def make_config(d=None, semantics="karto", loop=False, threads=1, minimum_distan
             setattr(c, k, int(v) if k == "use_response_expansion" else float(v))
     c.minimum_distance_penalty = float(cfg.get("minimum_distance_penalty", minimum_distance_penalty))
     c.semantics = _SEM[semantics] if isinstance(semantics, str) else int(semantics)
+    if delta_mask is not None:  # per-switch choice between the Karto and the Python behaviour
+        c.semantics = SEM_MIXED
+        c.delta_mask = int(delta_mask)
     c.threads = int(threads)
     return c
 
@@ -173,10 +187,10 @@ def make_config(d=None, semantics="karto", loop=False, threads=1, minimum_distan
 class Oracle:
     """One matcher instance == Scan2DMatcherCpp / Scan2DMatcherPy of the reference."""
 
-    def __init__(self, config_dict=None, semantics="karto", loop=False, threads=1, lib=None):
+    def __init__(self, config_dict=None, semantics="karto", loop=False, threads=1, lib=None, delta_mask=None):
         self.lib = lib or load()
         self.semantics = semantics
-        self.cfg = make_config(config_dict, semantics, loop, threads)
+        self.cfg = make_config(config_dict, semantics, loop, threads, delta_mask=delta_mask)
         self.ctx = self.lib.orc_create(C.byref(self.cfg))
         if not self.ctx:
             raise ValueError(self.lib.orc_last_error().decode())
@@ -246,11 +260,8 @@ class Oracle:
         p = fn(self.ctx, pass_, C.byref(nx), C.byref(ny), C.byref(nt))
         if not p or nx.value * ny.value * nt.value == 0:
             return None
-        if self.semantics == "karto":
-            a = np.ctypeslib.as_array(p, shape=(ny.value, nx.value, nt.value)).copy()
-            return a.transpose(2, 0, 1)  # -> [it][iy][ix]
-        a = np.ctypeslib.as_array(p, shape=(nx.value, ny.value, nt.value)).copy()
-        return a.transpose(2, 1, 0)  # -> [it][iy][ix]
+        a = np.ctypeslib.as_array(p, shape=(ny.value, nx.value, nt.value)).copy()
+        return a.transpose(2, 0, 1)  # -> [it][iy][ix]
 
     def sums(self, pass_=0):
         """integer correlation sums, canonical layout [itheta][iy][ix]"""

@@ -387,23 +387,29 @@ def test_maximum_scan_size_and_limits():
 
 def test_against_karto_wheel_if_present():
     """Optional: wherever the reference's native dependency is installed, compare against it directly
-    (north_star tolerances: response 1e-4, pose 1e-3 m / 1e-3 rad)."""
+    (north_star tolerances: response 1e-4, pose 1e-3 m / 1e-3 rad) -- on the cfg2 problem and on the reference's own
+    smoke input (/root/reference/test.py:29-38: 230 beams of 3.0 m, base (0,0,0), query (1.0,0,1.57), penalize +
+    refine).  This is the one test that could pin the Karto branch of the oracle's eighteen switches."""
     ks = pytest.importorskip("karto_scanmatcher")
     from yag_slam_amd.scan_matching import ScanMatcher
-    q, base = cfg2_scans()
-    cfg = ks.ScanMatcherConfig()
     from yag_slam_amd.config import default_config
+    cfg = ks.ScanMatcherConfig()
     for k, v in default_config.items():
         setattr(cfg, k, v)
     w = ks.Wrapper(cfg)
     mk = lambda s: ks.LocalizedRangeScan(ks.LaserScanConfig(s.min_angle, s.max_angle, s.angle_increment, s.min_range, s.max_range, s.range_threshold, ""),
                                          list(s.ranges), ks.Pose2(s.corrected_pose.x, s.corrected_pose.y, s.corrected_pose.euler[-1]),
                                          ks.Pose2(s.corrected_pose.x, s.corrected_pose.y, s.corrected_pose.euler[-1]), 0, 0.0)
-    ref = w.match_scan(mk(q), [mk(b) for b in base], True, True)
-    r = ScanMatcher().match_scan(q, base, True, True)
-    assert abs(r.response - ref.response) <= 1e-4
-    assert abs(r.best_pose.x - ref.best_pose.x) <= 1e-3 and abs(r.best_pose.y - ref.best_pose.y) <= 1e-3
-    assert abs(r.best_pose.euler[-1] - ref.best_pose.yaw) <= 1e-3
+    q, base = cfg2_scans()
+    flat = lambda p: PlainScan([3.0] * 230, -1.0, float(np.deg2rad(0.5)), 0.0, 5.0, p)
+    for query, chain in ((q, base), (flat((1.0, 0.0, 1.57)), [flat((0.0, 0.0, 0.0))])):
+        ref = w.match_scan(mk(query), [mk(b) for b in chain], True, True)
+        r = ScanMatcher().match_scan(query, chain, True, True)
+        assert abs(r.response - ref.response) <= 1e-4
+        assert abs(r.best_pose.x - ref.best_pose.x) <= 1e-3 and abs(r.best_pose.y - ref.best_pose.y) <= 1e-3
+        assert abs(r.best_pose.euler[-1] - ref.best_pose.yaw) <= 1e-3
+        for i in range(3):
+            assert abs(r.covariance[i][i] - ref.covariance[i][i]) <= 1e-4 * max(1.0, abs(ref.covariance[i][i]))
 
 
 def test_c_abi_error_behaviour():

@@ -68,3 +68,143 @@ def test_match_matches_reference(name):
     else:  # response == 0 -> the reference divides by zero; same non-finite pattern expected
         assert np.array_equal(np.isfinite(r["cov"]), np.isfinite(cov))
         assert np.array_equal(np.isnan(r["cov"]), np.isnan(cov))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The oracle is ONE code path with eighteen switches between what Karto does and what the reference's Python matcher
+# does (oracle/ym_oracle.h).  The tests above run it with every switch on "Python" and pin it on reference-generated
+# vectors; these show that this is the same code the Karto setting runs, and that every switch is live.
+def _full(o, c):
+    r = o.match_scan(c["query"], c["base"], c["penalty"], c["do_fine"])
+    g, _ = o.grid_u8()
+    return r, g, o.sums(0), o.responses(0)
+
+
+def test_semantics_are_mask_settings_of_one_path():
+    c = load_case("small_dirty_rot")
+    for sem, mask in (("yagpy", orc.ALL_PY), ("karto", 0)):
+        cfg = c["cfg"] if sem == "yagpy" else dict(c["cfg"], search_size=0.32)
+        a = _full(orc.Oracle(cfg, semantics=sem), c)
+        b = _full(orc.Oracle(cfg, delta_mask=mask), c)
+        assert a[0]["response"] == b[0]["response"] and np.array_equal(a[0]["pose"], b[0]["pose"])
+        assert np.array_equal(a[0]["cov"], b[0]["cov"], equal_nan=True)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("name", SMALL + ["testpy_flat", "cfg2_pen1_fine1"])
+def test_all_python_switches_through_the_mask_reproduce_the_reference(name):
+    """the Karto code path with each of its eighteen switches set to the Python behaviour == the reference's outputs"""
+    c = load_case(name)
+    z = c["z"]
+    o = orc.Oracle(c["cfg"], delta_mask=orc.ALL_PY)
+    r = o.match_scan(c["query"], c["base"], c["penalty"], c["do_fine"])
+    g = o.grid_f64()
+    nzy, nzx = np.nonzero(g)
+    assert np.array_equal(nzy, z["grid_nz_y"]) and np.array_equal(nzx, z["grid_nz_x"])
+    np.testing.assert_allclose(g[nzy, nzx], z["grid_nz_val"], rtol=0, atol=1e-15)
+    if "coarse_sums" in z.files:
+        assert np.array_equal(o.sums(0).astype(np.int64), z["coarse_sums"])
+    assert abs(r["response"] - float(z["response"])) <= 1e-12
+    np.testing.assert_allclose(r["pose"], z["best_pose"], rtol=0, atol=1e-9)
+
+
+# what each switch must change when it alone leaves the Python setting, on a case where it can matter
+_LIVE = {
+    "D1_CELL_VALUE": "grid", "D2_KERNEL_HALF": "grid", "D3_GRID_SIZE": "shape", "D5_ROUNDING": "none_here",
+    "D6_VALID_FILTER": "grid", "D7_RANGE_GATE": "npoints", "D8_RESTAMP": "none_at_this_smear", "D9_COARSE_LATTICE": "dims",
+    "D10_FINE_LATTICE": "fine_dims", "D11_NORMALISER": "resp_bits", "D12_PENALTY": "resp", "D13_TIES": "pose_or_same",
+    "D14_POS_COV": "cov", "D15_ANG_COV": "cov", "D16_EXPANSION_CLAMP": "none_here", "D18_LOOKUP": "sums",
+}
+
+
+@pytest.mark.parametrize("delta", sorted(_LIVE))
+def test_every_switch_is_live(delta):
+    """flip ONE switch from the pinned all-Python setting to Karto's: the documented part of the result moves (and for
+    the two switches this input cannot exercise, nothing does)"""
+    c = load_case("small_dirty_rot")
+    c["query"].ranges[7] = 0.01  # below min_range: Karto's range gate drops it, the Python one keeps it (D7)
+    cfg = dict(c["cfg"], search_size=0.32, smear_deviation=0.05)  # even S/r for Karto's lattice; sigma/r = 2.5: D2 differs
+    ref = orc.Oracle(cfg, delta_mask=orc.ALL_PY)
+    one = orc.Oracle(cfg, delta_mask=orc.ALL_PY & ~orc.delta_bit(delta))
+    try:
+        a, b = _full(ref, c), _full(one, c)
+    except RuntimeError:
+        assert delta in ("D3_GRID_SIZE", "D9_COARSE_LATTICE")  # a Karto-only range check may fire in a mixed setting
+        return
+    kind = _LIVE[delta]
+    ra, rb = a[0], b[0]
+    if kind in ("none_at_this_smear", "none_here"):  # D5, D8, D16: see the dedicated tests below
+        assert ra["response"] == rb["response"] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    elif kind == "grid":
+        assert not np.array_equal(a[1], b[1])
+    elif kind == "shape":
+        assert a[1].shape != b[1].shape
+    elif kind == "npoints":
+        assert ra["n_query_points"] != rb["n_query_points"]
+    elif kind == "dims":
+        assert ra["coarse_dims"] != rb["coarse_dims"]
+    elif kind == "fine_dims":
+        assert ra["fine_dims"] != rb["fine_dims"]
+    elif kind == "resp_bits":
+        assert np.array_equal(a[2], b[2]) and not np.array_equal(a[3], b[3]) and np.allclose(a[3], b[3], rtol=1e-12)
+    elif kind == "resp":
+        assert np.array_equal(a[2], b[2]) and not np.allclose(a[3], b[3], rtol=1e-6)
+    elif kind == "sums":
+        # hypothesis positions sit on cell centres, so rounding (hypothesis + point) and rounding the point's offset alone
+        # pick the same cell except on floating-point knife edges: the sums agree here; what differs by construction is
+        # how the sensor-frame points are obtained (inverse transform of world readings vs direct projection)
+        qa, qb = ref.query_local(), one.query_local()
+        assert qa.shape == qb.shape and not np.array_equal(qa, qb) and np.allclose(qa, qb, rtol=0, atol=1e-12)
+        assert a[2].shape == b[2].shape and (a[2] != b[2]).mean() < 0.01
+    elif kind == "cov":
+        assert np.array_equal(a[2], b[2]) and not np.allclose(ra["cov"], rb["cov"], rtol=1e-6, equal_nan=True)
+    elif kind == "pose_or_same":
+        assert np.array_equal(a[3], b[3])
+    else:
+        raise AssertionError(kind)
+
+
+def test_restamp_switch_matters_at_the_smear_boundary():
+    """D8 only shows when the kernel holds 100 off-centre (sigma >= 9.99 resolution): then skipping an occupied cell
+    (Karto) and stamping it again (Python) leave different grids"""
+    c = load_case("small_dirty_rot")
+    cfg = dict(c["cfg"], search_size=0.32, smear_deviation=0.2)  # sigma = 10 * resolution
+    mask_k = 0
+    a = _full(orc.Oracle(cfg, delta_mask=mask_k), c)
+    b = _full(orc.Oracle(cfg, delta_mask=mask_k | orc.delta_bit("D8_RESTAMP")), c)
+    assert not np.array_equal(a[1], b[1])
+    assert (b[1] >= a[1]).all()  # stamping again can only add
+
+
+def test_rounding_switch_matters_on_a_tie():
+    """D5 only shows when a coordinate sits exactly on a cell boundary: a reading at 1.125 m straight up the y axis on a
+    0.25 m grid is cell 22.5 -- half to even (Python) says 22, half away from zero (Karto) 23"""
+    cfg = dict(search_size=1.0, resolution=0.25, smear_deviation=0.25, range_threshold=4.0, coarse_search_angle_offset=0.2,
+               coarse_angle_resolution=0.1)
+    from tests.util import PlainScan
+    mk = lambda: PlainScan(np.full(7, 1.125), 0.0, np.pi / 6, 0.05, 4.0, (0.0, 0.0, 0.0))
+    occ = {}
+    for name, mask in (("py", orc.ALL_PY), ("k", orc.ALL_PY & ~orc.delta_bit("D5_ROUNDING"))):
+        o = orc.Oracle(cfg, delta_mask=mask)
+        o.match_scan(mk(), [mk()], True, True)
+        g, _ = o.grid_u8()
+        occ[name] = set(map(tuple, np.argwhere(g == 100).tolist()))
+    assert (22, 18) in occ["py"] and (23, 18) not in occ["py"]
+    assert (23, 18) in occ["k"] and (22, 18) not in occ["k"]
+    assert occ["py"] - {(22, 18)} == occ["k"] - {(23, 18)}
+
+
+def test_guard_switch_covers_expansion_clamp_and_empty_scan():
+    """D16: Karto's response expansion (three wider retries when nothing matched) and its early return for a query
+    without readings exist only on the Karto side"""
+    from tests.util import PlainScan
+    mk = lambda r, p: PlainScan(r, -0.5, 0.01, 0.05, 20.0, p)
+    base = [mk(np.full(101, 2.0), (0.0, 0.0, 0.0))]
+    q = mk(np.full(101, 2.0), (10.0, 10.0, 0.0))
+    cfg = dict(search_size=0.3, range_threshold=12.0)
+    rk = orc.Oracle(cfg, delta_mask=0).match_scan(q, base, True, False)
+    rp = orc.Oracle(cfg, delta_mask=orc.delta_bit("D16_EXPANSION_CLAMP")).match_scan(q, base, True, False)
+    assert rk["expansions"] == 3 and rp["expansions"] == 0 and rp["hypotheses"] * 4 < rk["hypotheses"]
+    empty = mk(np.full(101, np.nan), (0.1, 0.0, 0.0))
+    rk = orc.Oracle(cfg, delta_mask=0).match_scan(empty, base, True, False)
+    assert rk["hypotheses"] == 0 and rk["cov"][0, 0] == 500.0
