@@ -300,6 +300,9 @@ def test_order_dependent_smear_in_a_batch():
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     m = ScanMatcher(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0))
     chains = [nb[:4], nb[2:6], nb[:2], nb[5:], nb[1:4], nb[:4][::-1], nb[3:4], nb[4:9], nb[:6]]
+    # a full batch first: it leaves real cells in every chain slot, which the ragged batch's unused slots must not
+    # feed to the select kernel
+    m.match_scan_batch(nq, [nb[4:]] * 9, True, True)
     per, best = m.match_scan_batch(nq, chains, True, True)
     for ch, a in zip(chains, per):
         b = m.match_scan(nq, ch, True, True)
@@ -664,3 +667,65 @@ def test_query_reading_beyond_the_matcher_threshold_is_refused():
     # the same readings gated by the scan's own threshold are fine and match the oracle
     ok_q = PlainScan(q.ranges, q.min_angle, q.angle_increment, q.min_range, 4.0, (3.0, 3.0, 0.0))
     compare(dict(range_threshold=4.0), ok_q, base[:3], True, True)
+
+
+def test_point_cache_is_invisible():
+    """A matcher keeps the world point readings and the trigger chain of resident base scans per (scan, pose), as Karto's
+    LocalizedRangeScan keeps m_PointReadings until the pose is set again.  Hits, pose changes, one scan in several
+    chains, a scan moved between two uses, the arena growing and (tiny limit) starting over: every call must equal a
+    matcher that never caches, bit for bit -- results, rasterised cells, grids."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    extra = [_mk_native(b) for b in base]
+
+    def same(a, b):
+        return (a.response == b.response and a.covariance == b.covariance and a.meta == b.meta and
+                (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1]))
+
+    for limit_kib in (0, 200):  # 200 KiB holds 7 scans of 1081 beams: the cache keeps starting over
+        m, ref = ScanMatcher(), ScanMatcher()
+        ref.debug_option(7, 1)
+        if limit_kib:
+            m.debug_option(8, limit_kib)
+        plans = [
+            ("single", nb), ("single", nb), ("move", 3), ("single", nb), ("single", nb[2:7]),
+            ("batch", [nb, nb[:5], nb[5:], nb]), ("move", 0), ("move", 9), ("batch", [nb, nb[:5], nb[5:], nb]),
+            ("batch", [nb[:4] + extra[:3], extra, nb]), ("move", 5), ("single", nb[::-1]),
+            ("batch", [nb] * 9 + [extra] * 3), ("batch", [nb] * 9 + [extra] * 3),
+        ]
+        k = 0
+        for kind, arg in plans:
+            if kind == "move":
+                p = nb[arg].corrected_pose
+                k += 1
+                nb[arg].corrected_pose = Transform(p.x + 0.013 * k, p.y - 0.007 * k, 0.0, p.euler[-1] + 0.011 * k)
+                continue
+            if kind == "single":
+                a, b = m.match_scan(nq, arg, True, True), ref.match_scan(nq, arg, True, True)
+                assert same(a, b), (limit_kib, kind)
+                n_items = 1
+            else:
+                pa, pb = m.match_scan_batch(nq, arg, True, True)[0], ref.match_scan_batch(nq, arg, True, True)[0]
+                assert all(same(a, b) for a, b in zip(pa, pb)), (limit_kib, kind)
+                n_items = len(arg)
+            for item in range(n_items):
+                ca, _ = m.debug_cells(item)
+                cb, _ = ref.debug_cells(item)
+                assert np.array_equal(ca, cb)
+                ga, _ = m.debug_grid(item)
+                gb, _ = ref.debug_grid(item)
+                assert np.array_equal(ga, gb)
+        m.close()
+        ref.close()
+    # the yagpy path shares the kernel: same check on one golden case
+    from tests.util import load_case
+    c = load_case("small_dirty_rot")
+    gq, gb = _mk_native(c["query"]), [_mk_native(b) for b in c["base"]]
+    m, ref = ScanMatcher(c["cfg"], semantics="yagpy"), ScanMatcher(c["cfg"], semantics="yagpy")
+    ref.debug_option(7, 1)
+    for _ in range(2):
+        a, b = m.match_scan(gq, gb, True, True), ref.match_scan(gq, gb, True, True)
+        assert a.response == b.response and a.covariance == b.covariance
+        assert np.array_equal(m.debug_grid()[0], ref.debug_grid()[0])

@@ -11,7 +11,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/yagmatch.h"
@@ -118,11 +120,16 @@ struct CallScan {
     double pose[3];
     double max_valid; // largest reading that survives range gating (bounds the query's reach)
     double lbox[4];   // sensor-frame bounding box of the points (bounds where a base scan can stamp)
+    uint64_t id = 0;  // resident scan identity (0: ranges uploaded for this call only, never cached)
+    int cache_hint = -1;            // entry of the matcher's point cache this scan used last time (ym_batch remembers it)
+    unsigned char *cache = nullptr; // this call's cache slot (device), or null
+    int stale = 0;                  // the slot must be (re)computed by this call
 };
 
 struct CallItem {
     int query;
     int base_begin, base_count;
+    int qslot = 0; // batches: query slot (distinct queries of a call are projected once)
 };
 
 struct Call {
@@ -156,6 +163,7 @@ struct ProfEvents {
 }  // namespace
 
 struct ym_scan {
+    uint64_t id; // unique per created scan: the key of the matchers' point caches
     int device;
     double *d_ranges;
     int n;
@@ -169,6 +177,7 @@ struct ym_batch {
     const ym_scan *query;
     std::vector<const ym_scan *> scans;
     std::vector<int32_t> offsets;
+    mutable std::vector<int> cache_hints; // per scan: its entry in the owning matcher's point cache (validated on use)
 };
 
 struct ym_matcher {
@@ -182,7 +191,9 @@ struct ym_matcher {
     // workspace
     DevBuf<unsigned char> desc_dev; // batch call descriptors (single calls travel in the kernel arguments)
     DevBuf<YmItemState> states;
-    DevBuf<double2> qlocal;
+    DevBuf<double2> qlocal;    // [query slots][max_n] sensor-frame query points
+    DevBuf<int32_t> qnp;       // [query slots]
+    DevBuf<unsigned char> tmp_cache; // batches: per-call cache slots of base scans the point cache cannot hold
     DevBuf<int2> cells;
     DevBuf<int4> bbox;
     DevBuf<uint8_t> grid;
@@ -208,6 +219,18 @@ struct ym_matcher {
     bool stamps_on = false;
     int corr_u = 0;      // development: force the number of beams in flight per lane (16, 32, 48)
     int full_raster = 0; // development: launch every raster tile
+    // point cache: world point readings + trigger chain of resident base scans, per (scan id, pose) -- what Karto's
+    // LocalizedRangeScan keeps in m_PointReadings until the pose is set again.  One arena, bump-allocated; everything
+    // that touches it runs on this matcher's stream, so recomputing a slot in place is ordered after its readers.
+    struct CacheEntry { uint64_t id; size_t off; int n; double pose[3]; uint64_t stale_in_call; };
+    uint64_t call_counter = 0;
+    std::vector<CacheEntry> cache_entries;
+    std::unordered_map<uint64_t, int> cache_index;
+    DevBuf<unsigned char> cache_arena;
+    size_t cache_used = 0;
+    size_t cache_limit = (size_t)16 << 30; // bytes; beyond it the cache starts over
+    int cache_off = 0;                     // development: 1 = never cache (every call projects every scan)
+    int64_t cache_hits = 0, cache_misses = 0;
     DevBuf<uint16_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
     int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
@@ -432,6 +455,11 @@ struct CallPlan {
     int launch[4] = {0, 0, -1, -1}, ltx = 0, lty = 0, tile_cap = 1;
     bool use_tile_list = false;
     unsigned long long *stamps = nullptr;
+    // batches: heavy work once per distinct scan (points_kernel), then the light cells_kernel
+    bool split_prepare = false;
+    int n_jobs = 0;
+    std::vector<int32_t> jobs, job_slot; // travel at the end of the call descriptor
+    const int32_t *d_jobs = nullptr, *d_job_slot = nullptr;
 };
 
 // sizes, lattices (ScanMatcher::MatchScan), the device window, the correlate decomposition, device buffers
@@ -541,6 +569,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     int rc;
     if ((rc = m->states.ensure(B))) return rc;
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
+    if ((rc = m->qnp.ensure(B))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * ((max_n + 63) / 64)))) return rc;
     if ((rc = m->grid.ensure((size_t)B * P.grid_stride))) return rc;
@@ -561,13 +590,135 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     return YM_OK;
 }
 
+// the point cache: give every resident base scan of the call its slot and decide whether the slot is current
+int plan_cache(ym_matcher *m, Slot &slot) {
+    Call &call = slot.call;
+    const int n = (int)call.scans.size();
+    for (CallScan &s : call.scans) { s.cache = nullptr; s.stale = 0; }
+    if (m->cache_off) return YM_OK;
+    const uint64_t this_call = ++m->call_counter;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // look every scan up; count what the new ones need
+        size_t need = 0;
+        std::vector<int> found(n, -1);
+        for (int i = 1; i < n; i++) { // scan 0 is the query: projected by its own block, never cached
+            CallScan &s = call.scans[i];
+            if (s.id == 0 || s.n <= 0) continue;
+            int e = -1;
+            if (s.cache_hint >= 0 && (size_t)s.cache_hint < m->cache_entries.size() && m->cache_entries[s.cache_hint].id == s.id)
+                e = s.cache_hint;
+            else {
+                auto it = m->cache_index.find(s.id);
+                if (it != m->cache_index.end()) e = it->second;
+            }
+            if (e >= 0 && m->cache_entries[e].n != s.n) e = -1; // cannot happen (ranges are immutable); be safe
+            found[i] = e;
+            if (e < 0) need += align_up(YM_CACHE_BYTES(s.n), 16);
+        }
+        if (m->cache_used + need > m->cache_arena.cap) {
+            if (attempt == 0 && need <= m->cache_limit) {
+                // grow (or, at the limit, start over): the arena's contents go, every entry with them
+                size_t want = std::max(m->cache_used + need, 2 * m->cache_arena.cap);
+                if (want > m->cache_limit) want = std::max(need, std::min(m->cache_limit, 2 * need));
+                m->cache_entries.clear();
+                m->cache_index.clear();
+                m->cache_used = 0;
+                if (want > m->cache_arena.cap) {
+                    HIP_TRY(hipStreamSynchronize(m->stream)); // calls in flight still read the old arena
+                    int rc = m->cache_arena.ensure(want);
+                    if (rc) return rc;
+                }
+                continue; // look everything up again: all new now
+            }
+            // does not fit even alone: cache what fits, project the rest per call
+        }
+        for (int i = 1; i < n; i++) {
+            CallScan &s = call.scans[i];
+            if (s.id == 0 || s.n <= 0) continue;
+            int e = found[i];
+            if (e < 0) {
+                auto it = m->cache_index.find(s.id); // the same scan may appear in several chains of one call
+                if (it != m->cache_index.end()) e = it->second;
+            }
+            if (e < 0) {
+                const size_t bytes = align_up(YM_CACHE_BYTES(s.n), 16);
+                if (m->cache_used + bytes > m->cache_arena.cap) continue; // uncached
+                e = (int)m->cache_entries.size();
+                m->cache_entries.push_back(ym_matcher::CacheEntry{s.id, m->cache_used, s.n, {s.pose[0], s.pose[1], s.pose[2]}, this_call});
+                m->cache_index.emplace(s.id, e);
+                m->cache_used += bytes;
+                s.stale = 1;
+                m->cache_misses++;
+            } else {
+                ym_matcher::CacheEntry &ce = m->cache_entries[e];
+                if (ce.stale_in_call == this_call) {
+                    s.stale = 1; // (re)computed by this very call: every block that sees the scan computes it
+                } else if (ce.pose[0] != s.pose[0] || ce.pose[1] != s.pose[1] || ce.pose[2] != s.pose[2]) {
+                    ce.pose[0] = s.pose[0]; ce.pose[1] = s.pose[1]; ce.pose[2] = s.pose[2];
+                    ce.stale_in_call = this_call;
+                    s.stale = 1;
+                    m->cache_misses++;
+                } else {
+                    m->cache_hits++;
+                }
+            }
+            s.cache = m->cache_arena.p + m->cache_entries[e].off;
+            s.cache_hint = e;
+        }
+        break;
+    }
+    return YM_OK;
+}
+
+// Batches: the work list of points_kernel -- every distinct query once (into its query slot, which the items then
+// share) and every base scan whose cache slot this call has to fill once.  Base scans the point cache cannot hold get a
+// slot in a per-call scratch arena, so that cells_kernel reads all of them the same way.
+int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P) {
+    Call &call = slot.call;
+    P.split_prepare = P.B >= 8;
+    if (!P.split_prepare) return YM_OK;
+    const int n = (int)call.scans.size();
+    std::vector<int> base_used(n, 0), qslot_of(n, -1);
+    for (const CallItem &it : call.items)
+        for (int j = 0; j < it.base_count; j++) base_used[it.base_begin + j] = 1;
+    size_t tmp_need = 0;
+    for (int i = 0; i < n; i++)
+        if (base_used[i] && !call.scans[i].cache) tmp_need += align_up(YM_CACHE_BYTES(std::max(1, call.scans[i].n)), 16);
+    if (tmp_need) {
+        int rc = m->tmp_cache.ensure(tmp_need);
+        if (rc) return rc;
+        size_t at = 0;
+        for (int i = 0; i < n; i++)
+            if (base_used[i] && !call.scans[i].cache) {
+                call.scans[i].cache = m->tmp_cache.p + at;
+                call.scans[i].stale = 1;
+                at += align_up(YM_CACHE_BYTES(std::max(1, call.scans[i].n)), 16);
+            }
+    }
+    std::vector<int32_t> &jobs = P.jobs, &job_slot = P.job_slot;
+    int n_q = 0;
+    for (CallItem &it : call.items) {
+        if (qslot_of[it.query] < 0) {
+            qslot_of[it.query] = n_q++;
+            jobs.push_back((int32_t)(0x80000000u | (unsigned)it.query));
+            job_slot.push_back(qslot_of[it.query]);
+        }
+        it.qslot = qslot_of[it.query];
+    }
+    for (int i = 0; i < n; i++)
+        if (base_used[i] && call.scans[i].stale) { jobs.push_back(i); job_slot.push_back(0); }
+    P.n_jobs = (int)jobs.size();
+    return YM_OK;
+}
+
 // the call descriptor: written into pinned host memory; a single match carries it in the kernel arguments, a batch
 // gets it by one async H2D copy (hundreds of blocks reading pinned host memory directly is slower)
 int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
     const Call &call = slot.call;
     int rc;
     P.scans_bytes = align_up(sizeof(YmScanRef) * P.nscans, 16);
-    P.desc_bytes = P.scans_bytes + sizeof(YmItem) * P.B;
+    const size_t items_bytes = align_up(sizeof(YmItem) * P.B, 16);
+    P.desc_bytes = P.scans_bytes + items_bytes + sizeof(int32_t) * 2 * (size_t)P.n_jobs;
     if ((rc = slot.desc.ensure(P.desc_bytes))) return rc;
     if ((rc = slot.result.ensure(sizeof(YmItemState) * P.B))) return rc;
     YmScanRef *hs = P.hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
@@ -576,7 +727,8 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
         const CallScan &s = call.scans[i];
         hs[i].ranges = s.d_ranges;
         hs[i].n = s.n;
-        hs[i].pad = 0;
+        hs[i].stale = s.stale;
+        hs[i].cache = s.cache;
         hs[i].min_angle = s.min_angle;
         hs[i].angle_inc = s.angle_inc;
         hs[i].min_range = s.min_range;
@@ -587,14 +739,21 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
         hi[i].query = call.items[i].query;
         hi[i].base_begin = call.items[i].base_begin;
         hi[i].base_count = call.items[i].base_count;
-        hi[i].pad = 0;
+        hi[i].pad = call.items[i].qslot;
     }
-    P.inline_desc = (P.B == 1 && P.nscans <= YM_INLINE_SCANS);
+    if (P.n_jobs > 0) {
+        int32_t *hj = reinterpret_cast<int32_t *>(slot.desc.p + P.scans_bytes + items_bytes);
+        std::memcpy(hj, P.jobs.data(), sizeof(int32_t) * P.n_jobs);
+        std::memcpy(hj + P.n_jobs, P.job_slot.data(), sizeof(int32_t) * P.n_jobs);
+    }
+    P.inline_desc = (P.B == 1 && P.nscans <= YM_INLINE_SCANS && !P.split_prepare);
     if (!P.inline_desc) {
         if ((rc = m->desc_dev.ensure(P.desc_bytes))) return rc;
         HIP_TRY(hipMemcpyAsync(m->desc_dev.p, slot.desc.p, P.desc_bytes, hipMemcpyHostToDevice, m->stream));
         P.d_scans = reinterpret_cast<const YmScanRef *>(m->desc_dev.p);
         P.d_items = reinterpret_cast<const YmItem *>(m->desc_dev.p + P.scans_bytes);
+        P.d_jobs = reinterpret_cast<const int32_t *>(m->desc_dev.p + P.scans_bytes + items_bytes);
+        P.d_job_slot = P.d_jobs + P.n_jobs;
     }
     return YM_OK;
 }
@@ -685,9 +844,14 @@ void enqueue_prepare(ym_matcher *m, const CallPlan &P) {
         a.inl.item = P.hi[0];
         for (int i = 0; i < P.nscans; i++) a.inl.scans[i] = P.hs[i];
     }
+    a.qnp = m->qnp.p; a.jobs = P.d_jobs; a.job_slot = P.d_job_slot;
     const size_t lds = YM_PREP_LDS_BYTES(P.max_n);
-    if (P.B >= 8) hipLaunchKernelGGL(ym::prepare_kernel<256>, dim3(P.max_base + 1, P.B), dim3(256), lds, m->stream, a);
-    else hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(P.max_base + 1, P.B), dim3(512), lds, m->stream, a);
+    if (P.split_prepare) {
+        if (P.n_jobs > 0) hipLaunchKernelGGL(ym::points_kernel, dim3(P.n_jobs), dim3(YM_POINTS_THREADS), lds, m->stream, a);
+        hipLaunchKernelGGL(ym::cells_kernel, dim3(P.max_base + 1, P.B), dim3(256), 0, m->stream, a);
+    } else {
+        hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(P.max_base + 1, P.B), dim3(512), lds, m->stream, a);
+    }
 }
 
 // ---- K1b select: Karto's order-dependent "value already set" rule (only when the kernel has 100-valued taps off-centre)
@@ -826,6 +990,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
     CallPlan P;
     int rc;
     if ((rc = plan_sizes(m, slot, P))) return rc;
+    if ((rc = plan_cache(m, slot))) return rc;
+    if ((rc = plan_jobs(m, slot, P))) return rc;
     if ((rc = plan_descriptor(m, slot, P))) return rc;
     hipStream_t st = m->stream;
     hipEvent_t ev_call = nullptr;
@@ -966,6 +1132,8 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->pose[0] = s->pose[0]; o->pose[1] = s->pose[1]; o->pose[2] = s->pose[2];
     o->max_valid = semantics == YM_SEM_YAGPY ? s->max_valid_yagpy : s->max_valid_karto;
     for (int i = 0; i < 4; i++) o->lbox[i] = s->lbox[i];
+    o->id = s->id;
+    o->cache_hint = -1;
     return YM_OK;
 }
 
@@ -1059,7 +1227,7 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(ym::points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot raise the dynamic LDS limit of prepare_kernel");
         ym_destroy(m);
@@ -1074,10 +1242,10 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release();
+    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
-    m->tmp_ranges_host.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
+    m->tmp_ranges_host.release(); m->cache_arena.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
     for (Slot &s : m->slots) {
         s.desc.release();
         s.result.release();
@@ -1116,7 +1284,9 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err(YM_ERR_NO_DEVICE, "no HIP device available"); return nullptr; }
     if (device < 0 || device >= n) { set_err(YM_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, n); return nullptr; }
+    static std::atomic<uint64_t> next_id{1};
     ym_scan *s = new ym_scan();
+    s->id = next_id.fetch_add(1);
     s->device = device;
     s->n = d->n;
     s->min_angle = d->min_angle; s->max_angle = d->max_angle; s->angle_inc = d->angle_increment;
@@ -1282,8 +1452,11 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     call.scans.resize(1 + (size_t)n_scans);
     int rc = scan_to_call(b->query, m->cfg.semantics, &call.scans[0]);
     if (rc) return rc;
-    for (int i = 0; i < n_scans; i++)
+    b->cache_hints.resize(n_scans, -1);
+    for (int i = 0; i < n_scans; i++) {
         if ((rc = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
+        call.scans[1 + i].cache_hint = b->cache_hints[i];
+    }
     call.items.resize(n_chains);
     for (int c = 0; c < n_chains; c++) call.items[c] = CallItem{0, 1 + b->offsets[c], b->offsets[c + 1] - b->offsets[c]};
     call.penalize = penalize ? 1 : 0;
@@ -1294,6 +1467,7 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     slot.dev_best_user = dev_best_out;
     rc = launch_call(m, slot);
     slot.dev_best_out = nullptr; // a response-expansion re-run must not overwrite the caller's buffer
+    for (int i = 0; i < n_scans; i++) b->cache_hints[i] = call.scans[1 + i].cache_hint;
     return rc;
 }
 
@@ -1382,7 +1556,7 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
     *n = s.nq;
     if (cap < s.nq) return set_err(YM_ERR_INVALID, "buffer too small: need %d points", s.nq);
     if (s.nq > 0)
-        HIP_TRY(hipMemcpy(out_xy, m->qlocal.p + (size_t)item * m->last_max_n, sizeof(double2) * s.nq, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_xy, m->qlocal.p + (size_t)s.qslot * m->last_max_n, sizeof(double2) * s.nq, hipMemcpyDeviceToHost));
     return YM_OK;
 }
 
@@ -1407,6 +1581,20 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 4) m->corr_pad_lds = value;
     else if (option == 5) m->corr_chunks = value;
     else if (option == 6) m->finish_form = value;
+    else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
+        m->cache_off = value == 1;
+        m->cache_entries.clear();
+        m->cache_index.clear();
+        m->cache_used = 0;
+    }
+    else if (option == 8) { // point cache limit in KiB (development / tests: force the start-over path)
+        m->cache_limit = (size_t)std::max(1, value) << 10;
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        m->cache_entries.clear();
+        m->cache_index.clear();
+        m->cache_used = 0;
+        m->cache_arena.release();
+    }
     else return set_err(YM_ERR_INVALID, "unknown option %d", option);
     return YM_OK;
 }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     if (k_ok) {
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
-        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
         for (int c = threadIdx.x % jobs_pb; c < a.chunk; c += jobs_pb) {
             const int i = i0 + c;
             int o = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) : 0;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     {
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
-        const double2 *ql = a.qlocal + (size_t)b * a.max_n;
+        const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
         for (int c = tid; c < a.chunk; c += 256) {
             const int i = i0 + c;
             int2 cell = make_int2(0, 0);

@@ -12,7 +12,7 @@ struct YmInlineDesc {        // call descriptor passed in the kernel arguments (
     YmScanRef scans[YM_INLINE_SCANS];
 };
 struct PrepareArgs {
-    const YmScanRef *scans;  // pinned host memory (device-mapped); unused when use_inline
+    const YmScanRef *scans;  // device copy of the call descriptor; unused when use_inline
     const YmItem *items;
     int32_t use_inline;
     int32_t pad0;
@@ -20,54 +20,46 @@ struct PrepareArgs {
     YmGeom g;
     YmLattice lat;           // coarse lattice
     YmItemState *states;
-    double2 *qlocal;         // [B][max_n]
+    double2 *qlocal;         // [query slots][max_n]
+    int32_t *qnp;            // [query slots] number of point readings of the slot's query
     int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
     int4 *bbox;              // [B][max_base][ceil(max_n/64)] window bounding box of 64 consecutive cells
     double2 *ctrig;          // [B][nt_stride] (cos, sin) of every coarse angle
     int32_t *hypcell;        // [B][2][dim_stride]
     double *probs;           // [B][ny*nx] cleared here, filled by score_kernel
     int32_t max_n, max_base, nt_stride, dim_stride;
+    // batches: the heavy work (projection, trigger chain) runs once per distinct stale scan / distinct query in
+    // points_kernel; jobs[j] = scan index, bit 31 set = "as a query, into query slot (j's low bits in qjob_slot)"
+    const int32_t *jobs;     // [n_jobs] scan index | (query ? 0x80000000 : 0)
+    const int32_t *job_slot; // [n_jobs] query slot of a query job
     unsigned long long *stamps;
 };
 
-// grid (max_base + 1, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).  NT = 512: shortest latency (single
-// match); NT = 256: the kernel needs ~100 VGPRs (fp64 sincos), i.e. 16 waves per CU, and four blocks of 256 hide
-// each other's barriers and loads better than two of 512 (98 -> 76 us on 256 items).
-// blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.
-template <int NT>
-__global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    YM_STAMP(a, 0);
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const YmItem it = a.use_inline ? a.inl.item : a.items[b];
-    const bool is_query = blockIdx.x == 0;
-    const int slot = (int)blockIdx.x - 1;
-    const int n_cchunks = (a.max_n + 63) / 64;
-    if (!is_query && slot >= it.base_count) { // unused chain slot: no points, empty boxes
-        int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
-        for (int i = threadIdx.x; i < n_cchunks; i += NT) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
-        return;
-    }
-    const int si = is_query ? it.query : it.base_begin + slot;
-    const YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
-    const YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
-    double *sx = reinterpret_cast<double *>(lds_raw);
-    double *sy = sx + a.max_n;
-    int *nxt = reinterpret_cast<int *>(sy + a.max_n);
-    int *ex = nxt + a.max_n;                     // exit of the chain walk from point i out of its segment
-    int *ent = ex + a.max_n;                     // chain entry node per 64-point segment (max_n/64 + 1)
-    unsigned char *chain = reinterpret_cast<unsigned char *>(ent + a.max_n / 64 + 2);
-    const bool yag = a.g.semantics == 1;
+// LDS carve-up shared by the kernels that project a scan
+struct PrepLds {
+    double *sx, *sy;
+    int *nxt, *ex, *ent;
+    unsigned char *chain;
+};
+__device__ __forceinline__ PrepLds prep_lds(unsigned char *raw, int max_n) {
+    PrepLds l;
+    l.sx = reinterpret_cast<double *>(raw);
+    l.sy = l.sx + max_n;
+    l.nxt = reinterpret_cast<int *>(l.sy + max_n);
+    l.ex = l.nxt + max_n;                     // exit of the chain walk from point i out of its segment
+    l.ent = l.ex + max_n;                     // chain entry node per 64-point segment (max_n/64 + 1)
+    l.chain = reinterpret_cast<unsigned char *>(l.ent + max_n / 64 + 2);
+    return l;
+}
 
-    // ---- point readings, compacted in beam order (LocalizedRangeScan::Update / _get_point_readings)
-    const double px = (is_query && yag) ? 0.0 : sr.pose[0];
-    const double py = (is_query && yag) ? 0.0 : sr.pose[1];
-    const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
-    // One barrier for the whole scan instead of two per NT beams: pass 1 counts the valid beams of every (chunk of NT
-    // beams, wave) by ballot, pass 2 re-reads the ranges (L1) and places each valid beam after everything before it.
+// ---- point readings, compacted in beam order (LocalizedRangeScan::Update / _get_point_readings) -> sx, sy; returns np.
+// One barrier for the whole scan instead of two per NT beams: pass 1 counts the valid beams of every (chunk of NT
+// beams, wave) by ballot, pass 2 re-reads the ranges (L1) and places each valid beam after everything before it.
+template <int NT>
+__device__ __forceinline__ int project_points(const YmScanRef &sr, double px, double py, double pt, bool yag, double *sx, double *sy,
+                                              int *s_cnt /* (YM_MAX_BEAMS / NT + 1) * NT / 64 */) {
     constexpr int NW = NT / 64;
-    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * NW];
+    const int tid = threadIdx.x;
     const int lane_ = tid & 63, wave_ = tid >> 6;
     const int per = (sr.n + NT - 1) / NT; // chunks of NT beams
     auto valid = [&](int i, double &r) {
@@ -103,110 +95,141 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
         }
         running += total;
     }
-    const int np = running;
     __syncthreads();
-    YM_STAMP(a, 1);
-    YM_STAMP_B1(a, 20);
-    // world offset of ROI cell (0,0): MatchScan, "set scan pose to be center of grid"
-    const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
-    const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    return running;
+}
 
-    if (is_query) {
-        if (tid == 0) {
-            YmItemState &st = a.states[b];
-            st.pose[0] = sr.pose[0]; st.pose[1] = sr.pose[1]; st.pose[2] = sr.pose[2];
-            st.center[0] = sr.pose[0]; st.center[1] = sr.pose[1]; st.center[2] = sr.pose[2];
-            st.off_x = off_x;
-            st.off_y = off_y;
-            st.nq = np;
-            st.status = 0;
-            st.regular[0] = st.regular[1] = 0;
-            st.base_count = it.base_count;
-        }
-        // sensor-frame coordinates (karto: Transform(pose).InverseTransformPose; yagpy: points_local)
-        double2 *ql = a.qlocal + (size_t)b * a.max_n;
-        const bool identity = yag || (sr.pose[0] == 0.0 && sr.pose[1] == 0.0 && sr.pose[2] == 0.0);
-        const double cr = cos(0.0 - sr.pose[2]), sn = sin(0.0 - sr.pose[2]);
-        __syncthreads();
-        for (int i = tid; i < np; i += NT) {
-            double2 l;
-            if (identity) {
-                l = make_double2(sx[i], sy[i]);
-            } else {
-                const double dx = sx[i] - sr.pose[0], dy = sy[i] - sr.pose[1];
-                l = make_double2(cr * dx + (0.0 - sn) * dy, sn * dx + cr * dy);
-            }
-            ql[i] = l;
-        }
-        // one fp64 sin/cos per coarse angle (GridIndexLookup::ComputeOffsets); the cell offsets
-        // themselves are computed by the correlate blocks that consume them
-        if (tid < a.lat.nt) {
-            const double angle = (sr.pose[2] - a.lat.angle_off) + tid * a.lat.angle_res;
-            a.ctrig[(size_t)b * a.nt_stride + tid] = make_double2(cos(angle), sin(angle));
-        }
-        YM_STAMP(a, 2);
-        for (int i = tid; i < a.lat.nx * a.lat.ny; i += NT) a.probs[(size_t)b * a.lat.nx * a.lat.ny + i] = 0.0;
-        // coarse hypothesis cells + regularity flag
-        int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
-        int32_t *cy = cx + a.dim_stride;
-        for (int i = tid; i < a.lat.nx; i += NT) cx[i] = hyp_cell(sr.pose[0], -a.lat.off_x, i, a.lat.step_x, off_x, a.g);
-        for (int i = tid; i < a.lat.ny; i += NT) cy[i] = hyp_cell(sr.pose[1], -a.lat.off_y, i, a.lat.step_y, off_y, a.g);
-        __syncthreads();
-        {
-            const int stx = kt_round_int(a.lat.step_x * a.g.scale), sty = kt_round_int(a.lat.step_y * a.g.scale);
-            int ok = 1;
-            for (int i = tid; i < a.lat.nx; i += NT) ok &= (cx[i] == cx[0] + i * stx);
-            for (int i = tid; i < a.lat.ny; i += NT) ok &= (cy[i] == cy[0] + i * sty);
-            ok = __syncthreads_and(ok);
-            if (tid == 0) a.states[b].regular[0] = ok;
-        }
-        YM_STAMP(a, 18);
-        return;
-    }
-
-    // ---- valid-point filter (ScanMatcher::FindValidPoints / validate_points), parallel form:
-    // nxt[i] = first j > i farther than d from point i; the trigger chain is 0 -> nxt[0] -> ...;
-    // the run that ends at chain node t = nxt[s] is kept or dropped by the sign of ss(s, t).
+// ---- the query-independent half of the valid-point filter (ScanMatcher::FindValidPoints / validate_points), parallel
+// form: nxt[i] = first j > i farther than d from point i; the trigger chain is 0 -> nxt[0] -> ...; chain[i] = 1 for
+// its nodes.  Marked without one long serial walk: cut the points into segments of 64; (1) every point walks to the
+// first node past its own segment, (2) one thread hops from segment to segment with those exits (<= n/64 hops),
+// (3) one thread per entered segment marks the chain nodes inside it.
+template <int NT>
+__device__ __forceinline__ void mark_chain(const PrepLds &l, int np, bool yag) {
+    const int tid = threadIdx.x;
     const double min_sq = yag ? 0.2 * 0.2 : 0.1 * 0.1;
-    const double vpx = qr.pose[0], vpy = qr.pose[1];
     for (int i = tid; i < np; i += NT) {
-        const double fx = sx[i], fy = sy[i];
+        const double fx = l.sx[i], fy = l.sy[i];
         int j = i + 1;
         for (; j < np; j++) {
-            const double dx = fx - sx[j], dy = fy - sy[j];
+            const double dx = fx - l.sx[j], dy = fy - l.sy[j];
             if (dx * dx + dy * dy > min_sq) break;
         }
-        nxt[i] = j;
-        chain[i] = 0;
+        l.nxt[i] = j;
+        l.chain[i] = 0;
     }
     __syncthreads();
-    YM_STAMP_B1(a, 21);
-    // Mark the chain 0 -> nxt[0] -> ... without one long serial walk: cut the points into segments
-    // of 64; (1) every point walks to the first node past its own segment, (2) one thread hops from
-    // segment to segment with those exits (<= n/64 hops), (3) one thread per entered segment marks
-    // the chain nodes inside it.
     constexpr int SEG = 64;
     const int nseg = (np + SEG - 1) / SEG;
     for (int i = tid; i < np; i += NT) {
         const int seg_end = min(np, (i / SEG + 1) * SEG);
-        int j = nxt[i];
-        while (j < seg_end) j = nxt[j];
-        ex[i] = j;
+        int j = l.nxt[i];
+        while (j < seg_end) j = l.nxt[j];
+        l.ex[i] = j;
     }
-    for (int i = tid; i < nseg; i += NT) ent[i] = -1;
+    for (int i = tid; i < nseg; i += NT) l.ent[i] = -1;
     __syncthreads();
     if (tid == 0)
-        for (int cur = 0; cur < np; cur = ex[cur]) ent[cur / SEG] = cur;
+        for (int cur = 0; cur < np; cur = l.ex[cur]) l.ent[cur / SEG] = cur;
     __syncthreads();
     for (int sgi = tid; sgi < nseg; sgi += NT) {
-        int c = ent[sgi];
+        int c = l.ent[sgi];
         if (c >= 0) {
             const int seg_end = min(np, (sgi + 1) * SEG);
-            for (; c < seg_end; c = nxt[c]) chain[c] = 1;
+            for (; c < seg_end; c = l.nxt[c]) l.chain[c] = 1;
         }
     }
     __syncthreads();
-    YM_STAMP_B1(a, 22);
+}
+
+// per point: the chain node that decides it (karto: the last node at or before i; yagpy: before i, none for point 0)
+// and where that node's run ends (np = it never does)
+__device__ __forceinline__ int2 gov_walk(const PrepLds &l, int i, int np, bool yag) {
+    int s = yag ? i - 1 : i;
+    if (s >= 0)
+        while (!l.chain[s]) s--;
+    return make_int2(s, s >= 0 ? l.nxt[s] : np);
+}
+
+// a projected base scan -> its slot of the matcher's point cache
+template <int NT>
+__device__ __forceinline__ void store_cache(const YmScanRef &sr, const PrepLds &l, int np, bool yag) {
+    double2 *cpts = reinterpret_cast<double2 *>(sr.cache + YM_CACHE_HEADER);
+    int2 *cgov = reinterpret_cast<int2 *>(sr.cache + YM_CACHE_HEADER + (size_t)sr.n * 16);
+    for (int i = threadIdx.x; i < np; i += NT) {
+        cpts[i] = make_double2(l.sx[i], l.sy[i]);
+        cgov[i] = gov_walk(l, i, np, yag);
+    }
+    if (threadIdx.x == 0) *reinterpret_cast<int *>(sr.cache) = np;
+}
+
+// sensor-frame coordinates of a projected query (karto: Transform(pose).InverseTransformPose; yagpy: points_local)
+template <int NT>
+__device__ __forceinline__ void store_query_local(const YmScanRef &sr, const PrepLds &l, int np, bool yag, double2 *ql) {
+    const bool identity = yag || (sr.pose[0] == 0.0 && sr.pose[1] == 0.0 && sr.pose[2] == 0.0);
+    const double cr = cos(0.0 - sr.pose[2]), sn = sin(0.0 - sr.pose[2]);
+    for (int i = threadIdx.x; i < np; i += NT) {
+        double2 v;
+        if (identity) {
+            v = make_double2(l.sx[i], l.sy[i]);
+        } else {
+            const double dx = l.sx[i] - sr.pose[0], dy = l.sy[i] - sr.pose[1];
+            v = make_double2(cr * dx + (0.0 - sn) * dy, sn * dx + cr * dy);
+        }
+        ql[i] = v;
+    }
+}
+
+// everything of an item that depends on its query's pose and the lattice, but not on the query's readings:
+// state, (cos, sin) per coarse angle (GridIndexLookup::ComputeOffsets), cleared search-space grid, hypothesis cells
+template <int NT>
+__device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmItem &it, const YmScanRef &sr, int np, int qslot,
+                                          double off_x, double off_y) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        YmItemState &st = a.states[b];
+        st.pose[0] = sr.pose[0]; st.pose[1] = sr.pose[1]; st.pose[2] = sr.pose[2];
+        st.center[0] = sr.pose[0]; st.center[1] = sr.pose[1]; st.center[2] = sr.pose[2];
+        st.off_x = off_x;
+        st.off_y = off_y;
+        st.nq = np;
+        st.status = 0;
+        st.regular[0] = st.regular[1] = 0;
+        st.base_count = it.base_count;
+        st.qslot = qslot;
+    }
+    // one fp64 sin/cos per coarse angle; the cell offsets themselves are computed by the correlate blocks that
+    // consume them
+    if (tid < a.lat.nt) {
+        const double angle = (sr.pose[2] - a.lat.angle_off) + tid * a.lat.angle_res;
+        a.ctrig[(size_t)b * a.nt_stride + tid] = make_double2(cos(angle), sin(angle));
+    }
+    for (int i = tid; i < a.lat.nx * a.lat.ny; i += NT) a.probs[(size_t)b * a.lat.nx * a.lat.ny + i] = 0.0;
+    // coarse hypothesis cells + regularity flag
+    int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    int32_t *cy = cx + a.dim_stride;
+    for (int i = tid; i < a.lat.nx; i += NT) cx[i] = hyp_cell(sr.pose[0], -a.lat.off_x, i, a.lat.step_x, off_x, a.g);
+    for (int i = tid; i < a.lat.ny; i += NT) cy[i] = hyp_cell(sr.pose[1], -a.lat.off_y, i, a.lat.step_y, off_y, a.g);
+    __syncthreads();
+    {
+        const int stx = kt_round_int(a.lat.step_x * a.g.scale), sty = kt_round_int(a.lat.step_y * a.g.scale);
+        int ok = 1;
+        for (int i = tid; i < a.lat.nx; i += NT) ok &= (cx[i] == cx[0] + i * stx);
+        for (int i = tid; i < a.lat.ny; i += NT) ok &= (cy[i] == cy[0] + i * sty);
+        ok = __syncthreads_and(ok);
+        if (tid == 0) a.states[b].regular[0] = ok;
+    }
+}
+
+// The query-dependent half of FindValidPoints + AddScan's cell lookup for one base scan of one item: point i is kept
+// iff its run's trigger pair (s, t) puts t on the far side of the line through the viewpoint and s; kept points
+// become window cells, 64 consecutive cells share a bounding box.  PT(i) / GOV(i) read point i and its (s, t) from
+// LDS (scan just projected) or from the matcher's point cache.
+template <int NT, typename PT, typename GOV>
+__device__ __forceinline__ void prepare_cells(const PrepareArgs &a, int b, int slot, int np, bool yag, double vpx, double vpy,
+                                              double off_x, double off_y, PT pt_of, GOV gov_of) {
+    const int tid = threadIdx.x;
+    const int n_cchunks = (a.max_n + 63) / 64;
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
     int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
     for (int i0 = 0; i0 < n_cchunks * 64; i0 += NT) {
@@ -214,27 +237,25 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
         int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
         if (i < np) {
             bool keep = false;
-            int s = yag ? i - 1 : i;
-            if (s >= 0) {
-                while (!chain[s]) s--;
-                const int t = nxt[s];
-                if (t < np) {
-                    const double fx = sx[s], fy = sy[s], cx = sx[t], cy = sy[t];
-                    const double aa = vpy - fy;
-                    const double bb = fx - vpx;
-                    const double cc = fy * vpx - fx * vpy;
-                    const double ss = cx * aa + cy * bb + cc;
-                    keep = yag ? (ss > 0.0) : !(ss < 0.0);
-                }
+            const int2 g = gov_of(i);
+            if (g.x >= 0 && g.y < np) {
+                const double2 f = pt_of(g.x), cp = pt_of(g.y);
+                const double fx = f.x, fy = f.y, cx = cp.x, cy = cp.y;
+                const double aa = vpy - fy;
+                const double bb = fx - vpx;
+                const double cc = fy * vpx - fx * vpy;
+                const double ss = cx * aa + cy * bb + cc;
+                keep = yag ? (ss > 0.0) : !(ss < 0.0);
             }
             if (keep) {
+                const double2 p = pt_of(i);
                 int gx, gy;
                 if (yag) {
-                    gx = (int)rint((sx[i] - off_x) / a.g.res);
-                    gy = (int)rint((sy[i] - off_y) / a.g.res);
+                    gx = (int)rint((p.x - off_x) / a.g.res);
+                    gy = (int)rint((p.y - off_y) / a.g.res);
                 } else {
-                    gx = world_to_grid(sx[i], off_x, a.g.scale);
-                    gy = world_to_grid(sy[i], off_y, a.g.scale);
+                    gx = world_to_grid(p.x, off_x, a.g.scale);
+                    gy = world_to_grid(p.y, off_y, a.g.scale);
                 }
                 if (gx >= 0 && gx < a.g.roi_w && gy >= 0 && gy < a.g.roi_w)
                     c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
@@ -248,7 +269,127 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
         const int x1 = wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
         if ((tid & 63) == 0 && i / 64 < n_cchunks) bbox[i / 64] = make_int4(x0, y0, x1, y1);
     }
+}
+
+// an unused chain slot of a ragged batch: no points (select_kernel walks every slot's cells), empty boxes
+template <int NT>
+__device__ __forceinline__ void clear_slot(const PrepareArgs &a, int b, int slot) {
+    const int n_cchunks = (a.max_n + 63) / 64;
+    int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
+    int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
+    for (int i = threadIdx.x; i < a.max_n; i += NT) cells[i] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    for (int i = threadIdx.x; i < n_cchunks; i += NT) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
+}
+
+// one base scan of one item from the point cache: no LDS, no barrier
+template <int NT>
+__device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, int slot, const YmScanRef &sr, const YmScanRef &qr, bool yag) {
+    const double2 *cpts = reinterpret_cast<const double2 *>(sr.cache + YM_CACHE_HEADER);
+    const int2 *cgov = reinterpret_cast<const int2 *>(sr.cache + YM_CACHE_HEADER + (size_t)sr.n * 16);
+    const int np = *reinterpret_cast<const int *>(sr.cache);
+    const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y, [&](int i) { return cpts[i]; },
+                      [&](int i) { return cgov[i]; });
+}
+
+// ---- K1, fused form (a few items): grid (max_base + 1, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).
+// blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.  A base scan whose slot of
+// the point cache is current takes the short path; otherwise it is projected here (and its slot filled).
+template <int NT>
+__global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
+    YM_STAMP(a, 0);
+    const int b = blockIdx.y;
+    const YmItem it = a.use_inline ? a.inl.item : a.items[b];
+    const bool is_query = blockIdx.x == 0;
+    const int slot = (int)blockIdx.x - 1;
+    if (!is_query && slot >= it.base_count) {
+        clear_slot<NT>(a, b, slot);
+        return;
+    }
+    const int si = is_query ? it.query : it.base_begin + slot;
+    const YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
+    const YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
+    const bool yag = a.g.semantics == 1;
+    if (!is_query && sr.cache && !sr.stale) {
+        cells_from_cache<NT>(a, b, slot, sr, qr, yag);
+        return;
+    }
+    const PrepLds l = prep_lds(lds_raw, a.max_n);
+    const double px = (is_query && yag) ? 0.0 : sr.pose[0];
+    const double py = (is_query && yag) ? 0.0 : sr.pose[1];
+    const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
+    const int np = project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
+    YM_STAMP(a, 1);
+    YM_STAMP_B1(a, 20);
+    // world offset of ROI cell (0,0): MatchScan, "set scan pose to be center of grid"
+    const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+    if (is_query) {
+        store_query_local<NT>(sr, l, np, yag, a.qlocal + (size_t)b * a.max_n);
+        if (threadIdx.x == 0) a.qnp[b] = np;
+        YM_STAMP(a, 2);
+        init_item<NT>(a, b, it, sr, np, b, off_x, off_y);
+        YM_STAMP(a, 18);
+        return;
+    }
+    mark_chain<NT>(l, np, yag);
+    YM_STAMP_B1(a, 22);
+    if (sr.cache) store_cache<NT>(sr, l, np, yag);
+    prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y,
+                      [&](int i) { return make_double2(l.sx[i], l.sy[i]); }, [&](int i) { return gov_walk(l, i, np, yag); });
     YM_STAMP_B1(a, 23);
+}
+
+// ---- K1 for batches, first half: the heavy, query-independent work ONCE per distinct scan of the call.
+// grid (n_jobs), 256 threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).  A query job projects the query and leaves its
+// sensor-frame points in its query slot; a base job projects a base scan whose cache slot is stale and fills it.
+#define YM_POINTS_THREADS 256
+__global__ __launch_bounds__(YM_POINTS_THREADS) void points_kernel(PrepareArgs a) {
+    constexpr int NT = YM_POINTS_THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
+    const int job = a.jobs[blockIdx.x];
+    const bool is_query = job < 0;
+    const YmScanRef sr = a.scans[job & 0x7fffffff];
+    const bool yag = a.g.semantics == 1;
+    const PrepLds l = prep_lds(lds_raw, a.max_n);
+    const double px = (is_query && yag) ? 0.0 : sr.pose[0];
+    const double py = (is_query && yag) ? 0.0 : sr.pose[1];
+    const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
+    const int np = project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
+    if (is_query) {
+        const int qs = a.job_slot[blockIdx.x];
+        store_query_local<NT>(sr, l, np, yag, a.qlocal + (size_t)qs * a.max_n);
+        if (threadIdx.x == 0) a.qnp[qs] = np;
+        return;
+    }
+    mark_chain<NT>(l, np, yag);
+    store_cache<NT>(sr, l, np, yag);
+}
+
+// ---- K1 for batches, second half: grid (max_base + 1, B), 256 threads, no dynamic LDS.  Block 0 of an item sets the
+// item up around its query's slot; block 1 + j turns base scan j's cached points into this item's cells.
+__global__ __launch_bounds__(256) void cells_kernel(PrepareArgs a) {
+    constexpr int NT = 256;
+    const int b = blockIdx.y;
+    const YmItem it = a.items[b];
+    const int slot = (int)blockIdx.x - 1;
+    const YmScanRef qr = a.scans[it.query];
+    if (blockIdx.x == 0) {
+        const int qs = it.pad; // query slot, set by the host
+        const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+        const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+        init_item<NT>(a, b, it, qr, a.qnp[qs], qs, off_x, off_y);
+        return;
+    }
+    if (slot >= it.base_count) {
+        clear_slot<NT>(a, b, slot);
+        return;
+    }
+    cells_from_cache<NT>(a, b, slot, a.scans[it.base_begin + slot], qr, a.g.semantics == 1);
 }
 
 // ================================================================== K1c tiles: the raster kernel's work list (batches)

@@ -53,17 +53,25 @@ struct YmLattice {
 struct YmScanRef {
     const double *ranges; // DEVICE pointer
     int32_t n;
-    int32_t pad;
+    int32_t stale;        // 1: the cache slot (if any) must be (re)computed by this call
     double min_angle, angle_inc, min_range, range_threshold;
     double pose[3];
+    unsigned char *cache; // DEVICE pointer to this scan's slot in the matcher's point cache, or null (see YM_CACHE_*)
 };
+
+// A matcher caches, per resident base scan and pose, what LocalizedRangeScan::Update and the viewpoint-independent half
+// of FindValidPoints produce (Karto keeps m_PointReadings the same way until the pose is set again):
+//   [int32 np][12 bytes pad][double2 pts[n]: world point readings, compacted, beam order]
+//   [int2 gov[n]: for point i the trigger-chain node s that decides its run and t = nxt[s] (np = the run never closes)]
+#define YM_CACHE_HEADER 16
+#define YM_CACHE_BYTES(n) ((size_t)YM_CACHE_HEADER + (size_t)(n) * 24)
 
 // one batch item = one (query, chain) problem
 struct YmItem {
     int32_t query;      // index into the scan-ref table
     int32_t base_begin; // first base scan in the scan-ref table
     int32_t base_count;
-    int32_t pad;
+    int32_t pad;        // batches: the item's query slot (distinct queries of a call are projected once)
 };
 
 // per-item device state handed from kernel to kernel, and finally copied back
@@ -79,7 +87,7 @@ struct YmItemState {
     int32_t status;
     int32_t regular[2];   // per pass: hypothesis cells form an exact lattice (fast path legal)
     int32_t base_count;   // chain length of this item (copied from the call descriptor)
-    int32_t pad;
+    int32_t qslot;        // which slot of the query-point buffer holds this item's query
     // "yagpy" semantics only: per pass lattice sizes and find_best_pose's return tuple
     int32_t ydims[2][3];  // nx, ny, nt
     int32_t ypad[2];
