@@ -124,6 +124,9 @@ struct CallScan {
     int cache_hint = -1;            // entry of the matcher's point cache this scan used last time (ym_batch remembers it)
     unsigned char *cache = nullptr; // this call's cache slot (device), or null
     int stale = 0;                  // the slot must be (re)computed by this call
+    int qcache_hint = -1;           // the same three for the scan as the QUERY of a batch
+    unsigned char *qcache = nullptr;
+    int qstale = 0;
 };
 
 struct CallItem {
@@ -178,6 +181,7 @@ struct ym_batch {
     std::vector<const ym_scan *> scans;
     std::vector<int32_t> offsets;
     mutable std::vector<int> cache_hints; // per scan: its entry in the owning matcher's point cache (validated on use)
+    mutable int query_hint = -1;
 };
 
 struct ym_matcher {
@@ -236,6 +240,7 @@ struct ym_matcher {
     int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
+    int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
@@ -438,6 +443,7 @@ struct CallPlan {
     size_t grid_stride = 0;
     // coarse correlate decomposition
     int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
+    int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
     // yagpy lattice bounds
     int ymaxd = 0, ymaxt = 0;
     size_t yvol = 0;
@@ -538,9 +544,12 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     // (measured on MI355X: sharing a block between adjacent angles does not help -- the kernel is bound by
     //  L1 tag lookups per lane, not by line reuse -- so one angle per block)
     P.tpb = 1;
-    const int jobs_pb = YM_CORR_THREADS / P.tpb;
-    P.job_blocks = (njobs + jobs_pb - 1) / jobs_pb;
-    P.ktiles = (lc.nt + P.tpb - 1) / P.tpb;
+    P.ktiles = lc.nt;
+    // a block = 4 waves = jw job-waves x cw chunk-waves: lattices with one (two) waves of lane jobs put four (two)
+    // consecutive beam chunks into one block and add them up before the partial sum is written
+    const bool staged = P.sx == 2 && m->use_lds_correlate >= 1 && njobs <= 128;
+    P.cw = staged ? 1 : (m->corr_cw > 0 ? m->corr_cw : njobs <= 64 ? 4 : njobs <= 128 ? 2 : 1);
+    P.job_blocks = (njobs + (4 / P.cw) * 64 - 1) / ((4 / P.cw) * 64);
     // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams; a small lattice (one
     // working wave per block) does best with blocks of 64 beams even when the batch alone fills the chip
     // (measured on MI355X, cfg2 x 256, whole step: 3 chunks 1.09 ms, 8 chunks 0.95 ms, 17 chunks 0.91 ms, 23 chunks
@@ -552,18 +561,21 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if (njobs <= 128) n_chunks = std::max(n_chunks, (max_n + 63) / 64);
     if (m->corr_chunks > 0) n_chunks = std::max(m->corr_chunks, (max_n + 511) / 512);
     int chunk = (max_n + n_chunks - 1) / n_chunks;
-    // beams in flight per lane: 32 for the latency-bound single match (one 32-beam chunk per block), else 16
+    // beams in flight per lane: 32 for the latency-bound single match (one 32-beam chunk per wave), else 16
     // (with the items pinned to XCDs 16 beats 32 on the batch: 618 vs 664 us; 48 spills)
     P.corr_u = m->corr_u > 0 ? m->corr_u : (chunk <= 32 && njobs <= 128 ? 32 : 16);
     chunk = (chunk + P.corr_u - 1) / P.corr_u * P.corr_u;
+    while (P.cw > 1 && P.cw * chunk > 640) P.cw /= 2; // a group's 16-bit sums must hold cw * chunk beams of 100
+    P.job_blocks = (njobs + (4 / P.cw) * 64 - 1) / ((4 / P.cw) * 64);
     P.chunk = chunk;
     P.n_chunks = (max_n + chunk - 1) / chunk;
+    P.n_groups = (P.n_chunks + P.cw - 1) / P.cw;
 
     P.nt_stride = lc.nt;
     P.dim_stride = std::max(lc.nx, lc.ny);
     P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
-    P.partial_stride = (size_t)P.n_chunks * lc.nt * lc.ny * P.nx_pad;
+    P.partial_stride = (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
     P.score_blocks = (int)((P.sums_c + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS);
 
     int rc;
@@ -590,30 +602,47 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     return YM_OK;
 }
 
-// the point cache: give every resident base scan of the call its slot and decide whether the slot is current
-int plan_cache(ym_matcher *m, Slot &slot) {
+// the point cache: give every resident base scan of the call (and, on batches, every resident query) its slot and
+// decide whether the slot is current.  Key = scan id * 2 + role (0 base: world points + trigger chain; 1 query:
+// sensor-frame points).
+int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
     Call &call = slot.call;
     const int n = (int)call.scans.size();
-    for (CallScan &s : call.scans) { s.cache = nullptr; s.stale = 0; }
+    for (CallScan &s : call.scans) { s.cache = s.qcache = nullptr; s.stale = s.qstale = 0; }
     if (m->cache_off) return YM_OK;
     const uint64_t this_call = ++m->call_counter;
+    // roles of every scan in this call
+    std::vector<unsigned char> role(n, 0); // bit 0: base of some item, bit 1: query of some item (batches only)
+    for (const CallItem &it : call.items) {
+        for (int j = 0; j < it.base_count; j++) role[it.base_begin + j] |= 1;
+        if (P.B >= 8) role[it.query] |= 2; // a few items: the query is projected by the item's own block
+    }
+    struct Want { int scan, kind; };
+    std::vector<Want> wants;
+    for (int i = 0; i < n; i++) {
+        if (call.scans[i].id == 0 || call.scans[i].n <= 0) continue;
+        if (role[i] & 1) wants.push_back(Want{i, 0});
+        if (role[i] & 2) wants.push_back(Want{i, 1});
+    }
+    auto bytes_of = [](const CallScan &s, int kind) { return align_up(kind ? YM_QCACHE_BYTES(s.n) : YM_CACHE_BYTES(s.n), 16); };
     for (int attempt = 0; attempt < 2; attempt++) {
         // look every scan up; count what the new ones need
         size_t need = 0;
-        std::vector<int> found(n, -1);
-        for (int i = 1; i < n; i++) { // scan 0 is the query: projected by its own block, never cached
-            CallScan &s = call.scans[i];
-            if (s.id == 0 || s.n <= 0) continue;
+        std::vector<int> found(wants.size(), -1);
+        for (size_t w = 0; w < wants.size(); w++) {
+            CallScan &s = call.scans[wants[w].scan];
+            const uint64_t key = s.id * 2 + wants[w].kind;
+            const int hint = wants[w].kind ? s.qcache_hint : s.cache_hint;
             int e = -1;
-            if (s.cache_hint >= 0 && (size_t)s.cache_hint < m->cache_entries.size() && m->cache_entries[s.cache_hint].id == s.id)
-                e = s.cache_hint;
+            if (hint >= 0 && (size_t)hint < m->cache_entries.size() && m->cache_entries[hint].id == key)
+                e = hint;
             else {
-                auto it = m->cache_index.find(s.id);
+                auto it = m->cache_index.find(key);
                 if (it != m->cache_index.end()) e = it->second;
             }
             if (e >= 0 && m->cache_entries[e].n != s.n) e = -1; // cannot happen (ranges are immutable); be safe
-            found[i] = e;
-            if (e < 0) need += align_up(YM_CACHE_BYTES(s.n), 16);
+            found[w] = e;
+            if (e < 0) need += bytes_of(s, wants[w].kind);
         }
         if (m->cache_used + need > m->cache_arena.cap) {
             if (attempt == 0 && need <= m->cache_limit) {
@@ -632,38 +661,41 @@ int plan_cache(ym_matcher *m, Slot &slot) {
             }
             // does not fit even alone: cache what fits, project the rest per call
         }
-        for (int i = 1; i < n; i++) {
-            CallScan &s = call.scans[i];
-            if (s.id == 0 || s.n <= 0) continue;
-            int e = found[i];
+        for (size_t w = 0; w < wants.size(); w++) {
+            CallScan &s = call.scans[wants[w].scan];
+            const int kind = wants[w].kind;
+            const uint64_t key = s.id * 2 + kind;
+            int e = found[w];
+            int stale = 0;
             if (e < 0) {
-                auto it = m->cache_index.find(s.id); // the same scan may appear in several chains of one call
+                auto it = m->cache_index.find(key); // the same scan may appear in several chains of one call
                 if (it != m->cache_index.end()) e = it->second;
             }
             if (e < 0) {
-                const size_t bytes = align_up(YM_CACHE_BYTES(s.n), 16);
+                const size_t bytes = bytes_of(s, kind);
                 if (m->cache_used + bytes > m->cache_arena.cap) continue; // uncached
                 e = (int)m->cache_entries.size();
-                m->cache_entries.push_back(ym_matcher::CacheEntry{s.id, m->cache_used, s.n, {s.pose[0], s.pose[1], s.pose[2]}, this_call});
-                m->cache_index.emplace(s.id, e);
+                m->cache_entries.push_back(ym_matcher::CacheEntry{key, m->cache_used, s.n, {s.pose[0], s.pose[1], s.pose[2]}, this_call});
+                m->cache_index.emplace(key, e);
                 m->cache_used += bytes;
-                s.stale = 1;
+                stale = 1;
                 m->cache_misses++;
             } else {
                 ym_matcher::CacheEntry &ce = m->cache_entries[e];
                 if (ce.stale_in_call == this_call) {
-                    s.stale = 1; // (re)computed by this very call: every block that sees the scan computes it
+                    stale = 1; // (re)computed by this very call: every block that sees the scan computes it
                 } else if (ce.pose[0] != s.pose[0] || ce.pose[1] != s.pose[1] || ce.pose[2] != s.pose[2]) {
                     ce.pose[0] = s.pose[0]; ce.pose[1] = s.pose[1]; ce.pose[2] = s.pose[2];
                     ce.stale_in_call = this_call;
-                    s.stale = 1;
+                    stale = 1;
                     m->cache_misses++;
                 } else {
                     m->cache_hits++;
                 }
             }
-            s.cache = m->cache_arena.p + m->cache_entries[e].off;
-            s.cache_hint = e;
+            unsigned char *p = m->cache_arena.p + m->cache_entries[e].off;
+            if (kind) { s.qcache = p; s.qstale = stale; s.qcache_hint = e; }
+            else { s.cache = p; s.stale = stale; s.cache_hint = e; }
         }
         break;
     }
@@ -700,8 +732,11 @@ int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P) {
     for (CallItem &it : call.items) {
         if (qslot_of[it.query] < 0) {
             qslot_of[it.query] = n_q++;
-            jobs.push_back((int32_t)(0x80000000u | (unsigned)it.query));
-            job_slot.push_back(qslot_of[it.query]);
+            const CallScan &q = call.scans[it.query];
+            if (!q.qcache || q.qstale) { // not already in the point cache at this pose
+                jobs.push_back((int32_t)(0x80000000u | (unsigned)it.query));
+                job_slot.push_back(qslot_of[it.query]);
+            }
         }
         it.qslot = qslot_of[it.query];
     }
@@ -729,6 +764,9 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
         hs[i].n = s.n;
         hs[i].stale = s.stale;
         hs[i].cache = s.cache;
+        hs[i].qcache = s.qcache;
+        hs[i].qstale = s.qstale;
+        hs[i].pad = 0;
         hs[i].min_angle = s.min_angle;
         hs[i].angle_inc = s.angle_inc;
         hs[i].min_range = s.min_range;
@@ -935,11 +973,11 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     a.g = P.g; a.lat = P.lc; a.grid = m->grid.p; a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.ctrig = m->ctrig.p;
     a.qlocal = m->qlocal.p; a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = P.partial_stride;
     a.max_n = P.max_n; a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.chunk = P.chunk; a.n_chunks = P.n_chunks;
-    a.ngx = P.ngx; a.nx_pad = P.nx_pad; a.sx = P.sx; a.stamps = P.stamps; a.tpb = P.tpb;
+    a.ngx = P.ngx; a.nx_pad = P.nx_pad; a.sx = P.sx; a.stamps = P.stamps; a.tpb = P.tpb; a.cw = P.cw;
     int rc;
     hipEvent_t ev_k = nullptr;
     if ((rc = prof_begin(m, 0, &ev_k))) return rc;
-    const dim3 grid_dim(P.job_blocks, P.ktiles * P.n_chunks, P.B);
+    const dim3 grid_dim(P.job_blocks, P.ktiles * P.n_groups, P.B);
     const size_t pad_lds = (size_t)m->corr_pad_lds;
     if (P.sx == 2 && m->use_lds_correlate >= 1 && P.njobs <= 128) {
         a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
@@ -965,7 +1003,7 @@ void enqueue_score_and_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
         ym::ScoreArgs a;
         a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
         a.sums = m->sums.p; a.sums_stride = P.sums_c; a.resp = m->resp.p; a.blockmax = m->blockmax.p;
-        a.n_chunks = P.n_chunks; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
+        a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
         a.probs = reinterpret_cast<unsigned long long *>(m->probs.p); a.probs_stride = (size_t)lc.nx * lc.ny;
         hipLaunchKernelGGL(ym::score_kernel, dim3(P.score_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
     }
@@ -990,7 +1028,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     CallPlan P;
     int rc;
     if ((rc = plan_sizes(m, slot, P))) return rc;
-    if ((rc = plan_cache(m, slot))) return rc;
+    if ((rc = plan_cache(m, slot, P))) return rc;
     if ((rc = plan_jobs(m, slot, P))) return rc;
     if ((rc = plan_descriptor(m, slot, P))) return rc;
     hipStream_t st = m->stream;
@@ -1133,7 +1171,7 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->max_valid = semantics == YM_SEM_YAGPY ? s->max_valid_yagpy : s->max_valid_karto;
     for (int i = 0; i < 4; i++) o->lbox[i] = s->lbox[i];
     o->id = s->id;
-    o->cache_hint = -1;
+    o->cache_hint = o->qcache_hint = -1;
     return YM_OK;
 }
 
@@ -1453,6 +1491,7 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     int rc = scan_to_call(b->query, m->cfg.semantics, &call.scans[0]);
     if (rc) return rc;
     b->cache_hints.resize(n_scans, -1);
+    call.scans[0].qcache_hint = b->query_hint;
     for (int i = 0; i < n_scans; i++) {
         if ((rc = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
         call.scans[1 + i].cache_hint = b->cache_hints[i];
@@ -1468,6 +1507,7 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     rc = launch_call(m, slot);
     slot.dev_best_out = nullptr; // a response-expansion re-run must not overwrite the caller's buffer
     for (int i = 0; i < n_scans; i++) b->cache_hints[i] = call.scans[1 + i].cache_hint;
+    b->query_hint = call.scans[0].qcache_hint;
     return rc;
 }
 
@@ -1556,7 +1596,7 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
     *n = s.nq;
     if (cap < s.nq) return set_err(YM_ERR_INVALID, "buffer too small: need %d points", s.nq);
     if (s.nq > 0)
-        HIP_TRY(hipMemcpy(out_xy, m->qlocal.p + (size_t)s.qslot * m->last_max_n, sizeof(double2) * s.nq, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_xy, s.ql, sizeof(double2) * s.nq, hipMemcpyDeviceToHost));
     return YM_OK;
 }
 
@@ -1581,6 +1621,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 4) m->corr_pad_lds = value;
     else if (option == 5) m->corr_chunks = value;
     else if (option == 6) m->finish_form = value;
+    else if (option == 9) m->corr_cw = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

@@ -16,12 +16,13 @@ struct CorrArgs {
     const double2 *qlocal;  // [B][max_n] query points in the sensor frame
     const int32_t *hypcell;
     const YmItemState *states;
-    uint16_t *partial;     // [B][n_chunks][nt][ny][nx_pad], 16-bit: a chunk sums at most 512 beams x 100
+    uint16_t *partial;     // [B][n_groups][nt][ny][nx_pad], 16-bit: a chunk group sums at most 640 beams x 100
     size_t partial_stride; // per item
     int32_t max_n, nt_stride, dim_stride;
     int32_t chunk;         // beams per chunk (multiple of 16, <= 512 keeps the 16-bit lanes from overflowing)
     int32_t n_chunks;
-    int32_t tpb;           // adjacent angles per block (1, 2 or 4)
+    int32_t tpb;           // staged kernel: development mode switch
+    int32_t cw;            // chunk-waves per block (1, 2 or 4): consecutive beam chunks summed inside a block
     int32_t ngx;           // x groups per row = ceil(nx / G)
     int32_t nx_pad;        // ngx * G
     int32_t sx;            // cell stride between x-adjacent hypotheses (1 or 2)
@@ -80,27 +81,29 @@ __device__ __forceinline__ void store_partial16(uint16_t *out, const uint32_t (&
 // per-beam, wave-uniform choice: parity of hypothesis column + beam offset).  For every beam of
 // its chunk a lane loads the 16 plane bytes of its 16 hypotheses (row start + wave-uniform beam
 // offset) and accumulates them in 16-bit lanes: no cross-lane reduction, no wasted bytes.
-// Partial sums per beam chunk are added up by score_kernel.  Each block first builds the offsets
-// of its own beam chunk in LDS (GridIndexLookup::ComputeOffsets for one angle: rotate the
-// sensor-frame point, WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are
-// issued 16 beams at a time; entries past the last beam are 0 and are masked by a scalar.
-// grid (ceil(ny*ngx / 256), nt * n_chunks, B).
+// A block is four waves = jw job-waves x cw chunk-waves (a.cw = 1, 2 or 4): small lattices have one wave of jobs,
+// so the four waves take four consecutive beam chunks of the same jobs and add their packed sums through LDS before
+// one 16-bit partial per chunk GROUP is written (a quarter of the partial-sum traffic score_kernel would otherwise
+// read back).  Each block first builds the offsets of its own beam chunks in LDS (GridIndexLookup::ComputeOffsets for
+// one angle: rotate the sensor-frame point, WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are
+// issued U beams at a time; entries past the last beam are 0 and are masked by a scalar.
+// grid (ceil(ny*ngx / (64 jw)), nt * n_groups, B).
 template <int SX, int U /* beams in flight per lane */>
 __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
     constexpr int G = 16;           // hypotheses per lane
     int bx, by;
     const int b = xcd_item_of_block(bx, by);
-    // a block covers jobs_pb lane jobs of each of tpb adjacent angles for one beam chunk: waves of
-    // one block read overlapping grid patches (adjacent angles shift the patch by a few cells)
-    const int tpb = a.tpb, jobs_pb = YM_CORR_THREADS / tpb;
-    const int ktiles = (a.lat.nt + tpb - 1) / tpb;
-    const int k = (by % ktiles) * tpb + threadIdx.x / jobs_pb, chunk = by / ktiles;
-    const int job = bx * jobs_pb + threadIdx.x % jobs_pb;
+    const int cw = a.cw, jw = 4 / cw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jw_idx = wave % jw, cw_idx = wave / jw;
+    const int k = by % a.lat.nt, group = by / a.lat.nt;
+    const int chunk = group * cw + cw_idx;
+    const int job = (bx * jw + jw_idx) * 64 + lane;
     __shared__ int offs_all[4][512];
-    int *offs = offs_all[threadIdx.x / jobs_pb];
+    __shared__ uint32_t red[4 * 8 * 64];
+    const int *offs = offs_all[cw_idx];
     YM_STAMP(a, 8);
     const int njobs = a.lat.ny * a.ngx;
-    const bool k_ok = k < a.lat.nt;
     const YmItemState &st = a.states[b];
     const int nq = st.nq;
     const int regular = st.regular[0];
@@ -110,41 +113,39 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     const int cx0 = cx[0];
     const int half_pitch = a.g.pitch / 2;
     const int plane_bytes = half_pitch * a.g.win_w;
-    if (k_ok) {
+    {
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
-        const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
-        for (int c = threadIdx.x % jobs_pb; c < a.chunk; c += jobs_pb) {
-            const int i = i0 + c;
+        const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+        for (int e = threadIdx.x; e < cw * a.chunk; e += YM_CORR_THREADS) {
+            const int ci = e / a.chunk, c = e - ci * a.chunk;
+            const int i = (group * cw + ci) * a.chunk + c;
             int o = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) : 0;
             if (SX == 2 && regular) {
                 // window-linear index of hypothesis column 0 for this beam -> (plane, index in plane)
                 const int l = o + cx0;
                 o = (l >> 1) + (l & 1) * plane_bytes;
             }
-            offs[c] = o;
+            offs_all[ci][c] = o;
         }
     }
     __syncthreads();
-    if (job >= njobs || !k_ok) return;
-    const int iy = job / a.ngx, xg = job - iy * a.ngx;
+    const bool active = job < njobs && i0 < nq;
+    const int iy = min(job, njobs - 1) / a.ngx, xg = min(job, njobs - 1) - iy * a.ngx;
     const int cyv = cy[iy];
-    uint16_t *out = a.partial + (size_t)b * a.partial_stride +
-                    (((size_t)chunk * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
+    uint32_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0u;
 
-    if (regular) {
+    if (active && regular) {
         const uint8_t *__restrict__ src = SX == 2 ? a.planes + (size_t)b * a.grid_stride : a.grid + (size_t)b * a.grid_stride;
         const uint32_t lane_off = SX == 2 ? (uint32_t)(cyv * half_pitch + xg * G)
                                           : (uint32_t)(cyv * a.g.pitch + cx0 + xg * G);
-        uint32_t acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = 0u;
         if (SX == 2) {
             // Plane loads are made dword-aligned (a byte-unaligned 16-byte load costs the vector L1 ~1.4x the
             // lookups, profiles/r01_c): the lane loads the aligned 16 bytes below its first hypothesis, takes the
             // 17th..19th byte from its right-hand neighbour lane (same row, next 16 hypotheses: DPP wave shift) and
             // funnels by the beam's byte misalignment, which is wave-uniform (v_alignbyte_b32).
-            const int lane = threadIdx.x & 63;
             // lanes whose neighbour is not the next group of the same row load the extra dword themselves
             const bool extra = (lane == 63 && xg != a.ngx - 1) || (a.nx_pad - a.lat.nx < 3 && xg == a.ngx - 1);
             for (int c = 0; c < a.chunk; c += U) {
@@ -186,10 +187,10 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
                 }
             }
         }
-        store_partial16(out, acc);
         YM_STAMP(a, 9);
-    } else {
-        // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path
+    } else if (active) {
+        // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path, packed like the
+        // fast path's lanes (acc[2j + (h & 1)] holds hypothesis 4j + h in its low (h < 2) or high 16 bits)
         const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
         const int n_here = min(nq - i0, a.chunk);
@@ -203,9 +204,22 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
                     sum += idx < limit ? grid[idx] : 0u;
                 }
             }
-            out[j] = (uint16_t)sum;
+            acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
         }
     }
+    if (cw > 1) { // add the chunk-waves of each job-wave (packed 16-bit lanes: a group is at most 640 beams x 100)
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[(wave * 8 + j) * 64 + lane] = acc[j];
+        __syncthreads();
+        if (cw_idx != 0) return;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            for (int w2 = 1; w2 < cw; w2++) acc[j] += red[((w2 * jw + jw_idx) * 8 + j) * 64 + lane];
+    }
+    if (job >= njobs) return;
+    uint16_t *out = a.partial + (size_t)b * a.partial_stride +
+                    (((size_t)group * a.lat.nt + k) * a.lat.ny + iy) * a.nx_pad + (size_t)xg * G;
+    store_partial16(out, acc);
 }
 
 __device__ __forceinline__ int2 lookup_cell(double2 p, double cosine, double sine, double off_x, double off_y, double scale) {
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     {
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
-        const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
+        const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
         for (int c = tid; c < a.chunk; c += 256) {
             const int i = i0 + c;
             int2 cell = make_int2(0, 0);

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     const uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
     const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
     int32_t *foff = a.foffsets + ((size_t)b * a.nt_stride + k) * a.max_n;
-    const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
                         s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
     if (block3) {
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(YM_FINISH1_THREADS) void finish_kernel(FinishArgs a
         for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g);
         for (int h = tid; h < nh; h += NT) s_sum[h] = 0u;
         __syncthreads();
-        const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
+        const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
         const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
                             s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
         for (int k = wave; k < nt; k += NW) { // wave-uniform

@@ -184,7 +184,7 @@ __device__ __forceinline__ void store_query_local(const YmScanRef &sr, const Pre
 // state, (cos, sin) per coarse angle (GridIndexLookup::ComputeOffsets), cleared search-space grid, hypothesis cells
 template <int NT>
 __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmItem &it, const YmScanRef &sr, int np, int qslot,
-                                          double off_x, double off_y) {
+                                          const double2 *ql, double off_x, double off_y) {
     const int tid = threadIdx.x;
     if (tid == 0) {
         YmItemState &st = a.states[b];
@@ -197,6 +197,7 @@ __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmI
         st.regular[0] = st.regular[1] = 0;
         st.base_count = it.base_count;
         st.qslot = qslot;
+        st.ql = ql;
     }
     // one fp64 sin/cos per coarse angle; the cell offsets themselves are computed by the correlate blocks that
     // consume them
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
         store_query_local<NT>(sr, l, np, yag, a.qlocal + (size_t)b * a.max_n);
         if (threadIdx.x == 0) a.qnp[b] = np;
         YM_STAMP(a, 2);
-        init_item<NT>(a, b, it, sr, np, b, off_x, off_y);
+        init_item<NT>(a, b, it, sr, np, b, a.qlocal + (size_t)b * a.max_n, off_x, off_y);
         YM_STAMP(a, 18);
         return;
     }
@@ -360,10 +361,10 @@ __global__ __launch_bounds__(YM_POINTS_THREADS) void points_kernel(PrepareArgs a
     const double py = (is_query && yag) ? 0.0 : sr.pose[1];
     const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
     const int np = project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
-    if (is_query) {
+    if (is_query) { // into the scan's query slot of the point cache, else into the call's own buffer
         const int qs = a.job_slot[blockIdx.x];
-        store_query_local<NT>(sr, l, np, yag, a.qlocal + (size_t)qs * a.max_n);
-        if (threadIdx.x == 0) a.qnp[qs] = np;
+        store_query_local<NT>(sr, l, np, yag, sr.qcache ? reinterpret_cast<double2 *>(sr.qcache + YM_CACHE_HEADER) : a.qlocal + (size_t)qs * a.max_n);
+        if (threadIdx.x == 0) *(sr.qcache ? reinterpret_cast<int *>(sr.qcache) : a.qnp + qs) = np;
         return;
     }
     mark_chain<NT>(l, np, yag);
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(256) void cells_kernel(PrepareArgs a) {
         const int qs = it.pad; // query slot, set by the host
         const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
         const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
-        init_item<NT>(a, b, it, qr, a.qnp[qs], qs, off_x, off_y);
+        const double2 *ql = qr.qcache ? reinterpret_cast<const double2 *>(qr.qcache + YM_CACHE_HEADER) : a.qlocal + (size_t)qs * a.max_n;
+        init_item<NT>(a, b, it, qr, qr.qcache ? *reinterpret_cast<const int *>(qr.qcache) : a.qnp[qs], qs, ql, off_x, off_y);
         return;
     }
     if (slot >= it.base_count) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void yag_setup_kernel(YagArgs a) {
     if (k >= nt) return;
     const double t = yag_arange_at(-a.search_t + ct, a.step_t, k);
     const double c = cos(t), s = sin(t);
-    const double2 *ql = a.qlocal + (size_t)st.qslot * a.max_n;
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     double2 *rot = a.rot + ((size_t)b * a.maxt + k) * a.max_n;
     for (int l = tid; l < st.nq; l += 256) { // helpers.py:76-78 _rotate_points
         const double2 p = ql[l];

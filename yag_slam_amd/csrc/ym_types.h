@@ -57,6 +57,9 @@ struct YmScanRef {
     double min_angle, angle_inc, min_range, range_threshold;
     double pose[3];
     unsigned char *cache; // DEVICE pointer to this scan's slot in the matcher's point cache, or null (see YM_CACHE_*)
+    unsigned char *qcache; // the same for the scan in the role of a QUERY of a batch: [int32 np][pad][double2 local[n]]
+    int32_t qstale;
+    int32_t pad;
 };
 
 // A matcher caches, per resident base scan and pose, what LocalizedRangeScan::Update and the viewpoint-independent half
@@ -65,6 +68,7 @@ struct YmScanRef {
 //   [int2 gov[n]: for point i the trigger-chain node s that decides its run and t = nxt[s] (np = the run never closes)]
 #define YM_CACHE_HEADER 16
 #define YM_CACHE_BYTES(n) ((size_t)YM_CACHE_HEADER + (size_t)(n) * 24)
+#define YM_QCACHE_BYTES(n) ((size_t)YM_CACHE_HEADER + (size_t)(n) * 16)
 
 // one batch item = one (query, chain) problem
 struct YmItem {
@@ -87,7 +91,8 @@ struct YmItemState {
     int32_t status;
     int32_t regular[2];   // per pass: hypothesis cells form an exact lattice (fast path legal)
     int32_t base_count;   // chain length of this item (copied from the call descriptor)
-    int32_t qslot;        // which slot of the query-point buffer holds this item's query
+    int32_t qslot;        // which slot of the query-point buffer holds this item's query (when not in the point cache)
+    const void *ql;       // the item's query points in the sensor frame (double2[nq])
     // "yagpy" semantics only: per pass lattice sizes and find_best_pose's return tuple
     int32_t ydims[2][3];  // nx, ny, nt
     int32_t ypad[2];
