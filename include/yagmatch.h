@@ -154,6 +154,33 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
                        int64_t chain_id_base, void *dev_best_out);
 int ym_batch_wait(ym_matcher *m, int slot, ym_result *per_chain, ym_result *best, int32_t *best_chain);
 
+/* ---- match against a prebuilt map (reference: Scan2DMatcherPy.match_scan_sets_with_map,
+ * /root/reference/yag_slam/scan_matching.py:124-173; YM_SEM_YAGPY matchers only -- Karto has no such entry) ---- */
+typedef struct ym_map ym_map;
+/* occupancy_grid_map_to_correlation_grid (/root/reference/yag_slam/helpers.py:24-34): every pixel of `image` equal to
+ * occupied_value becomes 1.0 and is max-smeared with the matcher's kernel (resolution, smear_deviation), on the device */
+ym_map *ym_map_from_occupancy(ym_matcher *m, const uint8_t *image, int width, int height, int pitch, int occupied_value);
+/* a correlation grid (float64 in [0, 1], row-major [y][x]) computed elsewhere */
+ym_map *ym_map_from_grid(ym_matcher *m, const double *cgrid, int width, int height);
+int ym_map_size(const ym_map *map, int *width, int *height);
+int ym_map_read(const ym_map *map, double *out, int64_t out_count); /* the float grid, width*height entries */
+void ym_map_destroy(ym_map *map);
+/* one find_best_pose_non_symmetric pass (/root/reference/yag_slam/helpers.py:434-573) */
+typedef struct ym_map_search {
+    double xy_search, xy_step;       /* +- metres around the centre, lattice step */
+    double angle_search, angle_step; /* +- radians, step */
+    double grid_resolution;          /* cell size the pass uses for indexing the map and in the penalty */
+    int32_t penalize;
+    int32_t reserved;
+} ym_map_search;
+/* The query scans' point readings (at their own poses) are matched as ONE point set against the map whose cell (0, 0)
+ * is at world (ox, oy): coarse pass around the mean of the query poses (coarse == NULL: the reference's constants
+ * 0.25 m / 0.01 m / 0.1 rad / 0.01 rad, cell size 0.05, no penalty -- scan_matching.py:152-153), then, if refine, the fine
+ * pass +-2 cells, +-0.01745 rad at 0.00349 with the matcher's resolution and `penalize`.  out->pose is the corrected
+ * mean pose (x, y, heading); the caller moves every query by its difference to the uncorrected mean. */
+int ym_match_map(ym_matcher *m, const ym_map *map, double ox, double oy, const ym_scan *const *queries, int n_queries,
+                 int penalize, int refine, const ym_map_search *coarse, ym_result *out);
+
 /* ---- introspection for parity tests (state of the LAST completed synchronous match) ---- */
 typedef struct ym_grid_info {
     int32_t width, height, pitch; /* device window (bytes) */

@@ -22,6 +22,7 @@ EXPORTS = (
     "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_option", "ym_debug_stamps",
     "ym_profile_enable",
     "ym_profile_read",
+    "ym_map_from_occupancy", "ym_map_from_grid", "ym_map_size", "ym_map_read", "ym_map_destroy", "ym_match_map",
 )
 
 
@@ -78,6 +79,11 @@ class YmResult(C.Structure):
         ("status", C.c_int32),
         ("reserved", C.c_int32),
     ]
+
+
+class YmMapSearch(C.Structure):
+    _fields_ = [("xy_search", C.c_double), ("xy_step", C.c_double), ("angle_search", C.c_double), ("angle_step", C.c_double),
+                ("grid_resolution", C.c_double), ("penalize", C.c_int32), ("reserved", C.c_int32)]
 
 
 class YmGridInfo(C.Structure):
@@ -163,6 +169,16 @@ def lib():
     L.ym_debug_stamps.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.c_int32]
     L.ym_profile_enable.argtypes = [vp, C.c_int]
     L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]
+    L.ym_map_from_occupancy.restype = vp
+    L.ym_map_from_occupancy.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ym_map_from_grid.restype = vp
+    L.ym_map_from_grid.argtypes = [vp, dp, C.c_int, C.c_int]
+    L.ym_map_size.argtypes = [vp, ip, ip]
+    L.ym_map_read.argtypes = [vp, dp, C.c_int64]
+    L.ym_map_destroy.argtypes = [vp]
+    L.ym_map_destroy.restype = None
+    L.ym_match_map.argtypes = [vp, vp, C.c_double, C.c_double, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(YmMapSearch),
+                               C.POINTER(YmResult)]
     _lib = L
     return L
 

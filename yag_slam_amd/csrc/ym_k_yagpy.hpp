@@ -28,6 +28,12 @@ struct YagArgs {
     size_t grid_stride;
     size_t vol_stride;   // entries per item in sums/out
     int32_t max_n, maxd, maxt;
+    // match against a prebuilt map (scan_matching.py:124-173, find_best_pose_non_symmetric helpers.py:434-573):
+    // map_w > 0 selects it.  The grid is the whole map (map_w x map_h cells, row pitch map_w) with corner (map_ox,
+    // map_oy); the cell size used for indexing AND in the penalty is the pass's own argument (the reference passes 0.05
+    // to the coarse pass whatever the map's resolution); the penalty is centred on the search centre.
+    int32_t map_w, map_h;
+    double map_ox, map_oy, map_res;
 };
 
 // numpy.arange(start, stop, step) for float64: length and i-th value (DOUBLE_fill)
@@ -81,8 +87,11 @@ __global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
     const int iy = c / nx, ix = c - iy * nx;
     const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
     const double xv = ax[ix], yv = ax[YM_YAG_MAX_DIM + iy], tv = ax[2 * YM_YAG_MAX_DIM + k];
-    const double ox = st.off_x, oy = st.off_y, res = a.g.res;
-    const int G = a.g.roi_w, w0 = a.g.win_origin, ww = a.g.win_w, pitch = a.g.pitch;
+    const bool map = a.map_w > 0;
+    const double ox = map ? a.map_ox : st.off_x, oy = map ? a.map_oy : st.off_y, res = map ? a.map_res : a.g.res;
+    const int GW = map ? a.map_w : a.g.roi_w, GH = map ? a.map_h : a.g.roi_w;
+    const int w0 = map ? 0 : a.g.win_origin, ww = map ? a.map_w : a.g.win_w, wh = map ? a.map_h : a.g.win_w;
+    const int pitch = map ? a.map_w : a.g.pitch;
     const double2 *__restrict__ rot = a.rot + ((size_t)b * a.maxt + k) * a.max_n;
     const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
     const int np = st.nq;
@@ -93,16 +102,18 @@ __global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
         const double x = xv + p.x, y = yv + p.y;
         const double gx = rint((x - ox) / res), gy = rint((y - oy) / res);
         const int _x = (int)gx, _y = (int)gy;
-        if (_x >= 0 && _x < G && _y >= 0 && _y < G) {
+        if (_x >= 0 && _x < GW && _y >= 0 && _y < GH) {
             const int wx = _x - w0, wy = _y - w0;
             // cells outside the device window are provably empty
-            if (wx >= 0 && wx < ww && wy >= 0 && wy < ww) sum += grid[wy * pitch + wx];
+            if (wx >= 0 && wx < ww && wy >= 0 && wy < wh) sum += grid[(size_t)wy * pitch + wx];
         }
     }
     double penalty_val = 1.0;
     if (a.penalize) {
         const double ct = a.pass ? st.ybest[0][3] : st.pose[2];
-        const double sx_ = ox + G * res / 2, sy_ = oy + G * res / 2;
+        // helpers.py:173-174: the grid's centre; find_best_pose_non_symmetric (helpers.py:451-452): the search centre
+        const double sx_ = map ? (a.pass ? st.ybest[0][1] : st.pose[0]) : ox + GW * res / 2;
+        const double sy_ = map ? (a.pass ? st.ybest[0][2] : st.pose[1]) : oy + GW * res / 2;
         const double sd = (xv - sx_) * (xv - sx_) + (yv - sy_) * (yv - sy_);
         const double dist_penalty = 1.0 - 0.2 * sd / (0.5 * res);
         const double sa = (tv - ct) * (tv - ct);
@@ -232,6 +243,72 @@ __global__ __launch_bounds__(1024) void yag_reduce_kernel(YagArgs a) {
             if (a.host_out) a.host_out[b] = st;
         }
     }
+}
+
+// ================================================================== prebuilt maps
+// helpers.py:24-34 occupancy_grid_map_to_correlation_grid: every cell of the image equal to `occupied_value` is set to
+// 1.0 and max-stamped with the float kernel, taps outside the image dropped.  As a gather: a cell's value is the
+// largest kernel tap over the occupied cells within reach -- the same set of candidates, and a maximum does not depend
+// on the order.  One thread per cell; `cgrid` keeps the float grid as the reference holds it, `g8` what scoring reads,
+// int(100 * cell) (helpers.py:142-145).
+__global__ __launch_bounds__(256) void map_from_occupancy_kernel(const uint8_t *image, int width, int height, int img_pitch,
+                                                                 int occupied_value, const double *kernel, int ksize,
+                                                                 double *cgrid, uint8_t *g8) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const int half = ksize / 2;
+    double v = 0.0;
+    for (int sy = 0; sy < ksize; sy++) {
+        const int py = y - (sy - half); // the stamped point that reaches (x, y) through tap (sx, sy)
+        if (py < 0 || py >= height) continue;
+        for (int sx = 0; sx < ksize; sx++) {
+            const int px = x - (sx - half);
+            if (px < 0 || px >= width) continue;
+            if (image[(size_t)py * img_pitch + px] == occupied_value) {
+                const double cand = kernel[sy * ksize + sx];
+                v = cand > v ? cand : v;
+            }
+        }
+    }
+    if (image[(size_t)y * img_pitch + x] == occupied_value) v = 1.0 > v ? 1.0 : v;
+    cgrid[(size_t)y * width + x] = v;
+    g8[(size_t)y * width + x] = (uint8_t)(int)(100 * v);
+}
+
+// a correlation grid computed elsewhere -> what scoring reads
+__global__ __launch_bounds__(256) void map_from_grid_kernel(const double *cgrid, size_t n, uint8_t *g8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g8[i] = (uint8_t)(int)(100 * cgrid[i]);
+}
+
+// The query point set of match_scan_sets_with_map (scan_matching.py:141-150): the world point readings of every query
+// scan at its own pose, concatenated in scan order, moved by _transform_points(., -ox_real, -oy_real, 0)
+// (helpers.py:71-78: a rotation by 0, then the shift).  One block; dynamic LDS = YM_PREP_LDS_BYTES(max_n).
+struct MapPointsArgs {
+    const YmScanRef *scans; // the query scans
+    int32_t n_scans, max_n;
+    double ox_real, oy_real;
+    double2 *out;           // [sum of readings]
+    YmItemState *state;     // nq is written here
+};
+__global__ __launch_bounds__(1024) void map_points_kernel(MapPointsArgs a) {
+    constexpr int NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
+    const PrepLds l = prep_lds(lds_raw, a.max_n);
+    int total = 0;
+    const double c0 = cos(0.0), s0 = sin(0.0), tx = -a.ox_real, ty = -a.oy_real;
+    for (int q = 0; q < a.n_scans; q++) {
+        const YmScanRef sr = a.scans[q];
+        const int np = project_points<NT>(sr, sr.pose[0], sr.pose[1], sr.pose[2], true, l.sx, l.sy, s_cnt);
+        for (int i = threadIdx.x; i < np; i += NT) {
+            const double px = l.sx[i], py = l.sy[i];
+            a.out[total + i] = make_double2((px * c0 - py * s0) + tx, (py * c0 + px * s0) + ty);
+        }
+        total += np;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.state->nq = total;
 }
 
 }  // namespace ym

@@ -176,6 +176,64 @@ class ScanMatcher(object):
             raise TypeError("match_scan_batch needs yag_slam_amd.models.LocalizedRangeScan instances")
         return h
 
+    # ---- match against a prebuilt map (Scan2DMatcherPy.match_scan_sets_with_map, scan_matching.py:124-173) ------------
+    def correlation_grid_from_occupancy(self, map_im, occupied_value=0):
+        """Device counterpart of `occupancy_grid_map_to_correlation_grid(map_im, res, smear_deviation, occupied_value)`
+        (/root/reference/yag_slam/helpers.py:24-34) with this matcher's resolution and smear: returns a resident
+        CorrelationMap (`.to_numpy()` gives the float grid the reference function returns)."""
+        im = np.ascontiguousarray(map_im, dtype=np.uint8)
+        if im.ndim != 2:
+            raise ValueError("occupancy image must be 2-D")
+        h = self._lib.ym_map_from_occupancy(self._m, im.ctypes.data_as(C.POINTER(C.c_uint8)), im.shape[1], im.shape[0],
+                                            im.strides[0], int(occupied_value))
+        if not h:
+            raise _capi.YmError(-1, _capi.last_error())
+        return CorrelationMap(self, h)
+
+    def upload_correlation_grid(self, cgrid):
+        """A correlation grid computed elsewhere (2-D float array, 0..1) as a resident CorrelationMap."""
+        g = np.ascontiguousarray(cgrid, dtype=np.float64)
+        if g.ndim != 2:
+            raise ValueError("correlation grid must be 2-D")
+        h = self._lib.ym_map_from_grid(self._m, g.ctypes.data_as(C.POINTER(C.c_double)), g.shape[1], g.shape[0])
+        if not h:
+            raise _capi.YmError(-1, _capi.last_error())
+        return CorrelationMap(self, h)
+
+    def match_scan_sets_with_map(self, cgrid, ox, oy, query_scans, penalty=True, do_fine=True, coarse=None):
+        """The reference's signature (scan_matching.py:124): the point readings of all `query_scans` are matched as one
+        set against the map `cgrid` (CorrelationMap or 2-D float array) whose cell (0, 0) lies at world (ox, oy).
+        Returns ScanMatcherResult(response, covariance, [corrected pose of every query scan], meta).
+        `coarse`: dict overriding the coarse pass the reference hard-codes (xy_search 0.25, xy_step 0.01,
+        angle_search 0.1, angle_step 0.01, grid_resolution 0.05, penalize False)."""
+        own = not isinstance(cgrid, CorrelationMap)
+        mp = self.upload_correlation_grid(cgrid) if own else cgrid
+        try:
+            hs = (C.c_void_p * len(query_scans))(*[self._require_native(q) for q in query_scans])
+            cs = None
+            if coarse:
+                cs = _capi.YmMapSearch(float(coarse.get("xy_search", 0.25)), float(coarse.get("xy_step", 0.01)),
+                                       float(coarse.get("angle_search", 0.1)), float(coarse.get("angle_step", 0.01)),
+                                       float(coarse.get("grid_resolution", 0.05)), int(bool(coarse.get("penalize", False))), 0)
+            res = _capi.YmResult()
+            _capi.check(self._lib.ym_match_map(self._m, mp._h, float(ox), float(oy), hs, len(query_scans), int(bool(penalty)),
+                                               int(bool(do_fine)), C.byref(cs) if cs else None, C.byref(res)))
+        finally:
+            if own:
+                mp.close()
+        if res.status != 0:
+            raise _capi.YmError(res.status, "empty search lattice or no query point")
+        r = _result(res)
+        # scan_matching.py:136-139,167-173: the search centre is the mean query position with heading 0; every query is
+        # moved by (corrected centre - centre)
+        xs = [float(q.corrected_pose.x) for q in query_scans]
+        ys = [float(q.corrected_pose.y) for q in query_scans]
+        oxy = Transform.from_position_euler(sum(xs) / float(len(xs)), sum(ys) / float(len(ys)), 0, 0, 0, 0)
+        diff = r.best_pose - oxy
+        r.meta["centre"] = (oxy.x, oxy.y, 0.0)
+        r.meta["corrected_centre"] = (r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1])
+        return ScanMatcherResult(r.response, r.covariance, [q.corrected_pose + diff for q in query_scans], r.meta)
+
     # ---- pipelined form ----------------------------------------------------------------------
     def match_scan_async(self, query, base_scans, penalty=True, do_fine=False, slot=0):
         hq = self._require_native(query)
@@ -239,6 +297,32 @@ class ScanMatcher(object):
         ms, n = C.c_double(), C.c_int64()
         _capi.check(self._lib.ym_profile_read(self._m, which, C.byref(ms), C.byref(n), int(bool(reset))))
         return ms.value, n.value
+
+
+class CorrelationMap(object):
+    """A correlation grid resident on the device (ym_map): built from an occupancy image or uploaded."""
+
+    def __init__(self, matcher, handle):
+        self.m, self._h = matcher, handle
+        w, h = C.c_int32(), C.c_int32()
+        _capi.check(matcher._lib.ym_map_size(handle, C.byref(w), C.byref(h)))
+        self.shape = (h.value, w.value)
+
+    def to_numpy(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        _capi.check(self.m._lib.ym_map_read(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.m._lib.ym_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MatchBatch(object):
