@@ -5,7 +5,9 @@ touches `.x`, `.y`, `.euler[-1]`, `from_position_euler`, `from_pose2d`, `+` and 
 (/root/reference/yag_slam/models.py:34-35,69; scan_matching.py:42,221; graph_slam.py:320-322).
 `a + b` composes (a then b in a's frame); `a - b` is b^-1 composed with a, so that
 `last.corrected_pose + (query.odom_pose - last.odom_pose)` is the odometry prior of
-graph_slam.py:320-324.
+graph_slam.py:320-324.  yag-slam's map files store a pose as tiny_tf does, position + quaternion
+(`x y z qx qy qz qw`, /root/reference/yag_slam/serde.py:94): the planar pose exposes those seven
+attributes and its constructor also takes them, so serde can write and rebuild it.
 """
 import math
 from collections import namedtuple
@@ -16,11 +18,24 @@ Pose2 = namedtuple("Pose2", ["x", "y", "yaw"])
 class Transform(object):
     __slots__ = ("x", "y", "z", "_yaw")
 
-    def __init__(self, x=0.0, y=0.0, z=0.0, yaw=0.0):
+    def __init__(self, x=0.0, y=0.0, z=0.0, *rest, **kw):
+        """Transform(x, y, z, yaw)  or, as tiny_tf spells it, Transform(x, y, z, qx, qy, qz, qw) (a rotation about z)."""
         self.x = float(x)
         self.y = float(y)
         self.z = float(z)
-        self._yaw = float(yaw)
+        if len(rest) == 4 or "qw" in kw:
+            qz = float(rest[2] if len(rest) == 4 else kw.get("qz", 0.0))
+            qw = float(rest[3] if len(rest) == 4 else kw.get("qw", 1.0))
+            self._yaw = 2.0 * math.atan2(qz, qw)
+        elif len(rest) <= 1:
+            self._yaw = float(rest[0] if rest else kw.get("yaw", 0.0))
+        else:
+            raise TypeError("Transform(x, y, z, yaw) or Transform(x, y, z, qx, qy, qz, qw)")
+
+    qx = property(lambda self: 0.0)
+    qy = property(lambda self: 0.0)
+    qz = property(lambda self: math.sin(0.5 * self._yaw))
+    qw = property(lambda self: math.cos(0.5 * self._yaw))
 
     @classmethod
     def from_position_euler(cls, x, y, z, roll, pitch, yaw):
