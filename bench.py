@@ -274,30 +274,59 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
             "collective": "all_gather of one 64-byte best record per rank" if world > 1 else "none"}
 
 
-def leg_cfg5(device, query, chain):
-    """BASELINE configs[4]: the stress lattice (search 2.0 m at 0.005 m, +-0.785 rad) as one match"""
+def leg_cfg5(device, query, chain, rank, world, torch, dist):
+    """BASELINE configs[4]: the stress lattice (search 2.0 m at 0.005 m, +-0.785 rad) as one match on one GPU; with
+    N > 1 also split over the ranks by coarse angle (grid replicated, response volume all-gathered over RCCL)"""
+    from yag_slam_amd import dist as ymdist
     from yag_slam_amd.scan_matching import ScanMatcher
     m = ScanMatcher(STRESS_CONFIG, device=device)
-    r = m.match_scan(query, chain, True, True)
-    for _ in range(3):
-        m.match_scan(query, chain, True, True)
-    n = 20
-    t0 = time.perf_counter()
-    for _ in range(n):
-        m.match_scan(query, chain, True, True)
-    dt = (time.perf_counter() - t0) / n
-    m.profile(True)
-    for _ in range(10):
-        m.match_scan(query, chain, True, True)
-    corr_ms, corr_n = m.profile_read(0)
-    m.profile(False)
-    cd, nq = r.meta["coarse_dims"], r.meta["n_query_points"]
-    corr_s = corr_ms / max(corr_n, 1) * 1e-3
-    alg = cd[0] * cd[1] * cd[2] * nq
-    out = {"lattice": "%dx%dx%d + %dx%dx%d" % (tuple(cd) + tuple(r.meta["fine_dims"])),
-           "hypotheses_per_match": r.meta["hypotheses"], "us_per_match": dt * 1e6, "scan_matches_per_s": 1.0 / dt,
-           "hypotheses_per_s": r.meta["hypotheses"] / dt, "correlate_kernel_us": corr_s * 1e6,
-           "correlate_algorithmic_GBps": alg / corr_s / 1e9, "correlate_frac_of_hbm_peak": alg / corr_s / 1e9 / HBM_PEAK_GBS}
+    out = {}
+    r = None
+    if rank == 0:
+        r = m.match_scan(query, chain, True, True)
+        for _ in range(3):
+            m.match_scan(query, chain, True, True)
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m.match_scan(query, chain, True, True)
+        dt = (time.perf_counter() - t0) / n
+        m.profile(True)
+        for _ in range(10):
+            m.match_scan(query, chain, True, True)
+        corr_ms, corr_n = m.profile_read(0)
+        m.profile(False)
+        cd, nq = r.meta["coarse_dims"], r.meta["n_query_points"]
+        corr_s = corr_ms / max(corr_n, 1) * 1e-3
+        alg = cd[0] * cd[1] * cd[2] * nq
+        out = {"lattice": "%dx%dx%d + %dx%dx%d" % (tuple(cd) + tuple(r.meta["fine_dims"])),
+               "hypotheses_per_match": r.meta["hypotheses"], "us_per_match": dt * 1e6, "scan_matches_per_s": 1.0 / dt,
+               "hypotheses_per_s": r.meta["hypotheses"] / dt, "correlate_kernel_us": corr_s * 1e6,
+               "correlate_algorithmic_GBps": alg / corr_s / 1e9, "correlate_frac_of_hbm_peak": alg / corr_s / 1e9 / HBM_PEAK_GBS}
+    if world > 1:
+        sp = ymdist.AngleSplitMatcher(m, rank, world)
+        g = sp.match_scan(query, chain, True, True)
+        for _ in range(3):
+            sp.match_scan(query, chain, True, True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            sp.match_scan(query, chain, True, True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dts = (time.perf_counter() - t0) / n
+        t = torch.tensor([dts], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            same = (g.response == r.response and g.covariance == r.covariance and
+                    (g.best_pose.x, g.best_pose.y, g.best_pose.euler[-1]) == (r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1]))
+            out["split_by_angle"] = {"gpus": world, "us_per_match": float(t.item()) * 1e6,
+                                     "hypotheses_per_s": r.meta["hypotheses"] / float(t.item()),
+                                     "identical_to_one_gpu": bool(same), "angles_per_gpu": sp.per,
+                                     "collective": "all_gather of %d doubles + all_reduce(MAX) of %d doubles per match" % (
+                                         sp.resp.numel(), sp.probs.numel())}
     m.close()
     return out
 
@@ -488,9 +517,11 @@ def main():
         by_config["cfg2_single_match"] = leg_single(m, query, chains[0], r1.meta["hypotheses"])
     if "cfg3" in legs and rank == 0:
         by_config["cfg3_sequential_mapping"] = leg_cfg3(m, gen["cfg3"], args.cfg3_scans)
-    if "cfg5" in legs and rank == 0:
+    if "cfg5" in legs and (rank == 0 or world > 1):
         q5, b5 = synth.single_match_scans(gen["scene"])
-        by_config["cfg5_stress"] = leg_cfg5(local_rank, q5, b5)
+        c5 = leg_cfg5(local_rank, q5, b5, rank, world, torch, dist)
+        if rank == 0:
+            by_config["cfg5_stress"] = c5
     if "cfg4" in legs:
         loop_m = ScanMatcher(None, loop=True, device=local_rank)
         c4 = leg_cfg4(loop_m, gen, args, rank, world, torch, dist)

@@ -154,6 +154,18 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
                        int64_t chain_id_base, void *dev_best_out);
 int ym_batch_wait(ym_matcher *m, int slot, ym_result *per_chain, ym_result *best, int32_t *best_chain);
 
+/* ---- one match split over several matchers by coarse angle (BASELINE configs[4] on 8 GPUs: one matcher per GPU) ----
+ * Every rank rasterises the same grid and scores the coarse angles [k_begin, k_end) only, writing their responses at
+ * their place in the caller-owned device volume dev_resp[nt][ny][nx] (doubles) and the per-(x, y) maxima of its slices
+ * into dev_probs[ny][nx] (doubles, cleared by the call).  The caller then completes both across ranks on the matcher's
+ * stream -- all-gather of the slices, element-wise MAX of dev_probs (RCCL) -- and calls _finish, which runs the rest of
+ * the match (arg-max, tie mean, covariances, the fine pass) on the whole volume: the result is bit-identical to an
+ * unsplit ym_match_scans on every rank.  Karto semantics only. */
+int ym_coarse_dims(const ym_matcher *m, int32_t dims[3]); /* nx, ny, ntheta of the coarse lattice */
+int ym_match_slice_begin(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base, int penalize,
+                         int refine, int k_begin, int k_end, double *dev_resp, double *dev_probs);
+int ym_match_slice_finish(ym_matcher *m, ym_result *out);
+
 /* ---- match against a prebuilt map (reference: Scan2DMatcherPy.match_scan_sets_with_map,
  * /root/reference/yag_slam/scan_matching.py:124-173; YM_SEM_YAGPY matchers only -- Karto has no such entry) ---- */
 typedef struct ym_map ym_map;

@@ -145,3 +145,63 @@ def test_sharded_loop_matcher_two_ranks(tmp_path, n_chains):
         assert w0[1] == 0.0 and allrec[1, 1] == -1.0               # rank 1's shard is empty
     with pytest.raises(ValueError):
         ymdist.ShardedLoopMatcher.from_local_shard(_StubMatcher([0.1] * 4), "q", [0, 1, 2], 0, 4, 0, 2, stream=False)
+
+
+# ---- AngleSplitMatcher (one match split by coarse angle), two ranks over gloo, stand-in matcher on CPU tensors -----
+class _StubSliceMatcher(object):
+    """slice_begin fills this rank's angles of the response volume and its own per-cell maxima through the raw
+    pointers, like the device kernels; slice_finish reads the whole volume back"""
+    NX, NY, NT = 5, 4, 7
+
+    @staticmethod
+    def value(k, c):
+        return ((k * 37 + c * 11) % 23) / 23.0
+
+    def coarse_dims(self):
+        return (self.NX, self.NY, self.NT)
+
+    def slice_begin(self, query, base, penalty, do_fine, k0, k1, dev_resp, dev_probs):
+        import ctypes as C
+        nxy = self.NX * self.NY
+        self.ptrs = (dev_resp, dev_probs)
+        probs = [0.0] * nxy
+        for k in range(k0, k1):
+            row = [self.value(k, c) for c in range(nxy)]
+            C.memmove(dev_resp + 8 * k * nxy, (C.c_double * nxy)(*row), 8 * nxy)
+            probs = [max(a, b) for a, b in zip(probs, row)]
+        C.memmove(dev_probs, (C.c_double * nxy)(*probs), 8 * nxy)
+
+    def slice_finish(self):
+        import ctypes as C
+        nxy = self.NX * self.NY
+        resp = np.ctypeslib.as_array((C.c_double * (self.NT * nxy)).from_address(self.ptrs[0])).copy()
+        probs = np.ctypeslib.as_array((C.c_double * nxy).from_address(self.ptrs[1])).copy()
+        return resp, probs
+
+
+def _angle_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from yag_slam_amd import dist as ymdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = ymdist.AngleSplitMatcher(_StubSliceMatcher(), rank, world, stream=False)
+        assert (sp.k0, sp.k1) == ((0, 4) if rank == 0 else (4, 7))
+        resp, probs = sp.match_scan("q", ["b"], True, True)
+        np.save(os.path.join(out_dir, "aresp%d.npy" % rank), resp)
+        np.save(os.path.join(out_dir, "aprobs%d.npy" % rank), probs)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_angle_split_matcher_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_angle_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    S = _StubSliceMatcher
+    nxy = S.NX * S.NY
+    want = np.array([[S.value(k, c) for c in range(nxy)] for k in range(S.NT)])
+    for r in (0, 1):
+        resp, probs = np.load(tmp_path / ("aresp%d.npy" % r)), np.load(tmp_path / ("aprobs%d.npy" % r))
+        assert np.array_equal(resp.reshape(S.NT, nxy), want)        # both ranks hold the whole volume
+        assert np.array_equal(probs, want.max(axis=0))              # and the maxima over ALL angles

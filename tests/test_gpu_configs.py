@@ -159,3 +159,49 @@ def test_sharded_loop_matcher_one_rank_rccl():
         assert w4[0] == max(p.response for p in per4) and int(w4[1]) == int(np.argmax([p.response for p in per4]))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["default", "stress"])
+def test_angle_sliced_match_equals_the_whole_match(which):
+    """configs[4]'s multi-GPU split, on one GPU: the coarse angles scored in three slices (as three ranks would) into one
+    response volume, per-(x, y) maxima combined with MAX, finish on the whole volume -- bit-identical to match_scan.
+    Then the same through AngleSplitMatcher over a 1-rank RCCL group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from yag_slam_amd import dist as ymdist
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    cfg = None if which == "default" else dict(search_size=2.0, resolution=0.005, coarse_search_angle_offset=0.785)
+    query, base = synth.single_match_scans()
+    ref = ScanMatcher(cfg).match_scan(query, base, True, True)
+    m = ScanMatcher(cfg)
+    nx, ny, nt = m.coarse_dims()
+    assert (nx, ny, nt) == tuple(ref.meta["coarse_dims"])
+    torch.cuda.set_device(0)
+    st = torch.cuda.Stream()
+    m.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        resp = torch.full((nt * nx * ny,), -7.0, dtype=torch.float64, device="cuda")
+        cuts = [0, nt // 3, nt // 3 + 1, nt]            # uneven slices, one of a single angle
+        probs = [torch.empty(nx * ny, dtype=torch.float64, device="cuda") for _ in range(3)]
+        for i in range(3):
+            m.slice_begin(query, base, True, True, cuts[i], cuts[i + 1], resp.data_ptr(), probs[i].data_ptr())
+        probs[2].copy_(torch.maximum(torch.maximum(probs[0], probs[1]), probs[2]))
+    got = m.slice_finish()
+    assert got.response == ref.response and got.covariance == ref.covariance and got.meta == ref.meta
+    assert (got.best_pose.x, got.best_pose.y, got.best_pose.euler[-1]) == (ref.best_pose.x, ref.best_pose.y, ref.best_pose.euler[-1])
+    assert float(resp.min()) >= 0.0                    # every slice was written
+    # through the class, one rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sp = ymdist.AngleSplitMatcher(ScanMatcher(cfg), 0, 1)
+        for _ in range(2):
+            got = sp.match_scan(query, base, True, True)
+            assert got.response == ref.response and got.covariance == ref.covariance
+            assert (got.best_pose.x, got.best_pose.y, got.best_pose.euler[-1]) == (ref.best_pose.x, ref.best_pose.y, ref.best_pose.euler[-1])
+    finally:
+        dist.destroy_process_group()
+

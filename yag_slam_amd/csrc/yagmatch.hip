@@ -141,6 +141,50 @@ struct Call {
     int penalize = 1, refine = 1;
     double coarse_angle_off = 0; // response expansion widens this
     int expansions = 0;
+    // one match split over several matchers by coarse angle (ym_match_slice_*): this matcher scores angles [k_begin,
+    // k_end) into caller-owned device buffers and stops after the score stage
+    int k_begin = 0, k_end = -1;
+    double *ext_resp = nullptr, *ext_probs = nullptr;
+    bool slice = false;
+};
+
+// Everything one call's launches share: sizes, lattices, the device window, how the coarse correlate is cut up,
+// strides, the descriptor, and which tiles the raster covers.  Filled in by the plan_* functions below.
+struct CallPlan {
+    int B = 0, nscans = 0, max_n = 1, max_base = 1;
+    bool yag = false;
+    YmGeom g;
+    YmLattice lc, lf;
+    // device window
+    int tiles_x = 0, tiles_y = 0;
+    size_t grid_stride = 0;
+    // coarse correlate decomposition
+    int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
+    int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
+    // yagpy lattice bounds
+    int ymaxd = 0, ymaxt = 0;
+    size_t yvol = 0;
+    // strides
+    int nt_stride = 0, dim_stride = 0, score_blocks = 0;
+    size_t sums_c = 0, sums_f = 0, partial_stride = 0;
+    // call descriptor
+    size_t scans_bytes = 0, desc_bytes = 0;
+    bool inline_desc = false;
+    YmScanRef *hs = nullptr;
+    YmItem *hi = nullptr;
+    const YmScanRef *d_scans = nullptr;
+    const YmItem *d_items = nullptr;
+    // raster coverage
+    int launch[4] = {0, 0, -1, -1}, ltx = 0, lty = 0, tile_cap = 1;
+    bool use_tile_list = false;
+    unsigned long long *stamps = nullptr;
+    // batches: heavy work once per distinct scan (points_kernel), then the light cells_kernel
+    bool split_prepare = false;
+    int n_jobs = 0;
+    std::vector<int32_t> jobs, job_slot; // travel at the end of the call descriptor
+    double *resp = nullptr, *probs = nullptr; // the matcher's buffers, or the caller's on an angle-sliced match
+    int k_begin = 0, k_end = 0;
+    const int32_t *d_jobs = nullptr, *d_job_slot = nullptr;
 };
 
 struct Slot {
@@ -152,6 +196,7 @@ struct Slot {
     YmLattice coarse{}, fine{};
     int n_items = 0;
     int64_t chain_id_base = 0;
+    CallPlan plan;     // angle-sliced match: kept between ym_match_slice_begin and _finish
     void *dev_best_out = nullptr; // optional device buffer (8 doubles) for the cross-rank arg-max
     void *dev_best_user = nullptr; // the same pointer, kept until the slot is collected (rewritten after a response expansion)
 };
@@ -443,43 +488,6 @@ int prof_collect(ym_matcher *m) {
 }
 
 // ---------------------------------------------------------------- launch one call
-// Everything one call's launches share: sizes, lattices, the device window, how the coarse correlate is cut up,
-// strides, the descriptor, and which tiles the raster covers.  Filled in by the plan_* functions below.
-struct CallPlan {
-    int B = 0, nscans = 0, max_n = 1, max_base = 1;
-    bool yag = false;
-    YmGeom g;
-    YmLattice lc, lf;
-    // device window
-    int tiles_x = 0, tiles_y = 0;
-    size_t grid_stride = 0;
-    // coarse correlate decomposition
-    int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
-    int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
-    // yagpy lattice bounds
-    int ymaxd = 0, ymaxt = 0;
-    size_t yvol = 0;
-    // strides
-    int nt_stride = 0, dim_stride = 0, score_blocks = 0;
-    size_t sums_c = 0, sums_f = 0, partial_stride = 0;
-    // call descriptor
-    size_t scans_bytes = 0, desc_bytes = 0;
-    bool inline_desc = false;
-    YmScanRef *hs = nullptr;
-    YmItem *hi = nullptr;
-    const YmScanRef *d_scans = nullptr;
-    const YmItem *d_items = nullptr;
-    // raster coverage
-    int launch[4] = {0, 0, -1, -1}, ltx = 0, lty = 0, tile_cap = 1;
-    bool use_tile_list = false;
-    unsigned long long *stamps = nullptr;
-    // batches: heavy work once per distinct scan (points_kernel), then the light cells_kernel
-    bool split_prepare = false;
-    int n_jobs = 0;
-    std::vector<int32_t> jobs, job_slot; // travel at the end of the call descriptor
-    const int32_t *d_jobs = nullptr, *d_job_slot = nullptr;
-};
-
 // sizes, lattices (ScanMatcher::MatchScan), the device window, the correlate decomposition, device buffers
 int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     Call &call = slot.call;
@@ -610,6 +618,11 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     }
     if ((rc = m->blockmax.ensure((size_t)B * P.score_blocks))) return rc;
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
+    P.resp = call.ext_resp ? call.ext_resp : m->resp.p;
+    P.probs = call.ext_probs ? call.ext_probs : m->probs.p;
+    P.k_begin = call.slice ? std::max(0, call.k_begin) : 0;
+    P.k_end = call.slice ? std::min(lc.nt, call.k_end) : lc.nt;
+    if (call.slice && (yag || B != 1)) return set_err(YM_ERR_UNSUPPORTED, "angle-sliced matches are single Karto matches");
     P.stamps = m->stamps_on ? m->stamps.p : nullptr;
     return YM_OK;
 }
@@ -885,7 +898,7 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
 void enqueue_prepare(ym_matcher *m, const CallPlan &P) {
     ym::PrepareArgs a;
     a.scans = P.d_scans; a.items = P.d_items; a.g = P.g; a.lat = P.lc; a.states = m->states.p; a.qlocal = m->qlocal.p;
-    a.cells = m->cells.p; a.bbox = m->bbox.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = m->probs.p;
+    a.cells = m->cells.p; a.bbox = m->bbox.p; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p; a.probs = P.probs;
     a.max_n = P.max_n; a.max_base = P.max_base; a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.stamps = P.stamps;
     a.use_inline = P.inline_desc ? 1 : 0;
     a.pad0 = 0;
@@ -986,14 +999,16 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     a.qlocal = m->qlocal.p; a.hypcell = m->hypcell.p; a.states = m->states.p; a.partial = m->partial.p; a.partial_stride = P.partial_stride;
     a.max_n = P.max_n; a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.chunk = P.chunk; a.n_chunks = P.n_chunks;
     a.ngx = P.ngx; a.nx_pad = P.nx_pad; a.sx = P.sx; a.stamps = P.stamps; a.tpb = P.tpb; a.cw = P.cw;
+    a.k_begin = P.k_begin; a.nk = std::max(0, P.k_end - P.k_begin);
+    if (a.nk == 0) return YM_OK; // an empty angle slice
     int rc;
     hipEvent_t ev_k = nullptr;
     if ((rc = prof_begin(m, 0, &ev_k))) return rc;
-    const dim3 grid_dim(P.job_blocks, P.ktiles * P.n_groups, P.B);
+    const dim3 grid_dim(P.job_blocks, a.nk * P.n_groups, P.B);
     const size_t pad_lds = (size_t)m->corr_pad_lds;
     if (P.sx == 2 && m->use_lds_correlate >= 1 && P.njobs <= 128) {
         a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
-        hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((P.njobs + 63) / 64, P.lc.nt * P.n_chunks, P.B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((P.njobs + 63) / 64, a.nk * P.n_chunks, P.B), dim3(256), 0, st, a);
     }
     else if (P.sx == 2 && P.corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
     else if (P.sx == 2 && P.corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
@@ -1005,25 +1020,32 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
 // ---- K5 score, then the finish stage: fine_kernel (coarse arg-max/mean + 3x3 fine lattice, one block per fine angle)
 // + final_kernel (covariances, fine arg-max/mean) for a few items, the one-block finish_kernel on batches; results
 // land in pinned host memory
-void enqueue_score_and_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
+void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
+    hipStream_t st = m->stream;
+    const YmLattice &lc = P.lc;
+    m->sums_pass_offset[0] = 0;
+    m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
+    ym::ScoreArgs a;
+    a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
+    a.sums = m->sums.p; a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
+    a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
+    a.probs = reinterpret_cast<unsigned long long *>(P.probs); a.probs_stride = (size_t)lc.nx * lc.ny;
+    const int nxy = lc.nx * lc.ny;
+    a.h_begin = P.k_begin * nxy; a.h_end = P.k_end * nxy;
+    a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's blocks are not the volume's: recomputed once it is whole
+    const int blocks = slot.call.slice ? (a.h_end - a.h_begin + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS : P.score_blocks;
+    if (blocks > 0) hipLaunchKernelGGL(ym::score_kernel, dim3(blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
+}
+
+void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
     hipStream_t st = m->stream;
     const Call &call = slot.call;
     const YmLattice &lc = P.lc, &lf = P.lf;
-    m->sums_pass_offset[0] = 0;
-    m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
-    {
-        ym::ScoreArgs a;
-        a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
-        a.sums = m->sums.p; a.sums_stride = P.sums_c; a.resp = m->resp.p; a.blockmax = m->blockmax.p;
-        a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
-        a.probs = reinterpret_cast<unsigned long long *>(m->probs.p); a.probs_stride = (size_t)lc.nx * lc.ny;
-        hipLaunchKernelGGL(ym::score_kernel, dim3(P.score_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
-    }
     ym::FinishArgs a;
     a.g = P.g; a.lc = lc; a.lf = lf; a.refine = call.refine; a.max_n = P.max_n; a.nt_stride = lf.nt;
     a.n_blocks = P.score_blocks; a.states = m->states.p;
     a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
-    a.resp = m->resp.p; a.sums_stride = P.sums_c; a.blockmax = m->blockmax.p; a.probs = m->probs.p;
+    a.resp = P.resp; a.sums_stride = P.sums_c; a.blockmax = m->blockmax.p; a.probs = P.probs;
     a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = P.grid_stride;
     a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
     a.fsums_stride = P.sums_f; a.stamps = P.stamps;
@@ -1055,7 +1077,9 @@ int launch_call(ym_matcher *m, Slot &slot) {
         enqueue_yagpy_passes(m, slot, P);
     } else {
         if ((rc = enqueue_correlate(m, P))) return rc;
-        enqueue_score_and_finish(m, slot, P);
+        enqueue_score(m, slot, P);
+        if (!slot.call.slice) enqueue_finish(m, slot, P);
+        else slot.plan = P; // ym_match_slice_finish picks up here
     }
     if (slot.dev_best_out)
         hipLaunchKernelGGL(ym::argbest_kernel, dim3(1), dim3(256), 0, st, m->states.p, P.B, (long long)slot.chain_id_base,
@@ -1553,6 +1577,63 @@ int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *sc
     if (rc == YM_OK) rc = ym_batch_wait(m, slot_idx, per_chain, best, best_chain);
     ym_batch_destroy(b);
     return rc;
+}
+
+// ---- one match split by coarse angle over several matchers (one per GPU): BASELINE configs[4] on 8 GPUs
+int ym_coarse_dims(const ym_matcher *m, int32_t dims[3]) {
+    if (!m || !dims) return set_err(YM_ERR_INVALID, "null argument");
+    if (m->cfg.semantics != YM_SEM_KARTO) return set_err(YM_ERR_UNSUPPORTED, "the Karto lattice only");
+    const YmGeom &g = m->geom;
+    const YmLattice l = make_lattice(g, 0.5 * (g.side - 1) * g.res, 2 * g.res, m->cfg.coarse_search_angle_offset,
+                                     m->cfg.coarse_angle_resolution, 0, 0);
+    dims[0] = l.nx; dims[1] = l.ny; dims[2] = l.nt;
+    return YM_OK;
+}
+
+int ym_match_slice_begin(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base, int penalize,
+                         int refine, int k_begin, int k_end, double *dev_resp, double *dev_probs) {
+    if (!m || !dev_resp || !dev_probs) return set_err(YM_ERR_INVALID, "null argument");
+    if (k_begin < 0 || k_end < k_begin) return set_err(YM_ERR_INVALID, "bad angle slice [%d, %d)", k_begin, k_end);
+    Slot &slot = m->slots[kAsyncSlots];
+    if (slot.in_flight && !slot.call.slice) return set_err(YM_ERR_BUSY, "the synchronous slot is in flight");
+    if (slot.in_flight) { // another slice of the same volume scored by this matcher (tests; a rank owning two blocks)
+        HIP_TRY(hipEventSynchronize(slot.done));
+        slot.in_flight = false;
+    }
+    Call call;
+    int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
+    if (rc) return rc;
+    call.slice = true;
+    call.k_begin = k_begin; call.k_end = k_end;
+    call.ext_resp = dev_resp; call.ext_probs = dev_probs;
+    slot.call = call;
+    return launch_call(m, slot); // stops after the score stage; stream-ordered, no host wait
+}
+
+int ym_match_slice_finish(ym_matcher *m, ym_result *out) {
+    if (!m || !out) return set_err(YM_ERR_INVALID, "null argument");
+    Slot &slot = m->slots[kAsyncSlots];
+    if (!slot.in_flight || !slot.call.slice) return set_err(YM_ERR_BUSY, "no angle-sliced match in flight");
+    DEV_GUARD(m->device);
+    const CallPlan &P = slot.plan;
+    // the caller has completed the response volume (all slices gathered) and the per-(x, y) maxima (max over all
+    // slices) on this stream: block maxima of the whole volume, then the ordinary finish stage
+    hipLaunchKernelGGL(ym::blockmax_kernel, dim3(P.score_blocks), dim3(YM_SCORE_THREADS), 0, m->stream, P.resp, (int)P.sums_c, m->blockmax.p);
+    enqueue_finish(m, slot, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(slot.done, m->stream));
+    const Call sliced = slot.call;
+    slot.call.slice = false;
+    slot.call.ext_resp = slot.call.ext_probs = nullptr;
+    slot.call.k_begin = 0; slot.call.k_end = -1;
+    ym_result r;
+    // Karto's response expansion re-runs the match with a wider angle range: done by finish_call on this matcher alone,
+    // over the whole (wider) lattice -- every rank does the same and gets the same result
+    int rc = finish_call(m, slot, &r);
+    (void)sliced;
+    if (rc) return rc;
+    *out = r;
+    return YM_OK;
 }
 
 // ---- prebuilt maps: the "match against a map" entry of the reference's Python matcher

@@ -23,6 +23,8 @@ struct CorrArgs {
     int32_t n_chunks;
     int32_t tpb;           // staged kernel: development mode switch
     int32_t cw;            // chunk-waves per block (1, 2 or 4): consecutive beam chunks summed inside a block
+    int32_t k_begin, nk;   // the coarse angles this launch scores: [k_begin, k_begin + nk) (all of them unless the match
+                           // is split over several matchers by angle)
     int32_t ngx;           // x groups per row = ceil(nx / G)
     int32_t nx_pad;        // ngx * G
     int32_t sx;            // cell stride between x-adjacent hypotheses (1 or 2)
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     const int cw = a.cw, jw = 4 / cw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jw_idx = wave % jw, cw_idx = wave / jw;
-    const int k = by % a.lat.nt, group = by / a.lat.nt;
+    const int k = a.k_begin + by % a.nk, group = by / a.nk;
     const int chunk = group * cw + cw_idx;
     const int job = (bx * jw + jw_idx) * 64 + lane;
     __shared__ int offs_all[4][512];
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     const int b = xcd_item_of_block(bx, by);
-    const int k = by % a.lat.nt, chunk = by / a.lat.nt;
+    const int k = a.k_begin + by % a.nk, chunk = by / a.nk;
     const int njobs = a.lat.ny * a.ngx;
     const int j_first = bx * 64, j_last = min(njobs, j_first + 64) - 1;
     const bool active = j_first + lane <= j_last;

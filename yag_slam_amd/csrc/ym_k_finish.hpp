@@ -19,6 +19,8 @@ struct ScoreArgs {
     unsigned long long *probs; // [B][ny*nx] bit patterns of non-negative doubles, zeroed by prepare_kernel
     size_t probs_stride;
     int32_t n_chunks, nx_pad, n_blocks;
+    int32_t h_begin, h_end;   // hypotheses [h_begin, h_end) of the [k][iy][ix] volume (a slice of angles, or all)
+    int32_t write_blockmax;
     unsigned long long *stamps;
 };
 
@@ -47,10 +49,11 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     const int b = blockIdx.y;
     const YmItemState &st = a.states[b];
     const int nx = a.lat.nx, ny = a.lat.ny, nt = a.lat.nt, nxy = nx * ny;
-    const int h = blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
+    const int h = a.h_begin + blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
     double r = -1.0;
     YM_STAMP(a, 10);
-    if (h < nxy * nt) {
+    (void)nt;
+    if (h < a.h_end) {
         const int k = h / nxy, c = h - k * nxy;
         const int iy = c / nx, ix = c - iy * nx;
         const uint16_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
@@ -68,9 +71,20 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
         // u64 order of the bit patterns is the numeric order and an integer atomic max is exact.
         if (r > 0.0) atomicMax(&a.probs[(size_t)b * a.probs_stride + c], (unsigned long long)__double_as_longlong(r));
     }
-    const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
-    if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + blockIdx.x] = m;
+    if (a.write_blockmax) {
+        const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
+        if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + blockIdx.x] = m;
+    }
     YM_STAMP(a, 11);
+}
+
+// maxima of YM_SCORE_THREADS consecutive responses of a volume that was scored in angle slices (by several matchers):
+// what score_kernel writes itself when it scores the whole volume.  grid (n_blocks)
+__global__ __launch_bounds__(YM_SCORE_THREADS) void blockmax_kernel(const double *resp, int n, double *blockmax) {
+    __shared__ double scratch[16];
+    const int h = blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
+    const double m = block_reduce(h < n ? resp[h] : -1.0, OpMaxD(), -1.0, scratch);
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = m;
 }
 
 // ================================================================== K6 finish

@@ -1,4 +1,10 @@
-"""Loop-closure batches across the GPUs of one node (one process per GPU, torch.distributed).
+"""The matcher across the GPUs of one node (one process per GPU, torch.distributed; "nccl" is RCCL on ROCm).
+
+Two splits: loop-closure BATCHES shard by chain (ShardedLoopMatcher, below: no data-path
+collective, one all-gather of a 64-byte record), and ONE huge match shards by coarse angle (AngleSplitMatcher, at the
+end: the grid is rasterised on every rank, the response volume is all-gathered).
+
+Loop-closure batches:
 
 The reference closes loops by matching one query scan against candidate chains one after another
 (/root/reference/yag_slam/graph_slam.py:217-254).  Chains are independent problems, so they shard
@@ -125,3 +131,48 @@ class ShardedLoopMatcher(object):
             per, _, _ = self.batch.wait(slot)
         win, allrec = self.reduce(record, group)
         return win, allrec, per
+
+
+class AngleSplitMatcher(object):
+    """ONE match over `world` GPUs (BASELINE configs[4]: 201 x 201 x 46 coarse hypotheses): every rank rasterises the same
+    grid and scores its block of coarse angles; the response slices are all-gathered in place (RCCL), the per-(x, y)
+    maxima (Karto's search-space probability grid) reduced with MAX; arg-max, tie mean, covariances and the fine pass then
+    run on the whole volume on every rank.  Integer sums and fp64 responses do not depend on who computed them, and
+    the finish stage is the single-GPU one, so every rank returns the bits a single-GPU match_scan returns.
+
+    The exchange is one all-gather of nt_pad * ny * nx doubles (15 MB for configs[4]) + one all-reduce of ny * nx doubles
+    (0.3 MB) per match; on xGMI that costs about as much as the 1/world of the correlate it saves on that config, so this
+    is for lattices larger than one GPU wants to score alone, not a latency win on configs[4] itself."""
+
+    def __init__(self, matcher, rank, world, group=None, stream=None):
+        import torch
+        self.matcher, self.rank, self.world, self.group = matcher, rank, world, group
+        nx, ny, nt = matcher.coarse_dims()
+        self.nxy, self.nt = nx * ny, nt
+        self.per = (nt + world - 1) // world                   # angles per rank; the last ranks may get fewer, or none
+        self.k0 = min(nt, rank * self.per)
+        self.k1 = min(nt, self.k0 + self.per)
+        if stream is None:
+            stream = torch.cuda.current_stream()
+            if stream.cuda_stream == 0:                        # see ShardedLoopMatcher
+                stream = torch.cuda.Stream()
+        self.torch_stream = stream
+        if stream is not False:
+            matcher.set_stream(stream.cuda_stream)
+        dev = "cpu" if stream is False else "cuda"
+        self.resp = torch.zeros(world * self.per * self.nxy, dtype=torch.float64, device=dev)
+        self.probs = torch.zeros(self.nxy, dtype=torch.float64, device=dev)
+
+    def match_scan(self, query, base_scans, penalty=True, do_fine=False):
+        import contextlib
+        import torch
+        import torch.distributed as dist
+        self.matcher.slice_begin(query, base_scans, penalty, do_fine, self.k0, self.k1, self.resp.data_ptr(), self.probs.data_ptr())
+        ctx = contextlib.nullcontext() if self.torch_stream is False else torch.cuda.stream(self.torch_stream)
+        with ctx:
+            if self.world > 1:
+                chunk = self.per * self.nxy
+                mine = self.resp[self.rank * chunk:(self.rank + 1) * chunk]
+                dist.all_gather_into_tensor(self.resp, mine, group=self.group)           # in place: slice r lands at r * chunk
+                dist.all_reduce(self.probs, op=dist.ReduceOp.MAX, group=self.group)
+        return self.matcher.slice_finish()

@@ -176,6 +176,29 @@ class ScanMatcher(object):
             raise TypeError("match_scan_batch needs yag_slam_amd.models.LocalizedRangeScan instances")
         return h
 
+    # ---- one match split over several matchers by coarse angle (yag_slam_amd.dist.AngleSplitMatcher) -----------------
+    def coarse_dims(self):
+        """(nx, ny, ntheta) of the coarse lattice of this matcher's config"""
+        d = (C.c_int32 * 3)()
+        _capi.check(self._lib.ym_coarse_dims(self._m, d))
+        return tuple(d[:])
+
+    def slice_begin(self, query, base_scans, penalty, do_fine, k_begin, k_end, dev_resp, dev_probs):
+        """Enqueue the match up to the score stage for coarse angles [k_begin, k_end); responses and per-(x, y) maxima go
+        to the caller's device buffers (raw pointers).  No host wait."""
+        hq = self._require_native(query)
+        arr = (C.c_void_p * max(1, len(base_scans)))(*self._handles(base_scans))
+        _capi.check(self._lib.ym_match_slice_begin(self._m, hq, arr, len(base_scans), int(bool(penalty)), int(bool(do_fine)),
+                                                   int(k_begin), int(k_end), C.c_void_p(dev_resp), C.c_void_p(dev_probs)))
+
+    def slice_finish(self):
+        """The rest of the match on the completed volume; returns the ScanMatcherResult of the whole match."""
+        res = _capi.YmResult()
+        _capi.check(self._lib.ym_match_slice_finish(self._m, C.byref(res)))
+        if res.status != 0:
+            raise _capi.YmError(res.status, "Mapper FATAL ERROR - unable to find best position / index out of range")
+        return _result(res)
+
     # ---- match against a prebuilt map (Scan2DMatcherPy.match_scan_sets_with_map, scan_matching.py:124-173) ------------
     def correlation_grid_from_occupancy(self, map_im, occupied_value=0):
         """Device counterpart of `occupancy_grid_map_to_correlation_grid(map_im, res, smear_deviation, occupied_value)`
