@@ -44,6 +44,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--launch-batch", type=int, default=256, help="matches per enqueue (workspace size)")
+    ap.add_argument("--lanes", type=int, default=1, help="matchers (stream + workspace each) the enqueues of a step alternate over")
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cfg4-chains", type=int, default=CFG4_CHAINS)
@@ -401,14 +402,21 @@ def main():
     if "cfg2x" in legs:
         LB = args.launch_batch
         E = args.batch // LB  # enqueues per step
-        batches = [m.make_batch(query, chains[e * LB:(e + 1) * LB]) for e in range(E)]
-        nslots = min(64, 2 * E)
+        # lanes: independent matchers (own stream + workspace); enqueue e of a step goes to lane e % lanes, so the
+        # small tail kernels of one enqueue overlap the next one's big ones
+        lanes = [m] + [ScanMatcher(None, device=local_rank) for _ in range(max(1, args.lanes) - 1)]
+        lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in lanes[1:]]
+        for lm, ls in zip(lanes[1:], lane_streams[1:]):
+            lm.set_stream(ls.cuda_stream)
+        NL = len(lanes)
+        batches = [lanes[e % NL].make_batch(query, chains[e * LB:(e + 1) * LB]) for e in range(E)]
+        nslots = min(64, 2 * ((E + NL - 1) // NL))
         nbuf = 2
         records = torch.zeros((nbuf, E, ymdist.RECORD), dtype=torch.float64, device="cuda")
         gathered = torch.zeros((nbuf, world * E * ymdist.RECORD), dtype=torch.float64, device="cuda")
         works = [None] * nbuf
-        used = [None] * nslots  # which batch object a slot's call belongs to
-        counter = [0]
+        used = [[None] * nslots for _ in lanes]  # per lane: which batch object a slot's call belongs to
+        counter = [0] * NL
 
         def step(i):
             b = i % nbuf
@@ -416,23 +424,27 @@ def main():
                 works[b].wait()  # its gathered records are about to be overwritten
                 works[b] = None
             for e in range(E):
-                s = counter[0] % nslots
-                counter[0] += 1
-                if used[s] is not None:
-                    used[s].wait(s, per_chain=False)  # recycle the slot (long since finished)
+                ln = e % NL
+                s = counter[ln] % nslots
+                counter[ln] += 1
+                if used[ln][s] is not None:
+                    used[ln][s].wait(s, per_chain=False)  # recycle the slot (long since finished)
                 batches[e].run_async(True, True, slot=s, chain_id_base=rank * args.batch + e * LB,
                                      dev_best_out=records[b, e].data_ptr())
-                used[s] = batches[e]
+                used[ln][s] = batches[e]
             if dist is not None:
                 # cross-rank arg-max payload: E 64-byte records per rank.  Asynchronous: RCCL's stream waits for this
-                # step's records, the launch stream goes straight on to the next step
+                # step's records (on every lane's stream), the launch streams go straight on to the next step
+                for ls in lane_streams[1:]:
+                    lane_streams[0].wait_stream(ls)
                 works[b] = dist.all_gather_into_tensor(gathered[b], records[b].view(-1), async_op=True)
 
         def drain():
-            for s in range(nslots):
-                if used[s] is not None:
-                    used[s].wait(s, per_chain=False)
-                    used[s] = None
+            for ln in range(NL):
+                for s in range(nslots):
+                    if used[ln][s] is not None:
+                        used[ln][s].wait(s, per_chain=False)
+                        used[ln][s] = None
             for b in range(nbuf):
                 if works[b] is not None:
                     works[b].wait()
@@ -467,13 +479,17 @@ def main():
         dt = float(t.item())
 
         # roofline of the dominant kernel (coarse correlate): HIP events on the launch stream, second pass
-        m.profile(True)
+        for lm in lanes:
+            lm.profile(True)
         for i in range(min(args.steps, 4)):
             step(i)
         drain()
-        corr_ms, corr_n = m.profile_read(0)
-        call_ms, call_n = m.profile_read(2)
-        m.profile(False)
+        corr_ms = corr_n = call_ms = call_n = 0
+        for lm in lanes:
+            a_, b_ = lm.profile_read(0)
+            c_, d_ = lm.profile_read(2)
+            corr_ms, corr_n, call_ms, call_n = corr_ms + a_, corr_n + b_, call_ms + c_, call_n + d_
+            lm.profile(False)
 
         nq = per[0].meta["n_query_points"]
         cd = per[0].meta["coarse_dims"]
@@ -487,7 +503,7 @@ def main():
             "workload": "cfg2 x batch: %d independent single-match problems per step per GPU (1081-beam query vs distinct "
                         "10-scan chains, search 0.5 m / 0.349 rad, resolution 0.01, coarse 26x26x21 + fine 3x3x11, penalty "
                         "on), Karto semantics, issued as %d enqueues of %d" % (args.batch, E, LB),
-            "batch_per_gpu": args.batch, "launch_batch": LB, "hypotheses_per_match": hyp_per_match,
+            "batch_per_gpu": args.batch, "launch_batch": LB, "lanes": NL, "hypotheses_per_match": hyp_per_match,
             "scan_matches_per_s": args.batch * world * args.steps / dt,
             "timed_seconds": dt,
             "collective": "all_gather of %d 64-byte best records per rank per step" % E if world > 1 else "none",
@@ -507,6 +523,8 @@ def main():
             "l1_lane_access_rate": l1,
         }
         del batches
+        for lm in lanes[1:]:
+            lm.close()
 
     if dist is not None:
         dist.barrier()

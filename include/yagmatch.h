@@ -193,6 +193,22 @@ typedef struct ym_map_search {
 int ym_match_map(ym_matcher *m, const ym_map *map, double ox, double oy, const ym_scan *const *queries, int n_queries,
                  int penalize, int refine, const ym_map_search *coarse, ym_result *out);
 
+/* ---- occupancy-grid rendering: karto_scanmatcher.create_occupancy_grid(scans, resolution, range_threshold)
+ * (/root/reference/yag_slam/graph_slam.py:341-342, /root/reference/ros1/slam_node_ros1:187-202).  Every scan is ray-traced
+ * from its pose (open_karto OccupancyGrid::CreateFromScans): cells count passes and end-point hits, a cell passed more
+ * than twice is occupied when hits / passes > 0.1, else free.  image[y][x] uses the codes the ROS node reads: 0 occupied,
+ * 200 unknown, 255 free; row 0 is the lowest y; cell (0, 0) is at world (offset_x, offset_y).  Parity unpinned (the
+ * wheel's source is not in the reference tree). */
+typedef struct ym_occupancy ym_occupancy;
+typedef struct ym_occupancy_info {
+    int32_t width, height;
+    double offset_x, offset_y, resolution;
+} ym_occupancy_info;
+ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, double resolution, double range_threshold);
+int ym_occupancy_get_info(const ym_occupancy *og, ym_occupancy_info *info);
+int ym_occupancy_read(const ym_occupancy *og, uint8_t *image, int64_t image_bytes); /* width*height bytes */
+void ym_occupancy_destroy(ym_occupancy *og);
+
 /* ---- introspection for parity tests (state of the LAST completed synchronous match) ---- */
 typedef struct ym_grid_info {
     int32_t width, height, pitch; /* device window (bytes) */

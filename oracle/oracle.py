@@ -127,6 +127,8 @@ def load(path=None):
     lib.orc_raster_points.argtypes = [C.c_void_p, ip]
     lib.orc_last_serial_seconds.restype = C.c_double
     lib.orc_last_serial_seconds.argtypes = [C.c_void_p]
+    lib.orc_occupancy_grid.argtypes = [C.POINTER(OrcScan), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, ip, ip,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.c_longlong]
     lib.orc_query_local.restype = C.POINTER(C.c_double)
     lib.orc_query_local.argtypes = [C.c_void_p, ip]
     dp = C.POINTER(C.c_double)
@@ -328,3 +330,24 @@ def arange(start, stop, step):
     out = np.zeros(max(1, n))
     lib.orc_arange(start, stop, step, _dptr(out), n)
     return out[:n]
+
+
+def occupancy_grid(scans, resolution, range_threshold):
+    """duck-typed scans (with .max_range) -> (image uint8 [h][w], (offset_x, offset_y)); see orc_occupancy_grid"""
+    lib = load()
+    keep, arr = [], []
+    for sc in scans:
+        s, k = scan_from(sc)
+        arr.append(s)
+        keep.append(k)
+    a = (OrcScan * len(arr))(*arr)
+    mr = (C.c_double * len(arr))(*[float(getattr(sc, "max_range", 1e300)) for sc in scans])
+    w, h, ox, oy = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+    if lib.orc_occupancy_grid(a, mr, len(arr), float(resolution), float(range_threshold), C.byref(w), C.byref(h), C.byref(ox),
+                              C.byref(oy), None, 0) != 0:
+        raise RuntimeError(lib.orc_last_error().decode())
+    im = np.zeros((h.value, w.value), dtype=np.uint8)
+    if lib.orc_occupancy_grid(a, mr, len(arr), float(resolution), float(range_threshold), C.byref(w), C.byref(h), C.byref(ox),
+                              C.byref(oy), im.ctypes.data_as(C.POINTER(C.c_uint8)), im.size) != 0:
+        raise RuntimeError(lib.orc_last_error().decode())
+    return im, (ox.value, oy.value)

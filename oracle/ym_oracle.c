@@ -910,6 +910,92 @@ static int u_match(orc_ctx *c, const orc_scan *query, const orc_scan *base, int 
     return err ? -1 : 0;
 }
 
+/* ================================================================== occupancy-grid rendering
+ * karto_scanmatcher.create_occupancy_grid(scans, resolution, range_threshold) -- /root/reference/yag_slam/graph_slam.py:341-342,
+ * image codes as /root/reference/ros1/slam_node_ros1:199-202 reads them.  Restates open_karto OccupancyGrid::
+ * {CreateFromScans, ComputeDimensions, AddScan, RayTrace, Update, UpdateCell}, Grid<T>::TraceLine and the bounding box of
+ * LocalizedRangeScan::Update, sequentially, scan by scan and beam by beam as Karto does.  PARITY UNPINNED. */
+static int occ_valid(int x, int y, int w, int h) { return x >= 0 && x < w && y >= 0 && y < h; }
+
+int orc_occupancy_grid(const orc_scan *scans, const double *max_ranges, int n_scans, double resolution, double range_threshold,
+                       int *width, int *height, double *off_x, double *off_y, uint8_t *image, long long image_bytes) {
+    if (!scans || n_scans <= 0 || !width || !height) return fail("bad arguments");
+    /* LocalizedRangeScan::Update: bounding box = sensor position + readings within [min_range, range_threshold] */
+    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+    for (int s = 0; s < n_scans; s++) {
+        const orc_scan *sc = &scans[s];
+        double bx0 = sc->pose[0], by0 = sc->pose[1], bx1 = sc->pose[0], by1 = sc->pose[1];
+        for (int i = 0; i < sc->n; i++) {
+            double r = sc->ranges[i];
+            if (!(r >= sc->min_range && r <= range_threshold)) continue;
+            double angle = sc->pose[2] + sc->min_angle + i * sc->angle_increment;
+            double px = sc->pose[0] + r * cos(angle), py = sc->pose[1] + r * sin(angle);
+            if (px < bx0) bx0 = px;
+            if (px > bx1) bx1 = px;
+            if (py < by0) by0 = py;
+            if (py > by1) by1 = py;
+        }
+        if (bx0 < x0) x0 = bx0;
+        if (by0 < y0) y0 = by0;
+        if (bx1 > x1) x1 = bx1;
+        if (by1 > y1) y1 = by1;
+    }
+    /* OccupancyGrid::ComputeDimensions */
+    double scale = 1.0 / resolution;
+    int w = (int)kt_round((x1 - x0) * scale), h = (int)kt_round((y1 - y0) * scale);
+    *width = w; *height = h;
+    if (off_x) *off_x = x0;
+    if (off_y) *off_y = y0;
+    if (!image) return 0;
+    if (w <= 0 || h <= 0 || image_bytes < (long long)w * h) return fail("image buffer too small");
+    uint32_t *pass = (uint32_t *)calloc((size_t)w * h, sizeof(uint32_t));
+    uint32_t *hits = (uint32_t *)calloc((size_t)w * h, sizeof(uint32_t));
+    for (int s = 0; s < n_scans; s++) {
+        const orc_scan *sc = &scans[s];
+        for (int i = 0; i < sc->n; i++) {
+            /* OccupancyGrid::AddScan */
+            double r = sc->ranges[i];
+            int end_valid = r < (range_threshold - KT_TOLERANCE);
+            if (r <= sc->min_range || r >= max_ranges[s] || isnan(r)) continue;
+            double angle = sc->pose[2] + sc->min_angle + i * sc->angle_increment;
+            double px = sc->pose[0] + r * cos(angle), py = sc->pose[1] + r * sin(angle);
+            if (r >= range_threshold) {
+                double ratio = range_threshold / r;
+                double dx = px - sc->pose[0], dy = py - sc->pose[1];
+                px = sc->pose[0] + ratio * dx;
+                py = sc->pose[1] + ratio * dy;
+            }
+            /* RayTrace + Grid<T>::TraceLine */
+            int gx0 = (int)kt_round((sc->pose[0] - x0) * scale), gy0 = (int)kt_round((sc->pose[1] - y0) * scale);
+            int gx1 = (int)kt_round((px - x0) * scale), gy1 = (int)kt_round((py - y0) * scale);
+            int tx = gx1, ty = gy1;
+            int steep = abs(gy1 - gy0) > abs(gx1 - gx0);
+            if (steep) { int t = gx0; gx0 = gy0; gy0 = t; t = gx1; gx1 = gy1; gy1 = t; }
+            if (gx0 > gx1) { int t = gx0; gx0 = gx1; gx1 = t; t = gy0; gy0 = gy1; gy1 = t; }
+            int delta_x = gx1 - gx0, delta_y = abs(gy1 - gy0), error = 0, y = gy0;
+            int ystep = gy0 < gy1 ? 1 : -1;
+            for (int x = gx0; x <= gx1; x++) {
+                int cx = steep ? y : x, cy = steep ? x : y;
+                error += delta_y;
+                if (2 * error >= delta_x) { y += ystep; error -= delta_x; }
+                if (occ_valid(cx, cy, w, h)) pass[(size_t)cy * w + cx]++;
+            }
+            if (end_valid && occ_valid(tx, ty, w, h)) { pass[(size_t)ty * w + tx]++; hits[(size_t)ty * w + tx]++; }
+        }
+    }
+    /* OccupancyGrid::Update / UpdateCell: MinPassThrough 2, OccupancyThreshold 0.1; codes 0 occupied, 200 unknown, 255 free */
+    for (size_t c = 0; c < (size_t)w * h; c++) {
+        uint8_t v = 200;
+        if (pass[c] > 2u) {
+            double ratio = (double)hits[c] / (double)pass[c];
+            v = ratio > 0.1 ? 0 : 255;
+        }
+        image[c] = v;
+    }
+    free(pass); free(hits);
+    return 0;
+}
+
 /* ================================================================== public entry + accessors */
 int orc_match(orc_ctx *c, const orc_scan *query, const orc_scan *base, int n_base, int penalize,
               int refine, orc_result *out) {

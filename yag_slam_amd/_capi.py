@@ -23,6 +23,7 @@ EXPORTS = (
     "ym_profile_enable",
     "ym_profile_read",
     "ym_coarse_dims", "ym_match_slice_begin", "ym_match_slice_finish",
+    "ym_occupancy_create", "ym_occupancy_get_info", "ym_occupancy_read", "ym_occupancy_destroy",
     "ym_map_from_occupancy", "ym_map_from_grid", "ym_map_size", "ym_map_read", "ym_map_destroy", "ym_match_map",
 )
 
@@ -80,6 +81,11 @@ class YmResult(C.Structure):
         ("status", C.c_int32),
         ("reserved", C.c_int32),
     ]
+
+
+class YmOccupancyInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("offset_x", C.c_double), ("offset_y", C.c_double),
+                ("resolution", C.c_double)]
 
 
 class YmMapSearch(C.Structure):
@@ -173,6 +179,12 @@ def lib():
     L.ym_coarse_dims.argtypes = [vp, ip]
     L.ym_match_slice_begin.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.ym_match_slice_finish.argtypes = [vp, C.POINTER(YmResult)]
+    L.ym_occupancy_create.restype = vp
+    L.ym_occupancy_create.argtypes = [C.POINTER(vp), C.c_int, C.c_double, C.c_double]
+    L.ym_occupancy_get_info.argtypes = [vp, C.POINTER(YmOccupancyInfo)]
+    L.ym_occupancy_read.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64]
+    L.ym_occupancy_destroy.argtypes = [vp]
+    L.ym_occupancy_destroy.restype = None
     L.ym_map_from_occupancy.restype = vp
     L.ym_map_from_occupancy.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int]
     L.ym_map_from_grid.restype = vp

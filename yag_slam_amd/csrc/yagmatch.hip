@@ -228,6 +228,12 @@ struct ym_map {
     uint8_t *d_g8;    // int(100 * cell): what scoring reads
 };
 
+struct ym_occupancy {
+    int device;
+    ym_occupancy_info info;
+    std::vector<uint8_t> image; // [height][width], row 0 = lowest y
+};
+
 struct ym_batch {
     const ym_scan *query;
     std::vector<const ym_scan *> scans;
@@ -1827,6 +1833,101 @@ int ym_match_map(ym_matcher *m, const ym_map *mp, double ox, double oy, const ym
     m->last_valid = false; // the debug getters describe match_scan calls
     return YM_OK;
 }
+
+// ---- occupancy-grid rendering (karto_scanmatcher.create_occupancy_grid)
+ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, double resolution, double range_threshold) {
+    if (!scans || n_scans <= 0) { set_err(YM_ERR_INVALID, "no scans"); return nullptr; }
+    if (!(resolution > 0) || !(range_threshold > 0)) { set_err(YM_ERR_INVALID, "resolution and range_threshold must be > 0"); return nullptr; }
+    const int device = scans[0] ? scans[0]->device : -1;
+    int max_n = 1;
+    for (int i = 0; i < n_scans; i++) {
+        if (!scans[i] || scans[i]->device != device) { set_err(YM_ERR_INVALID, "scan %d is null or lives on another device", i); return nullptr; }
+        max_n = std::max(max_n, scans[i]->n);
+    }
+    DevGuard guard(device);
+    if (!guard.ok) { set_err(YM_ERR_HIP, "cannot make device %d current", device); return nullptr; }
+    std::vector<YmScanRef> hs(n_scans);
+    std::memset(hs.data(), 0, sizeof(YmScanRef) * n_scans);
+    for (int i = 0; i < n_scans; i++) {
+        const ym_scan *q = scans[i];
+        hs[i].ranges = q->d_ranges; hs[i].n = q->n;
+        hs[i].min_angle = q->min_angle; hs[i].angle_inc = q->angle_inc; hs[i].min_range = q->min_range;
+        hs[i].range_threshold = q->max_range; // the laser's MAXIMUM range travels in this field (see occ_trace_kernel)
+        hs[i].pose[0] = q->pose[0]; hs[i].pose[1] = q->pose[1]; hs[i].pose[2] = q->pose[2];
+    }
+    YmScanRef *d_scans = nullptr;
+    double *d_boxes = nullptr;
+    unsigned *d_cnt = nullptr;
+    uint8_t *d_img = nullptr;
+    ym_occupancy *og = nullptr;
+    bool ok = hipMalloc(reinterpret_cast<void **>(&d_scans), sizeof(YmScanRef) * n_scans) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&d_boxes), sizeof(double) * 4 * n_scans) == hipSuccess &&
+              hipMemcpy(d_scans, hs.data(), sizeof(YmScanRef) * n_scans, hipMemcpyHostToDevice) == hipSuccess;
+    ym::OccArgs a;
+    std::memset(&a, 0, sizeof a);
+    if (ok) {
+        a.scans = d_scans; a.n_scans = n_scans; a.max_n = max_n; a.range_threshold = range_threshold; a.boxes = d_boxes;
+        hipLaunchKernelGGL(ym::occ_bbox_kernel, dim3(n_scans), dim3(256), 0, nullptr, a);
+        std::vector<double> boxes((size_t)4 * n_scans);
+        ok = hipMemcpy(boxes.data(), d_boxes, sizeof(double) * boxes.size(), hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) {
+            // OccupancyGrid::ComputeDimensions: the scans' bounding boxes joined, width = Round(size * scale)
+            double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+            for (int i = 0; i < n_scans; i++) {
+                x0 = std::min(x0, boxes[4 * i]); y0 = std::min(y0, boxes[4 * i + 1]);
+                x1 = std::max(x1, boxes[4 * i + 2]); y1 = std::max(y1, boxes[4 * i + 3]);
+            }
+            const double scale = 1.0 / resolution;
+            const int width = (int)kt_round_h((x1 - x0) * scale), height = (int)kt_round_h((y1 - y0) * scale);
+            if (width <= 0 || height <= 0 || (double)width * height > 2.0e9) {
+                set_err(YM_ERR_UNSUPPORTED, "occupancy grid of %d x %d cells", width, height);
+                ok = false;
+            } else {
+                const size_t n = (size_t)width * height;
+                ok = hipMalloc(reinterpret_cast<void **>(&d_cnt), 2 * n * sizeof(unsigned)) == hipSuccess &&
+                     hipMalloc(reinterpret_cast<void **>(&d_img), n) == hipSuccess &&
+                     hipMemset(d_cnt, 0, 2 * n * sizeof(unsigned)) == hipSuccess;
+                if (ok) {
+                    a.scale = scale; a.off_x = x0; a.off_y = y0; a.width = width; a.height = height;
+                    a.pass = d_cnt; a.hits = d_cnt + n; a.image = d_img;
+                    hipLaunchKernelGGL(ym::occ_trace_kernel, dim3((max_n + 255) / 256, n_scans), dim3(256), 0, nullptr, a);
+                    hipLaunchKernelGGL(ym::occ_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, a);
+                    og = new ym_occupancy();
+                    og->device = device;
+                    og->info.width = width; og->info.height = height;
+                    og->info.offset_x = x0; og->info.offset_y = y0; og->info.resolution = resolution;
+                    og->image.resize(n);
+                    ok = hipGetLastError() == hipSuccess && hipMemcpy(og->image.data(), d_img, n, hipMemcpyDeviceToHost) == hipSuccess;
+                }
+            }
+        }
+    }
+    if (d_scans) (void)hipFree(d_scans);
+    if (d_boxes) (void)hipFree(d_boxes);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (d_img) (void)hipFree(d_img);
+    if (!ok) {
+        if (g_err.empty() || og) set_err(YM_ERR_HIP, "rendering the occupancy grid failed");
+        delete og;
+        return nullptr;
+    }
+    return og;
+}
+
+int ym_occupancy_get_info(const ym_occupancy *og, ym_occupancy_info *info) {
+    if (!og || !info) return set_err(YM_ERR_INVALID, "null argument");
+    *info = og->info;
+    return YM_OK;
+}
+
+int ym_occupancy_read(const ym_occupancy *og, uint8_t *image, int64_t image_bytes) {
+    if (!og || !image) return set_err(YM_ERR_INVALID, "null argument");
+    if ((size_t)image_bytes < og->image.size()) return set_err(YM_ERR_INVALID, "buffer too small: need %zu bytes", og->image.size());
+    std::memcpy(image, og->image.data(), og->image.size());
+    return YM_OK;
+}
+
+void ym_occupancy_destroy(ym_occupancy *og) { delete og; }
 
 // ---- debug getters
 int ym_debug_grid_info(ym_matcher *m, int item, ym_grid_info *info) {

@@ -26,3 +26,4 @@
 #include "ym_k_correlate.hpp"
 #include "ym_k_finish.hpp"
 #include "ym_k_yagpy.hpp"
+#include "ym_k_occupancy.hpp"

@@ -205,6 +205,11 @@ class LoopClosingMapper(SequentialMapper):
             return True
         return False
 
+    def make_occupancy_grid(self, resolution=0.05, range_threshold=12):
+        """graph_slam.py:341-342: every vertex scan ray-traced into one grid (on the device)"""
+        from .occupancy import create_occupancy_grid
+        return create_occupancy_grid(self.scans, resolution, range_threshold, device=getattr(self.seq_matcher, "device", 0))
+
     def run_opt(self):
         """graph_slam.py:262-272; a no-op without an optimizer except for the spatial index refresh"""
         if self.opt is not None:
