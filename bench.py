@@ -77,7 +77,9 @@ def self_launch(args):
             print(ln, file=sys.stderr)
     if line is not None:
         print(line)
-    return p.returncode if line is not None or p.returncode != 0 else 1
+    if line is not None:
+        return 0  # the metric line exists; a by_config leg that failed says so in its own entry (and on stderr)
+    return p.returncode if p.returncode != 0 else 1
 
 
 def profile_json(name):
@@ -337,6 +339,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # stdout carries exactly ONE line, the JSON; libraries that print there (RCCL's version banner) go to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -512,7 +517,7 @@ def main():
         l1 = profile_json("l1_correlate.json")
         step_alg = hyp_step * nq  # coarse + fine lattice points x one byte per valid beam
         line["roofline"] = {
-            "bound": "hbm", "kernel": "ym::correlate_kernel<2, 16>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "ym::correlate_kernel<2, 16, 4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic["hbm_bytes_per_launch"] if traffic and int(traffic.get("batch", 0)) == LB else None,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": corr_s * 1e6,
@@ -529,23 +534,49 @@ def main():
     if dist is not None:
         dist.barrier()
 
+    emitted = [False]
+
+    def emit():
+        if rank == 0 and not emitted[0]:
+            emitted[0] = True
+            line["config"]["by_config"] = by_config
+            if line["value"] is None:  # a development run of single legs: not a metric line
+                line["metric"] = "partial run (--only %s)" % args.only
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+
     # ---------------------------------------------------------------- the other BASELINE configs, same run
+    # (a leg that fails must not take the metric line with it: its entry then carries the error)
+    def guarded(name, fn, collective=False):
+        try:
+            out = fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            out = {"error": "%s: %s" % (type(e).__name__, e)}
+            if collective and dist is not None:
+                # the other ranks are inside the same collective leg: print what there is, then let the launcher end the job
+                if rank == 0:
+                    by_config[name] = out
+                    emit()
+                raise
+        if rank == 0 and out is not None:
+            by_config[name] = out
+
     if "single" in legs and rank == 0:
-        r1 = m.match_scan(query, chains[0], True, True)
-        by_config["cfg2_single_match"] = leg_single(m, query, chains[0], r1.meta["hypotheses"])
+        guarded("cfg2_single_match", lambda: leg_single(m, query, chains[0], m.match_scan(query, chains[0], True, True).meta["hypotheses"]))
     if "cfg3" in legs and rank == 0:
-        by_config["cfg3_sequential_mapping"] = leg_cfg3(m, gen["cfg3"], args.cfg3_scans)
+        guarded("cfg3_sequential_mapping", lambda: leg_cfg3(m, gen["cfg3"], args.cfg3_scans))
     if "cfg5" in legs and (rank == 0 or world > 1):
         q5, b5 = synth.single_match_scans(gen["scene"])
-        c5 = leg_cfg5(local_rank, q5, b5, rank, world, torch, dist)
-        if rank == 0:
-            by_config["cfg5_stress"] = c5
+        guarded("cfg5_stress", lambda: leg_cfg5(local_rank, q5, b5, rank, world, torch, dist), collective=world > 1)
     if "cfg4" in legs:
-        loop_m = ScanMatcher(None, loop=True, device=local_rank)
-        c4 = leg_cfg4(loop_m, gen, args, rank, world, torch, dist)
-        if rank == 0:
-            by_config["cfg4_loop_closure_batch"] = c4
-        loop_m.close()
+        def run_cfg4():
+            loop_m = ScanMatcher(None, loop=True, device=local_rank)
+            try:
+                return leg_cfg4(loop_m, gen, args, rank, world, torch, dist)
+            finally:
+                loop_m.close()
+        guarded("cfg4_loop_closure_batch", run_cfg4, collective=world > 1)
     if "cpu" in legs and rank == 0 and world == 1:  # the CPU baseline is a single-GPU-run item
         cb = cpu_baseline()
         line["cpu_baseline"] = {
@@ -562,11 +593,7 @@ def main():
         by_config["cfg1_cpu_single_match"] = {
             "ms_per_match": cb["single"]["ms_per_match"], "scan_matches_per_s": 1e3 / cb["single"]["ms_per_match"],
             "hypotheses_per_s": cb["single"]["hyp_per_s"], "what": "oracle/ym_oracle.c, karto semantics, 1 thread"}
-    if rank == 0:
-        line["config"]["by_config"] = by_config
-        if line["value"] is None:  # a development run of single legs: not a metric line
-            line["metric"] = "partial run (--only %s)" % args.only
-        print(json.dumps(line))
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 

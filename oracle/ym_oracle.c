@@ -381,6 +381,16 @@ static int u_add_scans(orc_ctx *c, const orc_scan *base, int n_base, double vpx,
             if (!PY(c, ORC_D8_RESTAMP) && *cell == GRID_OCCUPIED) continue;
             *cell = GRID_OCCUPIED;
             if (c->gridf) c->gridf[(size_t)(gy + c->roi_y) * c->gw + (gx + c->roi_x)] = 1.0;
+            if (!PY(c, ORC_D3_GRID_SIZE) && !c->gridf) {
+                /* CorrelationGrid::SmearPoint as Karto runs it: the border makes every tap land in storage */
+                for (int j = -half; j <= half; j++) {
+                    uint8_t *row = c->grid + (size_t)(gy + j + c->roi_y) * c->pitch + (gx + c->roi_x);
+                    const uint8_t *krow = c->kernel + ksz * (j + half) + half;
+                    for (int t = -half; t <= half; t++)
+                        if (krow[t] > row[t]) row[t] = krow[t];
+                }
+                continue;
+            }
             for (int j = -half; j <= half; j++) {
                 for (int t = -half; t <= half; t++) {
                     int x = gx + t, y = gy + j;

@@ -592,6 +592,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.corr_u = m->corr_u > 0 ? m->corr_u : (chunk <= 32 && njobs <= 128 ? 32 : 16);
     chunk = (chunk + P.corr_u - 1) / P.corr_u * P.corr_u;
     while (P.cw > 1 && P.cw * chunk > 640) P.cw /= 2; // a group's 16-bit sums must hold cw * chunk beams of 100
+    if (P.corr_u == 48) P.cw = 1;                     // (development variant: one instantiation only)
     P.job_blocks = (njobs + (4 / P.cw) * 64 - 1) / ((4 / P.cw) * 64);
     P.chunk = chunk;
     P.n_chunks = (max_n + chunk - 1) / chunk;
@@ -1016,10 +1017,21 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
         hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((P.njobs + 63) / 64, a.nk * P.n_chunks, P.B), dim3(256), 0, st, a);
     }
-    else if (P.sx == 2 && P.corr_u == 16) hipLaunchKernelGGL((ym::correlate_kernel<2, 16>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
-    else if (P.sx == 2 && P.corr_u == 32) hipLaunchKernelGGL((ym::correlate_kernel<2, 32>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
-    else if (P.sx == 2) hipLaunchKernelGGL((ym::correlate_kernel<2, 48>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
-    else hipLaunchKernelGGL((ym::correlate_kernel<1, 16>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a);
+    else {
+#define YM_CORR_LAUNCH(SX, U, CW) hipLaunchKernelGGL((ym::correlate_kernel<SX, U, CW>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a)
+#define YM_CORR_BY_CW(SX, U)                                  \
+    do {                                                      \
+        if (P.cw == 4) YM_CORR_LAUNCH(SX, U, 4);              \
+        else if (P.cw == 2) YM_CORR_LAUNCH(SX, U, 2);         \
+        else YM_CORR_LAUNCH(SX, U, 1);                        \
+    } while (0)
+        if (P.sx == 2 && P.corr_u == 16) YM_CORR_BY_CW(2, 16);
+        else if (P.sx == 2 && P.corr_u == 32) YM_CORR_BY_CW(2, 32);
+        else if (P.sx == 2) YM_CORR_LAUNCH(2, 48, 1);
+        else YM_CORR_BY_CW(1, 16);
+#undef YM_CORR_BY_CW
+#undef YM_CORR_LAUNCH
+    }
     return prof_end(m, ev_k);
 }
 

@@ -90,19 +90,19 @@ __device__ __forceinline__ void store_partial16(uint16_t *out, const uint32_t (&
 // one angle: rotate the sensor-frame point, WorldToGrid), so no lookup table ever round-trips through HBM.  Loads are
 // issued U beams at a time; entries past the last beam are 0 and are masked by a scalar.
 // grid (ceil(ny*ngx / (64 jw)), nt * n_groups, B).
-template <int SX, int U /* beams in flight per lane */>
+template <int SX, int U /* beams in flight per lane */, int CW /* chunk-waves per block */>
 __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) {
     constexpr int G = 16;           // hypotheses per lane
     int bx, by;
     const int b = xcd_item_of_block(bx, by);
-    const int cw = a.cw, jw = 4 / cw;
+    constexpr int cw = CW, jw = 4 / cw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jw_idx = wave % jw, cw_idx = wave / jw;
     const int k = a.k_begin + by % a.nk, group = by / a.nk;
     const int chunk = group * cw + cw_idx;
     const int job = (bx * jw + jw_idx) * 64 + lane;
-    __shared__ int offs_all[4][512];
-    __shared__ uint32_t red[4 * 8 * 64];
+    __shared__ int offs_all[CW][512];
+    __shared__ uint32_t red[CW > 1 ? 4 * 8 * 64 : 1];
     const int *offs = offs_all[cw_idx];
     YM_STAMP(a, 8);
     const int njobs = a.lat.ny * a.ngx;
@@ -158,7 +158,13 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
                     const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u);
                     w[u] = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(src + ad, 4));
                     e[u] = 0u;
-                    if (extra) e[u] = *reinterpret_cast<const uint32_t *>(src + ad + 16);
+                }
+                if (extra) { // one divergent region for all U loads (not U of them)
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u); // 32-bit wrap: offsets may be negative
+                        e[u] = *reinterpret_cast<const uint32_t *>(src + ad + 16);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
