@@ -1,6 +1,7 @@
 // ym_k_correlate.hpp -- K4 correlate_kernel and the experimental LDS-staged correlate_staged_kernel.
 // Part of ym_kernels.hpp (include that, not this file).
 #pragma once
+#include <type_traits>
 
 namespace ym {
 
@@ -150,36 +151,56 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
             // funnels by the beam's byte misalignment, which is wave-uniform (v_alignbyte_b32).
             // lanes whose neighbour is not the next group of the same row load the extra dword themselves
             const bool extra = (lane == 63 && xg != a.ngx - 1) || (a.nx_pad - a.lat.nx < 3 && xg == a.ngx - 1);
-            for (int c = 0; c < a.chunk; c += U) {
-                uint4 w[U];
-                uint32_t e[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u);
-                    w[u] = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(src + ad, 4));
-                    e[u] = 0u;
-                }
-                if (extra) { // one divergent region for all U loads (not U of them)
+            // Grid bytes are at most 100, so the bytes of TWO beams add without carries as packed u8: beams are added in
+            // pairs first and the pair sum is split into the 16-bit lanes (a third fewer VALU per beam).  Only the last
+            // chunk of a scan holds beams past the last reading; they are masked there (MASKED), nowhere else.
+            auto run = [&](auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                for (int c = 0; c < a.chunk; c += U) {
+                    uint4 w[U];
+                    uint32_t e[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u); // 32-bit wrap: offsets may be negative
-                        e[u] = *reinterpret_cast<const uint32_t *>(src + ad + 16);
+                        const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u);
+                        w[u] = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(src + ad, 4));
+                        e[u] = 0u;
+                    }
+                    if (extra) { // one divergent region for all U loads (not U of them)
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u); // 32-bit wrap: offsets may be negative
+                            e[u] = *reinterpret_cast<const uint32_t *>(src + ad + 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u += 2) {
+                        uint32_t x[2][4];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const uint32_t rr = (uint32_t)offs[c + u + h] & 3u;
+                            const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[u + h].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+                            const uint32_t w4 = extra ? e[u + h] : nb;
+                            x[h][0] = __builtin_amdgcn_alignbyte(w[u + h].y, w[u + h].x, rr);
+                            x[h][1] = __builtin_amdgcn_alignbyte(w[u + h].z, w[u + h].y, rr);
+                            x[h][2] = __builtin_amdgcn_alignbyte(w[u + h].w, w[u + h].z, rr);
+                            x[h][3] = __builtin_amdgcn_alignbyte(w4, w[u + h].w, rr);
+                            if (MASKED) {
+                                const uint32_t m = (i0 + c + u + h) < nq ? 0xFFFFFFFFu : 0u; // wave-uniform
+#pragma unroll
+                                for (int j = 0; j < 4; j++) x[h][j] &= m;
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t s2 = x[0][j] + x[1][j]; // packed bytes, each <= 200
+                            acc[2 * j] += s2 & 0x00FF00FFu;
+                            acc[2 * j + 1] += __builtin_amdgcn_perm(0u, s2, 0x0c030c01u); // bytes 1 and 3 -> 16-bit lanes
+                        }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint32_t m = (i0 + c + u) < nq ? 0x00FF00FFu : 0u; // wave-uniform
-                    const uint32_t rr = (uint32_t)offs[c + u] & 3u;
-                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[u].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
-                    const uint32_t w4 = extra ? e[u] : nb;
-                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w[u].y, w[u].x, rr), x1 = __builtin_amdgcn_alignbyte(w[u].z, w[u].y, rr);
-                    const uint32_t x2 = __builtin_amdgcn_alignbyte(w[u].w, w[u].z, rr), x3 = __builtin_amdgcn_alignbyte(w4, w[u].w, rr);
-                    acc[0] += x0 & m; acc[1] += (x0 >> 8) & m;
-                    acc[2] += x1 & m; acc[3] += (x1 >> 8) & m;
-                    acc[4] += x2 & m; acc[5] += (x2 >> 8) & m;
-                    acc[6] += x3 & m; acc[7] += (x3 >> 8) & m;
-                }
-            }
+            };
+            if (i0 + a.chunk <= nq) run(std::false_type());
+            else run(std::true_type());
         } else {
             for (int c = 0; c < a.chunk; c += U) {
                 uint4 w[U];
