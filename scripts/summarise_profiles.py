@@ -1,0 +1,89 @@
+"""Turn the rocprofv3 outputs of scripts/profile_round.sh / profile_pmc.sh (merged under gpurun_out/) into the small
+summaries kept under profiles/.    python scripts/summarise_profiles.py r02p 1024"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CU, CLOCK_HZ = 256, 2.4e9
+
+
+def kernel_means(tag, name):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if "ym::" in k:
+                out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, d in out.items():
+        res[k] = {}
+        for c, v in d.items():
+            v = sorted(v)
+            v = v[len(v) // 4:] if len(v) > 3 else v  # drop the small single-match launches of bench.py's self-check
+            res[k][c] = sum(v) / len(v)
+    return res
+
+
+def main():
+    tag, batch = sys.argv[1], int(sys.argv[2])
+    short = tag.replace("r02p", "r02_p")
+    prof = os.path.join(REPO, "profiles")
+    for src, dst in (("stats", "bench_kernel_stats"), ("single", "single_match_kernel_stats"), ("stress", "stress_kernel_stats")):
+        f = os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, src), "%s_kernel_stats.csv" % tag)
+        if os.path.exists(f):
+            rows = [r for r in csv.reader(open(f))]
+            with open(os.path.join(prof, "%s_%s.csv" % (short, dst)), "w") as o:
+                w = csv.writer(o)
+                for r in rows:
+                    if r and ("ym::" in r[0] or r[0] == "Name"):
+                        w.writerow(r)
+    for src in ("bench.json", "bench_under_rocprof.json"):
+        f = os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, src))
+        if os.path.exists(f) and os.path.getsize(f) > 0:
+            shutil.copy(f, os.path.join(prof, "%s_%s" % (short, src.replace("bench.json", "bench_line.json"))))
+    fetch, l2, tcp = kernel_means(tag, "fetch"), kernel_means(tag, "l2"), kernel_means(tag, "tcp")
+    stats = {}
+    f = os.path.join(REPO, "gpurun_out", "%s_stats" % tag, "%s_kernel_stats.csv" % tag)
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            stats[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
+    rows = []
+    for k in sorted(set(fetch) | set(l2) | set(tcp)):
+        rows.append((k, fetch.get(k, {}).get("FETCH_SIZE", 0.0), l2.get(k, {}).get("TCC_HIT_sum", 0.0), l2.get(k, {}).get("TCC_MISS_sum", 0.0),
+                     tcp.get(k, {}).get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0), tcp.get(k, {}).get("TCP_TOTAL_ACCESSES_sum", 0.0)))
+    pmc_csv = os.path.join(prof, "%s_pmc_batch%d.csv" % (short, batch))
+    with open(pmc_csv, "w") as o:
+        o.write("# rocprofv3 --pmc FETCH_SIZE | --pmc TCC_HIT_sum TCC_MISS_sum | --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum "
+                "(three separate passes, nothing else traced): python3 bench.py --only cfg2x --steps 2 --warmup 1  (launch batch %d)\n" % batch)
+        o.write("# means per launch.  FETCH_SIZE in KiB as reported; gfx950 counts half of a 16-B/lane stream (MI355X_MICROARCH.md): bytes ~= 2*1024*FETCH_SIZE\n")
+        o.write("kernel,FETCH_SIZE_KiB,TCC_HIT_sum,TCC_MISS_sum,l2_hit_rate,TCP_TOTAL_CACHE_ACCESSES_sum,TCP_TOTAL_ACCESSES_sum\n")
+        for k, fz, h, m, ca, ta in rows:
+            o.write("%s,%.1f,%.0f,%.0f,%.3f,%.0f,%.0f\n" % (k, fz, h, m, h / max(h + m, 1.0), ca, ta))
+    corr = [r for r in rows if "correlate_kernel<2, 16, 4>" in r[0]]
+    if corr:
+        k, fz, h, m, ca, ta = corr[0]
+        json.dump({"kernel": k, "batch": batch, "fetch_size_kib_per_launch": fz, "gfx950_wide_read_correction": 2.0,
+                   "hbm_bytes_per_launch": fz * 1024 * 2.0, "l2_hit_rate": h / max(h + m, 1.0), "source": os.path.relpath(pmc_csv, REPO)},
+                  open(os.path.join(prof, "traffic_correlate.json"), "w"), indent=1)
+        dur = stats.get(k)
+        if dur and ca:
+            per_cu_clk = ca / (CU * dur * 1e-9 * CLOCK_HZ)
+            json.dump({"kernel": k, "batch": batch, "counter": "TCP_TOTAL_CACHE_ACCESSES_sum", "per_launch": ca,
+                       "kernel_us_under_rocprof": dur * 1e-3, "per_cu_clk": per_cu_clk,
+                       "peak_per_cu_clk": 1.0, "frac": per_cu_clk / 1.0,
+                       "peak_source": "profiles/r02_ta_coalescing_experiment.md: one cache-line visit per clock per CU "
+                                      "(64 lanes in 64 lines = 65 clk per wave load)",
+                       "source": os.path.relpath(pmc_csv, REPO)},
+                      open(os.path.join(prof, "l1_correlate.json"), "w"), indent=1)
+    print(open(pmc_csv).read())
+    for n in ("traffic_correlate.json", "l1_correlate.json"):
+        print(n, open(os.path.join(prof, n)).read())
+
+
+if __name__ == "__main__":
+    main()

@@ -282,16 +282,68 @@ __device__ __forceinline__ void clear_slot(const PrepareArgs &a, int b, int slot
     for (int i = threadIdx.x; i < n_cchunks; i += NT) bbox[i] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
 }
 
-// one base scan of one item from the point cache: no LDS, no barrier
+// one base scan of one item from the point cache: no LDS, no barrier.  The three dependent rounds of loads (who decides
+// point i -> the two deciding points -> the point itself) are issued for Q chunks of the scan at a time, so a block
+// waits three round trips per Q * NT points instead of three per NT.
 template <int NT>
 __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, int slot, const YmScanRef &sr, const YmScanRef &qr, bool yag) {
-    const double2 *cpts = reinterpret_cast<const double2 *>(sr.cache + YM_CACHE_HEADER);
-    const int2 *cgov = reinterpret_cast<const int2 *>(sr.cache + YM_CACHE_HEADER + (size_t)sr.n * 16);
+    constexpr int Q = 4;
+    const double2 *__restrict__ cpts = reinterpret_cast<const double2 *>(sr.cache + YM_CACHE_HEADER);
+    const int2 *__restrict__ cgov = reinterpret_cast<const int2 *>(sr.cache + YM_CACHE_HEADER + (size_t)sr.n * 16);
     const int np = *reinterpret_cast<const int *>(sr.cache);
     const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
     const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
-    prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y, [&](int i) { return cpts[i]; },
-                      [&](int i) { return cgov[i]; });
+    const double vpx = qr.pose[0], vpy = qr.pose[1];
+    const int tid = threadIdx.x;
+    const int n_cchunks = (a.max_n + 63) / 64;
+    int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
+    int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
+    for (int i0 = 0; i0 < n_cchunks * 64; i0 += Q * NT) {
+        int2 g[Q];
+        double2 f[Q], t[Q], p[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = i0 + q * NT + tid;
+            g[q] = i < np ? cgov[i] : make_int2(-1, np);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = i0 + q * NT + tid;
+            const bool decided = g[q].x >= 0 && g[q].y < np;
+            f[q] = cpts[decided ? g[q].x : 0];
+            t[q] = cpts[decided ? g[q].y : 0];
+            p[q] = cpts[i < np ? i : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = i0 + q * NT + tid; // a wave covers one 64-cell chunk
+            if (i0 + q * NT >= n_cchunks * 64) break; // block-uniform
+            int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+            if (i < np && g[q].x >= 0 && g[q].y < np) {
+                const double fx = f[q].x, fy = f[q].y, cx = t[q].x, cy = t[q].y;
+                const double aa = vpy - fy;
+                const double bb = fx - vpx;
+                const double cc = fy * vpx - fx * vpy;
+                const double ss = cx * aa + cy * bb + cc;
+                const bool keep = yag ? (ss > 0.0) : !(ss < 0.0);
+                int gx, gy;
+                if (yag) {
+                    gx = (int)rint((p[q].x - off_x) / a.g.res);
+                    gy = (int)rint((p[q].y - off_y) / a.g.res);
+                } else {
+                    gx = world_to_grid(p[q].x, off_x, a.g.scale);
+                    gy = world_to_grid(p[q].y, off_y, a.g.scale);
+                }
+                if (keep && gx >= 0 && gx < a.g.roi_w && gy >= 0 && gy < a.g.roi_w)
+                    c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
+            }
+            if (i < a.max_n) cells[i] = c;
+            const bool has = c.x != YM_CELL_NONE;
+            const int x0 = wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = wave_reduce(has ? c.y : INT32_MAX, OpMinI());
+            const int x1 = wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+            if ((tid & 63) == 0 && i / 64 < n_cchunks) bbox[i / 64] = make_int4(x0, y0, x1, y1);
+        }
+    }
 }
 
 // ---- K1, fused form (a few items): grid (max_base + 1, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).
