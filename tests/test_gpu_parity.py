@@ -729,3 +729,26 @@ def test_point_cache_is_invisible():
         a, b = m.match_scan(gq, gb, True, True), ref.match_scan(gq, gb, True, True)
         assert a.response == b.response and a.covariance == b.covariance
         assert np.array_equal(m.debug_grid()[0], ref.debug_grid()[0])
+
+
+def test_order_dependent_smear_on_long_chains():
+    """More than 12 288 readings in a chain at smear_deviation = 10 * resolution: Karto's "value already set" rule is
+    evaluated with its tables in global memory instead of one CU's LDS.  Every grid byte must still equal the
+    sequential oracle's; and the same chain through both kernels (option 10 forces the global one) gives the same grid."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd import synth
+    scene = synth.Scene()
+    q, base = cfg2_scans(range_threshold=12.0)
+    mk = lambda r, p: PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 12.0, p)
+    poses = [(2.0 + 0.05 * i, 3.0 + 0.02 * (i % 5), 0.03 * (i % 7)) for i in range(26)]   # 26 x 1081 = 28 106 readings
+    long_chain = [mk(scene.scan_ranges(p, index=400 + i), p) for i, p in enumerate(poses)]
+    cfg = dict(resolution=0.01, smear_deviation=0.1, range_threshold=12.0, search_size=0.3)
+    compare(cfg, q, long_chain, True, True)
+    # both kernels on a chain either can hold
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    a, b = ScanMatcher(cfg), ScanMatcher(cfg)
+    b.debug_option(10, 1)
+    ra, rb = a.match_scan(nq, nb, True, True), b.match_scan(nq, nb, True, True)
+    assert ra.response == rb.response and ra.covariance == rb.covariance
+    assert np.array_equal(a.debug_grid()[0], b.debug_grid()[0])
+    assert np.array_equal(a.debug_cells()[0], b.debug_cells()[0])

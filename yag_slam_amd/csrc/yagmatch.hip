@@ -296,12 +296,14 @@ struct ym_matcher {
     size_t cache_limit = (size_t)16 << 30; // bytes; beyond it the cache starts over
     int cache_off = 0;                     // development: 1 = never cache (every call projects every scan)
     int64_t cache_hits = 0, cache_misses = 0;
+    DevBuf<unsigned> sel_scratch; // select on long chains: hash, states and neighbour lists in global memory
     DevBuf<uint16_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
     int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
+    int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
@@ -930,9 +932,24 @@ int enqueue_select(ym_matcher *m, const CallPlan &P) {
     const size_t pts = (size_t)P.max_base * P.max_n;
     int log2cap = 10;
     while (((size_t)3 << log2cap) < 4 * pts) log2cap++; // load factor <= 0.75
-    if (log2cap > 14 || P.g.storage_w >= 32768)
-        return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 12288 readings are not supported",
+    if (log2cap > 17 || P.g.storage_w >= 32768)
+        return set_err(YM_ERR_UNSUPPORTED, "order-dependent smear (smear_deviation/resolution = %g): chains of more than 98304 readings are not supported",
                        m->cfg.smear_deviation / m->cfg.resolution);
+    if (log2cap > 14 || m->select_global) { // too long for one CU's LDS: the same rule with its tables in global memory
+        const size_t cap = (size_t)1 << log2cap;
+        const int nb = m->z2max <= 1 ? 5 : 9;
+        int rc = m->sel_scratch.ensure((size_t)P.B * cap * (3 + (nb - 1)));
+        if (rc) return rc;
+        ym::SelectGlobalArgs g;
+        g.cells = m->cells.p; g.max_n = P.max_n; g.max_base = P.max_base; g.z2max = m->z2max; g.log2cap = log2cap;
+        g.keys = m->sel_scratch.p; g.status = g.keys + (size_t)P.B * cap; g.minidx = g.status + (size_t)P.B * cap; g.nbr = g.minidx + (size_t)P.B * cap;
+        HIP_TRY(hipMemsetAsync(g.keys, 0, (size_t)2 * P.B * cap * sizeof(unsigned), m->stream));
+        HIP_TRY(hipMemsetAsync(g.minidx, 0xff, (size_t)P.B * cap * sizeof(unsigned), m->stream));
+        const size_t lds = cap; // one byte per slot: the threads' lists of undecided slots
+        if (nb == 5) hipLaunchKernelGGL(ym::select_global_kernel<5>, dim3(P.B), dim3(1024), lds, m->stream, g);
+        else hipLaunchKernelGGL(ym::select_global_kernel<9>, dim3(P.B), dim3(1024), lds, m->stream, g);
+        return YM_OK;
+    }
     ym::SelectArgs a;
     a.cells = m->cells.p; a.max_n = P.max_n; a.max_base = P.max_base; a.z2max = m->z2max; a.log2cap = log2cap; a.stamps = P.stamps;
     const size_t lds = (size_t)9 << log2cap;
@@ -1317,6 +1334,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(ym::points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1334,7 +1353,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release();
+    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->sel_scratch.release();
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
     m->tmp_ranges_host.release(); m->kernel_f_dev.release(); m->map_pts.release(); m->cache_arena.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
@@ -2020,6 +2039,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 5) m->corr_chunks = value;
     else if (option == 6) m->finish_form = value;
     else if (option == 9) m->corr_cw = value;
+    else if (option == 10) m->select_global = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

@@ -662,4 +662,96 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     YM_STAMP(a, 29);
 }
 
+// ---- the same rule for chains too long for one CU's LDS (more than 12 288 readings): hash, earliest-point index, neighbour
+// lists and states live in global memory (one 1024-thread block per item again -- the relaxation is a chain of
+// dependent decisions, not a parallel job -- but its reads now cost an L2 round trip instead of an LDS one).  LDS only
+// holds each thread's shrinking list of undecided slots.  Capacity 2^17 slots = 98 304 readings at load factor 0.75.
+struct SelectGlobalArgs {
+    int2 *cells;          // [B][max_base][max_n]
+    int32_t max_n, max_base;
+    int32_t z2max, log2cap;
+    unsigned *keys;       // [B][cap]           zeroed by the host
+    unsigned *status;     // [B][cap]           zeroed by the host: 0 undecided, 1 effective, 2 out
+    unsigned *minidx;     // [B][cap]           set to 0xffffffff by the host
+    unsigned *nbr;        // [B][NB - 1][cap]   slot of the neighbour cell if it holds an earlier point, else 0xffffffff
+};
+
+template <int NB>
+__global__ __launch_bounds__(1024) void select_global_kernel(SelectGlobalArgs a) {
+    constexpr int NT = 1024;
+    constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
+    constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
+    extern __shared__ unsigned char und_list[]; // [cap / NT][NT]: ordinals k of the slots tid + k * NT still undecided
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned cap = 1u << a.log2cap, bmask = (cap >> 2) - 1u;
+    const int shift = 32 - (a.log2cap - 2);
+    unsigned *keys = a.keys + (size_t)b * cap, *minidx = a.minidx + (size_t)b * cap, *status = a.status + (size_t)b * cap;
+    unsigned *nbr = a.nbr + (size_t)b * (NB - 1) * cap;
+    int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
+    const int total = a.max_base * a.max_n;
+    // (1) cell -> earliest point index
+    for (int e = tid; e < total; e += NT) {
+        const int2 c = cells[e];
+        if (c.x == YM_CELL_NONE) continue;
+        const int slot = select_insert(keys, bmask, shift, select_key(c.x, c.y));
+        atomicMin(&minidx[slot], (unsigned)e);
+    }
+    // the tables were built by atomics in L2: make them visible to this CU's plain loads (its L1 may hold lines fetched
+    // while they were still being filled)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (2a) earlier neighbours of every cell; a cell without one is effective
+    int n_und = 0;
+    for (unsigned s = tid, k = 0; s < cap; s += NT, k++) {
+        const unsigned key = keys[s];
+        if (key == 0u) continue;
+        const unsigned me = minidx[s];
+        const int x = (int)(key & 0xffffu) - 32768, y = (int)(key >> 16) - 32768;
+        bool any = false;
+#pragma unroll
+        for (int n = 1; n < NB; n++) {
+            const int t = select_find(keys, bmask, shift, select_key(x + DX[n], y + DY[n]));
+            const bool earlier = t >= 0 && minidx[t] < me;
+            nbr[(size_t)(n - 1) * cap + s] = earlier ? (unsigned)t : 0xffffffffu;
+            any |= earlier;
+        }
+        if (any) und_list[(size_t)(n_und++) * NT + tid] = (unsigned char)k;
+        else __hip_atomic_store(&status[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (2b) asynchronous relaxation (see select_kernel): decisions are final and only taken from final states, so stale
+    // reads merely delay; every wave of the block is resident, so the earliest undecided cell always gets decided
+    while (__ballot(n_und > 0)) {
+        int kept = 0;
+        for (int i = 0; i < n_und; i++) {
+            const unsigned k = und_list[(size_t)i * NT + tid], s = tid + k * NT;
+            bool knocked = false, pending = false;
+#pragma unroll
+            for (int j = 0; j < NB - 1; j++) {
+                const unsigned t = nbr[(size_t)j * cap + s];
+                if (t != 0xffffffffu) {
+                    const unsigned stt = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    knocked |= stt == 1u;
+                    pending |= stt == 0u;
+                }
+            }
+            if (knocked) __hip_atomic_store(&status[s], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (!pending) __hip_atomic_store(&status[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else und_list[(size_t)(kept++) * NT + tid] = (unsigned char)k;
+        }
+        n_und = kept;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (3) keep only the earliest point of every effective cell
+    for (int e = tid; e < total; e += NT) {
+        const int2 c = cells[e];
+        if (c.x == YM_CELL_NONE) continue;
+        const int t = select_find(keys, bmask, shift, select_key(c.x, c.y));
+        if (!(t >= 0 && __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u && minidx[t] == (unsigned)e))
+            cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    }
+}
+
 }  // namespace ym
