@@ -206,10 +206,12 @@ def test_finish_kernel_single_item_matches_pair():
     ref = m.match_scan(nq, nb, True, True)
     fs_ref = m.debug_sums(1, dims=ref.meta["fine_dims"])
     m.debug_option(6, 2)
-    got = m.match_scan(nq, nb, True, True)
-    assert got.response == ref.response and got.covariance == ref.covariance
-    assert (got.best_pose.x, got.best_pose.y, got.best_pose.euler[-1]) == (ref.best_pose.x, ref.best_pose.y, ref.best_pose.euler[-1])
-    assert np.array_equal(m.debug_sums(1, dims=got.meta["fine_dims"]), fs_ref)
+    for threads in (1024, 256):  # both block sizes of the one-block finish kernel: the same bits
+        m.debug_option(11, threads)
+        got = m.match_scan(nq, nb, True, True)
+        assert got.response == ref.response and got.covariance == ref.covariance
+        assert (got.best_pose.x, got.best_pose.y, got.best_pose.euler[-1]) == (ref.best_pose.x, ref.best_pose.y, ref.best_pose.euler[-1])
+        assert np.array_equal(m.debug_sums(1, dims=got.meta["fine_dims"]), fs_ref)
 
 
 def test_async_pipeline_matches_sync():

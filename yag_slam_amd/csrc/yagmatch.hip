@@ -303,6 +303,8 @@ struct ym_matcher {
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
+    int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
+    int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
     int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
@@ -1062,7 +1064,8 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
     ym::ScoreArgs a;
     a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
-    a.sums = m->sums.p; a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
+    a.sums = (P.B >= 8 && !m->keep_sums) ? nullptr : m->sums.p;
+    a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
     a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
     a.probs = reinterpret_cast<unsigned long long *>(P.probs); a.probs_stride = (size_t)lc.nx * lc.ny;
     const int nxy = lc.nx * lc.ny;
@@ -1085,7 +1088,10 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
     a.fsums_stride = P.sums_f; a.stamps = P.stamps;
     if ((P.B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
-        hipLaunchKernelGGL(ym::finish_kernel, dim3(P.B), dim3(YM_FINISH1_THREADS), 0, st, a);
+        const size_t lds = YM_FINISH_LDS_BYTES(call.refine ? (size_t)lf.nx * lf.ny * lf.nt : 0);
+        const bool small_blocks = m->finish_threads ? m->finish_threads == 256 : P.B >= 512;
+        if (small_blocks) hipLaunchKernelGGL(ym::finish_kernel<256>, dim3(P.B), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(ym::finish_kernel<1024>, dim3(P.B), dim3(1024), lds, st, a);
     } else {
         hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
         hipLaunchKernelGGL(ym::final_kernel, dim3(P.B), dim3(YM_FINISH_THREADS), 0, st, a);
@@ -1132,7 +1138,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
     m->last_B = P.B; m->last_max_n = P.max_n; m->last_max_base = P.max_base;
     m->last_nt_stride = P.nt_stride; m->last_dim_stride = P.dim_stride;
     m->last_grid_stride = P.grid_stride;
-    m->last_sums_stride[0] = P.yag ? P.yvol : P.sums_c;
+    m->last_sums_stride[0] = P.yag ? P.yvol : (P.B >= 8 && !m->keep_sums) ? 0 : P.sums_c;
     m->last_sums_stride[1] = slot.call.refine ? (P.yag ? P.yvol : P.sums_f) : 0;
     m->last_valid = true;
     return YM_OK;
@@ -2040,6 +2046,8 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 6) m->finish_form = value;
     else if (option == 9) m->corr_cw = value;
     else if (option == 10) m->select_global = value;
+    else if (option == 11) m->finish_threads = value;
+    else if (option == 12) m->keep_sums = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

@@ -12,7 +12,7 @@ struct ScoreArgs {
     const uint16_t *partial;
     size_t partial_stride;
     const YmItemState *states;
-    uint32_t *sums;       // [B][nt][ny][nx]
+    uint32_t *sums;       // [B][nt][ny][nx], or null: batches do not keep the integer sums (a third of this kernel's writes)
     size_t sums_stride;
     double *resp;         // [B][nt][ny][nx]
     double *blockmax;     // [B][n_blocks]
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
         const double ct = st.center[2];
         const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
         r = hyp_response(a.g, a.lat.penalize, sum, st.nq, x * x + y * y, angle, ct);
-        a.sums[(size_t)b * a.sums_stride + h] = sum;
+        if (a.sums) a.sums[(size_t)b * a.sums_stride + h] = sum; // kept for the parity tests (single matches)
         a.resp[(size_t)b * a.sums_stride + h] = r;
         // search-space probability grid: max over theta per (x, y).  Responses are >= 0, so the
         // u64 order of the bit patterns is the numeric order and an integer atomic max is exact.
@@ -517,16 +517,23 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
 // ---- K6 finish, one block per item (batches): everything fine_kernel + final_kernel do, without the eleven-fold
 // recomputation of the coarse arg-max that one-block-per-fine-angle costs.  Wave w scores the 3x3 fine lattice for
 // fine angles w, w + 16, ...; the fine sums stay in LDS.  grid (B), 1024 threads.
+// NT = 1024 threads: shortest latency per item; NT = 256: the kernel is a chain of short dependent phases, so on a big
+// batch several small blocks per CU hide each other's waits better than one large block after the other (dynamic LDS
+// = 12 bytes per fine hypothesis: the fine sums and responses)
 #define YM_FINISH1_THREADS 1024
-__global__ __launch_bounds__(YM_FINISH1_THREADS) void finish_kernel(FinishArgs a) {
-    constexpr int NT = YM_FINISH1_THREADS, NW = NT / 64;
+#define YM_FINISH_LDS_BYTES(nh) ((size_t)(nh) * 12 + 16)
+template <int NT>
+__global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
     __shared__ double scratch[16 * 5];
     __shared__ int s_list[NT], s_tmp[NT];
     __shared__ int s_nlist;
     __shared__ double2 s_cs[YM_MAX_FINE_NT];
     __shared__ int s_cx[64], s_cy[64];
-    __shared__ unsigned s_sum[YM_MAX_FINE_HYP];
-    __shared__ double s_fresp[YM_MAX_FINE_HYP];
+    const int nh_fine = a.refine ? a.lf.nx * a.lf.ny * a.lf.nt : 0;
+    double *s_fresp = reinterpret_cast<double *>(fin_lds);                      // [nh_fine]
+    unsigned *s_sum = reinterpret_cast<unsigned *>(fin_lds + (size_t)nh_fine * 8); // [nh_fine]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     YmItemState &st = a.states[b];
     const int nq = st.nq;
