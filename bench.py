@@ -42,7 +42,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8192, help="independent cfg2 matches per step per GPU")
+    ap.add_argument("--batch", type=int, default=16384, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--launch-batch", type=int, default=1024, help="matches per enqueue (workspace size)")
     ap.add_argument("--lanes", type=int, default=1, help="matchers (stream + workspace each) the enqueues of a step alternate over")
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
