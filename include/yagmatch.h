@@ -233,7 +233,9 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * 1 = fine + final kernels, 2 = one-block finish kernel); 7: point cache of resident base scans (0 = on, 1 = off,
  * 2 = drop every entry); 8: point cache limit in KiB; 9: chunk-waves per correlate block; 10: order-dependent smear rule
  * always through the global-memory kernel; 11: threads per finish block (256 / 1024, 0 = by batch size);
- * 12: keep the coarse integer sums of batches of 8 or more items for ym_debug_sums (single matches always do). */
+ * 12: keep the coarse integer sums of batches of 8 or more items for ym_debug_sums (single matches always do);
+ * 13: merging of consecutive beams with the same lookup offset in the correlate kernel (0 = by grid coarseness, 1 = always,
+ * 2 = never). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.

@@ -754,3 +754,36 @@ def test_order_dependent_smear_on_long_chains():
     assert ra.response == rb.response and ra.covariance == rb.covariance
     assert np.array_equal(a.debug_grid()[0], b.debug_grid()[0])
     assert np.array_equal(a.debug_cells()[0], b.debug_cells()[0])
+
+
+def test_merged_equal_offsets_are_exact():
+    """On a coarse grid neighbouring beams fall into the same cell; the correlate kernel then merges runs of equal lookup
+    offsets into one entry with a multiplicity (integer sums: exact).  Forced on (option 13 = 1) and off (= 2), on the
+    loop config where it triggers by itself and on the fine default config where it never would: identical sum volumes
+    and results, and equal to the oracle."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    short = [_mk_native(PlainScan(b.ranges[:300], b.min_angle, b.angle_increment, b.min_range, 20.0,
+                                  (b.corrected_pose.x, b.corrected_pose.y, 0.0))) for b in base[:3]]
+    qshort = _mk_native(PlainScan(q.ranges[:707], q.min_angle, q.angle_increment, q.min_range, 20.0, (3.0, 3.0, 0.0)))  # ragged last chunk
+    for loop in (True, False):
+        for query, chain in ((nq, nb), (qshort, short)):
+            vols = []
+            for mode in (1, 2, 0):
+                m = ScanMatcher(None, loop=loop)
+                m.debug_option(13, mode)
+                r = m.match_scan(query, chain, False, True)
+                vols.append((m.debug_sums(0, dims=r.meta["coarse_dims"]), r))
+                # and inside a batch (the kernels with chunk-waves)
+                per, _ = m.match_scan_batch(query, [chain] * 9, False, True)
+                assert per[4].response == r.response and per[4].covariance == r.covariance
+            assert np.array_equal(vols[0][0], vols[1][0]) and np.array_equal(vols[0][0], vols[2][0])
+            assert vols[0][1].response == vols[1][1].response and vols[0][1].covariance == vols[1][1].covariance
+    o = orc.Oracle(None, "karto", loop=True)
+    ro = o.match_scan(q, base, False, False)
+    m = ScanMatcher(None, loop=True)
+    m.debug_option(13, 1)
+    r = m.match_scan(nq, nb, False, False)
+    assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]), o.sums(0)) and abs(r.response - ro["response"]) <= 1e-12

@@ -120,6 +120,7 @@ struct CallScan {
     double pose[3];
     double max_valid; // largest reading that survives range gating (bounds the query's reach)
     double lbox[4];   // sensor-frame bounding box of the points (bounds where a base scan can stamp)
+    double beam_spacing = 0; // median valid reading x angular resolution: how far apart neighbouring end points are
     uint64_t id = 0;  // resident scan identity (0: ranges uploaded for this call only, never cached)
     int cache_hint = -1;            // entry of the matcher's point cache this scan used last time (ym_batch remembers it)
     unsigned char *cache = nullptr; // this call's cache slot (device), or null
@@ -160,6 +161,7 @@ struct CallPlan {
     size_t grid_stride = 0;
     // coarse correlate decomposition
     int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
+    int dedup = 0;            // merge consecutive beams with equal lookup offsets (coarse grids)
     int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
     // yagpy lattice bounds
     int ymaxd = 0, ymaxt = 0;
@@ -218,6 +220,7 @@ struct ym_scan {
     double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
     double pose[3];
     double max_valid_karto, max_valid_yagpy;
+    double beam_spacing; // median valid reading x angular resolution
     double lbox[4]; // sensor-frame bounding box (xmin, ymin, xmax, ymax) of every reading that can become a point
 };
 
@@ -303,6 +306,7 @@ struct ym_matcher {
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
+    int corr_dedup = 0;     // development / tests: 1 = always merge equal consecutive lookup offsets, 2 = never
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
@@ -601,6 +605,12 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.chunk = chunk;
     P.n_chunks = (max_n + chunk - 1) / chunk;
     P.n_groups = (P.n_chunks + P.cw - 1) / P.cw;
+    // coarse grids (loop closure: 5 cm cells, neighbouring end points ~1.3 cm apart) see runs of beams in one cell
+    {
+        const double spacing = call.scans[call.items[0].query].beam_spacing;
+        const bool likely = spacing > 0 && spacing < 0.6 * g.res;
+        P.dedup = (P.sx == 2 && chunk == 64 && !staged && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
+    }
 
     P.nt_stride = lc.nt;
     P.dim_stride = std::max(lc.nx, lc.ny);
@@ -1026,6 +1036,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     a.max_n = P.max_n; a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.chunk = P.chunk; a.n_chunks = P.n_chunks;
     a.ngx = P.ngx; a.nx_pad = P.nx_pad; a.sx = P.sx; a.stamps = P.stamps; a.tpb = P.tpb; a.cw = P.cw;
     a.k_begin = P.k_begin; a.nk = std::max(0, P.k_end - P.k_begin);
+    a.dedup = P.dedup; a.pad2 = 0;
     if (a.nk == 0) return YM_OK; // an empty angle slice
     int rc;
     hipEvent_t ev_k = nullptr;
@@ -1248,6 +1259,7 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->max_valid = semantics == YM_SEM_YAGPY ? s->max_valid_yagpy : s->max_valid_karto;
     for (int i = 0; i < 4; i++) o->lbox[i] = s->lbox[i];
     o->id = s->id;
+    o->beam_spacing = s->beam_spacing;
     o->cache_hint = o->qcache_hint = -1;
     return YM_OK;
 }
@@ -1274,6 +1286,16 @@ void max_valid_ranges(const double *r, int n, double min_range, double rt, doubl
     }
     *karto = k;
     *yagpy = y;
+}
+
+double median_beam_spacing(const double *r, int n, double min_range, double rt, double inc) {
+    std::vector<double> v;
+    v.reserve(n);
+    for (int i = 0; i < n; i++)
+        if (r[i] >= min_range && r[i] <= rt) v.push_back(r[i]);
+    if (v.empty()) return 0.0;
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    return v[v.size() / 2] * std::fabs(inc);
 }
 
 int check_desc(const ym_scan_desc *d) {
@@ -1412,6 +1434,7 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     s->d_ranges = nullptr;
     max_valid_ranges(d->ranges, d->n, d->min_range, d->range_threshold, &s->max_valid_karto, &s->max_valid_yagpy);
     local_bbox(d->ranges, d->n, d->min_angle, d->angle_increment, d->range_threshold, s->lbox);
+    s->beam_spacing = median_beam_spacing(d->ranges, d->n, d->min_range, d->range_threshold, d->angle_increment);
     DevGuard guard(device);
     if (!guard.ok ||
         hipMalloc(reinterpret_cast<void **>(&s->d_ranges), sizeof(double) * std::max(1, d->n)) != hipSuccess) {
@@ -1496,6 +1519,7 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
         max_valid_ranges(d.ranges, d.n, d.min_range, d.range_threshold, &k, &y);
         c.max_valid = m->cfg.semantics == YM_SEM_YAGPY ? y : k;
         local_bbox(d.ranges, d.n, d.min_angle, d.angle_increment, d.range_threshold, c.lbox);
+        c.beam_spacing = median_beam_spacing(d.ranges, d.n, d.min_range, d.range_threshold, d.angle_increment);
         at += (size_t)d.n;
     }
     if (total > 0)
@@ -2048,6 +2072,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 10) m->select_global = value;
     else if (option == 11) m->finish_threads = value;
     else if (option == 12) m->keep_sums = value;
+    else if (option == 13) m->corr_dedup = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

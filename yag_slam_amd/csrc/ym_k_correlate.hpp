@@ -7,6 +7,7 @@ namespace ym {
 
 // ================================================================== K4 correlate (coarse lattice)
 #define YM_CORR_THREADS 256
+#define YM_CORR_DEDUP_U 8
 struct CorrArgs {
     YmGeom g;
     YmLattice lat;
@@ -24,6 +25,8 @@ struct CorrArgs {
     int32_t n_chunks;
     int32_t tpb;           // staged kernel: development mode switch
     int32_t cw;            // chunk-waves per block (1, 2 or 4): consecutive beam chunks summed inside a block
+    int32_t dedup;         // 1: consecutive beams with the same lookup offset are merged into one entry with a multiplicity
+    int32_t pad2;          // (coarse grids: several beams per cell; needs chunk == 64, one wave builds one chunk)
     int32_t k_begin, nk;   // the coarse angles this launch scores: [k_begin, k_begin + nk) (all of them unless the match
                            // is split over several matchers by angle)
     int32_t ngx;           // x groups per row = ceil(nx / G)
@@ -103,6 +106,8 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     const int chunk = group * cw + cw_idx;
     const int job = (bx * jw + jw_idx) * 64 + lane;
     __shared__ int offs_all[CW][512];
+    __shared__ unsigned short mult_all[CW][128]; // dedup: multiplicity of every merged entry
+    __shared__ int n_entries[CW];                // dedup: entries of the chunk, padded to a multiple of U
     __shared__ uint32_t red[CW > 1 ? 4 * 8 * 64 : 1];
     const int *offs = offs_all[cw_idx];
     YM_STAMP(a, 8);
@@ -120,6 +125,36 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
         const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+        const bool dedup = SX == 2 && a.dedup && regular; // (host: only with chunk == 64)
+        if (dedup) {
+            // On a coarse grid consecutive beams land in the same cell: every run of equal lookup offsets becomes ONE
+            // entry with its length as multiplicity (sum_i G[c + o_i] = sum_runs len * G[c + o_run]: integer, exact).
+            // One wave compacts one 64-beam chunk by ballot.
+            for (int ci = wave; ci < cw; ci += 4) {
+                const int i = (group * cw + ci) * 64 + lane;
+                const bool valid = i < nq;
+                int o = 0;
+                if (valid) {
+                    const int l = lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) + cx0;
+                    o = (l >> 1) + (l & 1) * plane_bytes;
+                }
+                const int prev = __shfl_up(o, 1);
+                const bool newrun = valid && (lane == 0 || o != prev);
+                const unsigned long long mask = __ballot(newrun);
+                const int nvalid = __popcll(__ballot(valid)), n_u = __popcll(mask);
+                if (newrun) {
+                    const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+                    const unsigned long long higher = lane == 63 ? 0ull : (mask >> (lane + 1));
+                    const int next = higher ? lane + 1 + (__ffsll((long long)higher) - 1) : nvalid;
+                    offs_all[ci][pos] = o;
+                    mult_all[ci][pos] = (unsigned short)(next - lane);
+                }
+                const int padded = (n_u + YM_CORR_DEDUP_U - 1) / YM_CORR_DEDUP_U * YM_CORR_DEDUP_U;
+                if (lane >= n_u && lane < padded) { offs_all[ci][lane] = 0; mult_all[ci][lane] = 0; }
+                if (lane + 64 < padded) { offs_all[ci][lane + 64] = 0; mult_all[ci][lane + 64] = 0; }
+                if (lane == 0) n_entries[ci] = padded;
+            }
+        } else
         for (int e = threadIdx.x; e < cw * a.chunk; e += YM_CORR_THREADS) {
             const int ci = e / a.chunk, c = e - ci * a.chunk;
             const int i = (group * cw + ci) * a.chunk + c;
@@ -154,6 +189,49 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
             // Grid bytes are at most 100, so the bytes of TWO beams add without carries as packed u8: beams are added in
             // pairs first and the pair sum is split into the 16-bit lanes (a third fewer VALU per beam).  Only the last
             // chunk of a scan holds beams past the last reading; they are masked there (MASKED), nowhere else.
+            if (a.dedup) {
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const unsigned short *mult = mult_all[cw_idx];
+                const int n_ent = n_entries[cw_idx];
+                constexpr int DU = YM_CORR_DEDUP_U; // merged entries in flight per lane (their count is padded to a multiple)
+                for (int c = 0; c < n_ent; c += DU) {
+                    uint4 w[DU];
+                    uint32_t e[DU];
+#pragma unroll
+                    for (int u = 0; u < DU; u++) {
+                        const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u);
+                        w[u] = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(src + ad, 4));
+                        e[u] = 0u;
+                    }
+                    if (extra) {
+#pragma unroll
+                        for (int u = 0; u < DU; u++) {
+                            const uint32_t ad = lane_off + ((uint32_t)offs[c + u] & ~3u);
+                            e[u] = *reinterpret_cast<const uint32_t *>(src + ad + 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < DU; u++) {
+                        const uint32_t rr = (uint32_t)offs[c + u] & 3u;
+                        const unsigned short mv = mult[c + u]; // wave-uniform; 0 for the padding entries
+                        const us2 mm = (us2){mv, mv};
+                        const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[u].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+                        const uint32_t w4 = extra ? e[u] : nb;
+                        const uint32_t x[4] = {__builtin_amdgcn_alignbyte(w[u].y, w[u].x, rr), __builtin_amdgcn_alignbyte(w[u].z, w[u].y, rr),
+                                               __builtin_amdgcn_alignbyte(w[u].w, w[u].z, rr), __builtin_amdgcn_alignbyte(w4, w[u].w, rr)};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t ev = x[j] & 0x00FF00FFu, od = __builtin_amdgcn_perm(0u, x[j], 0x0c030c01u);
+                            us2 a0, a1, e2, o2;
+                            __builtin_memcpy(&a0, &acc[2 * j], 4); __builtin_memcpy(&a1, &acc[2 * j + 1], 4);
+                            __builtin_memcpy(&e2, &ev, 4); __builtin_memcpy(&o2, &od, 4);
+                            a0 = (us2)(e2 * mm + a0); // v_pk_mad_u16: a run is at most 64 beams x 100
+                            a1 = (us2)(o2 * mm + a1);
+                            __builtin_memcpy(&acc[2 * j], &a0, 4); __builtin_memcpy(&acc[2 * j + 1], &a1, 4);
+                        }
+                    }
+                }
+            } else {
             auto run = [&](auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
                 for (int c = 0; c < a.chunk; c += U) {
@@ -201,6 +279,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
             };
             if (i0 + a.chunk <= nq) run(std::false_type());
             else run(std::true_type());
+            }
         } else {
             for (int c = 0; c < a.chunk; c += U) {
                 uint4 w[U];
