@@ -167,7 +167,7 @@ struct CallPlan {
     int ymaxd = 0, ymaxt = 0;
     size_t yvol = 0;
     // strides
-    int nt_stride = 0, dim_stride = 0, score_blocks = 0;
+    int nt_stride = 0, dim_stride = 0, score_blocks = 0, cell_blocks = 0;
     size_t sums_c = 0, sums_f = 0, partial_stride = 0;
     // call descriptor
     size_t scans_bytes = 0, desc_bytes = 0;
@@ -617,7 +617,8 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
     P.partial_stride = (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
-    P.score_blocks = (int)((P.sums_c + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS);
+    P.cell_blocks = (lc.nx * lc.ny + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
+    P.score_blocks = P.cell_blocks * lc.nt; // block maxima per (angle, block of cells)
 
     int rc;
     if ((rc = m->states.ensure(B))) return rc;
@@ -1078,12 +1079,10 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.sums = (P.B >= 8 && !m->keep_sums) ? nullptr : m->sums.p;
     a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
     a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
-    a.probs = reinterpret_cast<unsigned long long *>(P.probs); a.probs_stride = (size_t)lc.nx * lc.ny;
-    const int nxy = lc.nx * lc.ny;
-    a.h_begin = P.k_begin * nxy; a.h_end = P.k_end * nxy;
-    a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's blocks are not the volume's: recomputed once it is whole
-    const int blocks = slot.call.slice ? (a.h_end - a.h_begin + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS : P.score_blocks;
-    if (blocks > 0) hipLaunchKernelGGL(ym::score_kernel, dim3(blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
+    a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
+    a.k_begin = P.k_begin; a.k_end = P.k_end;
+    a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's maxima are recomputed once the volume is whole
+    hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
 }
 
 void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
@@ -1685,7 +1684,7 @@ int ym_match_slice_finish(ym_matcher *m, ym_result *out) {
     const CallPlan &P = slot.plan;
     // the caller has completed the response volume (all slices gathered) and the per-(x, y) maxima (max over all
     // slices) on this stream: block maxima of the whole volume, then the ordinary finish stage
-    hipLaunchKernelGGL(ym::blockmax_kernel, dim3(P.score_blocks), dim3(YM_SCORE_THREADS), 0, m->stream, P.resp, (int)P.sums_c, m->blockmax.p);
+    hipLaunchKernelGGL(ym::blockmax_kernel, dim3(P.cell_blocks, P.lc.nt), dim3(YM_SCORE_THREADS), 0, m->stream, P.resp, P.lc.nx * P.lc.ny, m->blockmax.p);
     enqueue_finish(m, slot, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(slot.done, m->stream));

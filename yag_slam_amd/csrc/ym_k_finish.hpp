@@ -16,10 +16,10 @@ struct ScoreArgs {
     size_t sums_stride;
     double *resp;         // [B][nt][ny][nx]
     double *blockmax;     // [B][n_blocks]
-    unsigned long long *probs; // [B][ny*nx] bit patterns of non-negative doubles, zeroed by prepare_kernel
+    double *probs;        // [B][ny*nx] max over theta per (x, y)
     size_t probs_stride;
     int32_t n_chunks, nx_pad, n_blocks;
-    int32_t h_begin, h_end;   // hypotheses [h_begin, h_end) of the [k][iy][ix] volume (a slice of angles, or all)
+    int32_t k_begin, k_end;   // the coarse angles this launch scores (a slice, or all)
     int32_t write_blockmax;
     unsigned long long *stamps;
 };
@@ -42,49 +42,57 @@ __device__ __forceinline__ double hyp_response(const YmGeom &g, int penalize, un
     return response;
 }
 
-// one thread per coarse hypothesis: add the beam-chunk partials, normalise, penalise.
-// grid (n_blocks, B)
+// One thread per (x, y) lattice cell, walking the coarse angles [k_begin, k_end): add the chunk-group partials,
+// normalise, penalise, keep the maximum over theta (Karto's search-space probability grid: a plain store, no atomics).
+// Block maxima are kept per (angle, block of YM_SCORE_THREADS cells): blockmax[k * n_cell_blocks + cb] covers the
+// hypotheses h = k * nxy + cb * YM_SCORE_THREADS + t -- the finish stage looks for the arg-max and the tie set there.
+// grid (n_cell_blocks, B)
 __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     __shared__ double scratch[16];
     const int b = blockIdx.y;
     const YmItemState &st = a.states[b];
     const int nx = a.lat.nx, ny = a.lat.ny, nt = a.lat.nt, nxy = nx * ny;
-    const int h = a.h_begin + blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
-    double r = -1.0;
+    const int c = blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
+    const bool live = c < nxy;
+    const int iy = live ? c / nx : 0, ix = live ? c - iy * nx : 0;
+    const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
+    const double sq_dist = x * x + y * y;
+    const double ct = st.center[2];
+    const int nq = st.nq;
+    const size_t cstride = (size_t)nt * ny * a.nx_pad;
+    const uint16_t *p0 = a.partial + (size_t)b * a.partial_stride + (size_t)iy * a.nx_pad + ix;
+    double best = 0.0;
     YM_STAMP(a, 10);
-    (void)nt;
-    if (h < a.h_end) {
-        const int k = h / nxy, c = h - k * nxy;
-        const int iy = c / nx, ix = c - iy * nx;
-        const uint16_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
-        const size_t cstride = (size_t)nt * ny * a.nx_pad;
-        unsigned sum = 0;
-#pragma unroll 8
-        for (int c2 = 0; c2 < a.n_chunks; c2++) sum += p[(size_t)c2 * cstride];
-        const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
-        const double ct = st.center[2];
-        const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
-        r = hyp_response(a.g, a.lat.penalize, sum, st.nq, x * x + y * y, angle, ct);
-        if (a.sums) a.sums[(size_t)b * a.sums_stride + h] = sum; // kept for the parity tests (single matches)
-        a.resp[(size_t)b * a.sums_stride + h] = r;
-        // search-space probability grid: max over theta per (x, y).  Responses are >= 0, so the
-        // u64 order of the bit patterns is the numeric order and an integer atomic max is exact.
-        if (r > 0.0) atomicMax(&a.probs[(size_t)b * a.probs_stride + c], (unsigned long long)__double_as_longlong(r));
+    for (int k = a.k_begin; k < a.k_end; k++) {
+        double r = -1.0;
+        if (live) {
+            const uint16_t *p = p0 + (size_t)k * ny * a.nx_pad;
+            unsigned sum = 0;
+#pragma unroll 4
+            for (int c2 = 0; c2 < a.n_chunks; c2++) sum += p[(size_t)c2 * cstride];
+            const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
+            r = hyp_response(a.g, a.lat.penalize, sum, nq, sq_dist, angle, ct);
+            const size_t h = (size_t)k * nxy + c;
+            if (a.sums) a.sums[(size_t)b * a.sums_stride + h] = sum; // kept for the parity tests (single matches)
+            a.resp[(size_t)b * a.sums_stride + h] = r;
+            best = r > best ? r : best;
+        }
+        if (a.write_blockmax) {
+            const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
+            if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + (size_t)k * gridDim.x + blockIdx.x] = m;
+        }
     }
-    if (a.write_blockmax) {
-        const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
-        if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + blockIdx.x] = m;
-    }
+    if (live) a.probs[(size_t)b * a.probs_stride + c] = best; // max over theta of this launch's angles (responses are >= 0)
     YM_STAMP(a, 11);
 }
 
-// maxima of YM_SCORE_THREADS consecutive responses of a volume that was scored in angle slices (by several matchers):
-// what score_kernel writes itself when it scores the whole volume.  grid (n_blocks)
-__global__ __launch_bounds__(YM_SCORE_THREADS) void blockmax_kernel(const double *resp, int n, double *blockmax) {
+// block maxima of a volume that was scored in angle slices (by several matchers): what score_kernel writes itself when
+// it scores the whole volume.  grid (n_cell_blocks, nt)
+__global__ __launch_bounds__(YM_SCORE_THREADS) void blockmax_kernel(const double *resp, int nxy, double *blockmax) {
     __shared__ double scratch[16];
-    const int h = blockIdx.x * YM_SCORE_THREADS + threadIdx.x;
-    const double m = block_reduce(h < n ? resp[h] : -1.0, OpMaxD(), -1.0, scratch);
-    if (threadIdx.x == 0) blockmax[blockIdx.x] = m;
+    const int c = blockIdx.x * YM_SCORE_THREADS + threadIdx.x, k = blockIdx.y;
+    const double m = block_reduce(c < nxy ? resp[(size_t)k * nxy + c] : -1.0, OpMaxD(), -1.0, scratch);
+    if (threadIdx.x == 0) blockmax[(size_t)k * gridDim.x + blockIdx.x] = m;
 }
 
 // ================================================================== K6 finish
@@ -99,7 +107,7 @@ struct FinishArgs {
     YmItemState *host_out;    // pinned host memory, written directly (nullable)
     const double *resp;       // coarse responses [B][nt][ny][nx]
     size_t sums_stride;
-    const double *blockmax;   // [B][n_blocks] maxima of YM_SCORE_THREADS consecutive responses
+    const double *blockmax;   // [B][n_blocks] maxima per (angle, block of YM_SCORE_THREADS lattice cells)
     const double *probs;      // [B][ny*nx] max over theta per (x, y)  (m_pSearchSpaceProbs)
     size_t probs_stride;
     const uint8_t *grid;
@@ -191,9 +199,12 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
     if (tid < YM_CANON) {
         if (!overflow) {
             const int nlist = *s_nlist;
+            const int nxy = L.nx * L.ny, ncb = (nxy + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
             for (int w = tid; w < nlist * YM_SCORE_THREADS; w += YM_CANON) {
-                const int h = s_list[w / YM_SCORE_THREADS] * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
-                if (h < nh && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+                const int bid = s_list[w / YM_SCORE_THREADS]; // block = (angle k, block cb of cells)
+                const int k = bid / ncb, c = (bid - k * ncb) * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
+                const int h = k * nxy + c;
+                if (c < nxy && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
             }
         } else {
             for (int h = tid; h < nh; h += YM_CANON)
