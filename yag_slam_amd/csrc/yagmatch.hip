@@ -1082,7 +1082,9 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
     a.k_begin = P.k_begin; a.k_end = P.k_end;
     a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's maxima are recomputed once the volume is whole
-    hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
+    if (P.B >= 8) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
+    else if (P.k_end > P.k_begin)
+        hipLaunchKernelGGL(ym::score_hyp_kernel, dim3(P.cell_blocks, P.k_end - P.k_begin, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
 }
 
 void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {

@@ -86,6 +86,43 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     YM_STAMP(a, 11);
 }
 
+// The same for a few items (a single match, an angle slice): one thread per HYPOTHESIS -- a thread walking all angles
+// would be a long serial chain with nothing to hide it behind -- in the same block layout: block (cb, k) holds the cells
+// cb * YM_SCORE_THREADS + t of angle k.  The per-(x, y) maximum is then an integer atomic max on the fp64 bit patterns
+// (responses are >= 0, so the u64 order is the numeric order; probs is zeroed by the prepare stage).
+// grid (n_cell_blocks, k_end - k_begin, B)
+__global__ __launch_bounds__(YM_SCORE_THREADS) void score_hyp_kernel(ScoreArgs a) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.z;
+    const YmItemState &st = a.states[b];
+    const int nx = a.lat.nx, ny = a.lat.ny, nt = a.lat.nt, nxy = nx * ny;
+    const int c = blockIdx.x * YM_SCORE_THREADS + threadIdx.x, k = a.k_begin + blockIdx.y;
+    double r = -1.0;
+    YM_STAMP(a, 10);
+    if (c < nxy) {
+        const int iy = c / nx, ix = c - iy * nx;
+        const uint16_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
+        const size_t cstride = (size_t)nt * ny * a.nx_pad;
+        unsigned sum = 0;
+#pragma unroll 8
+        for (int c2 = 0; c2 < a.n_chunks; c2++) sum += p[(size_t)c2 * cstride];
+        const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
+        const double ct = st.center[2];
+        const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
+        r = hyp_response(a.g, a.lat.penalize, sum, st.nq, x * x + y * y, angle, ct);
+        const size_t h = (size_t)k * nxy + c;
+        if (a.sums) a.sums[(size_t)b * a.sums_stride + h] = sum;
+        a.resp[(size_t)b * a.sums_stride + h] = r;
+        if (r > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long *>(a.probs) + (size_t)b * a.probs_stride + c, (unsigned long long)__double_as_longlong(r));
+    }
+    if (a.write_blockmax) {
+        const double m = block_reduce(r, OpMaxD(), -1.0, scratch);
+        if (threadIdx.x == 0) a.blockmax[(size_t)b * a.n_blocks + (size_t)k * gridDim.x + blockIdx.x] = m;
+    }
+    YM_STAMP(a, 11);
+}
+
 // block maxima of a volume that was scored in angle slices (by several matchers): what score_kernel writes itself when
 // it scores the whole volume.  grid (n_cell_blocks, nt)
 __global__ __launch_bounds__(YM_SCORE_THREADS) void blockmax_kernel(const double *resp, int nxy, double *blockmax) {

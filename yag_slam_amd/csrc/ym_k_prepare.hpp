@@ -26,7 +26,7 @@ struct PrepareArgs {
     int4 *bbox;              // [B][max_base][ceil(max_n/64)] window bounding box of 64 consecutive cells
     double2 *ctrig;          // [B][nt_stride] (cos, sin) of every coarse angle
     int32_t *hypcell;        // [B][2][dim_stride]
-    double *probs;           // [B][ny*nx] filled by score_kernel (unused here)
+    double *probs;           // [B][ny*nx] cleared here, filled by the score stage
     int32_t max_n, max_base, nt_stride, dim_stride;
     // batches: the heavy work (projection, trigger chain) runs once per distinct stale scan / distinct query in
     // points_kernel; jobs[j] = scan index, bit 31 set = "as a query, into query slot (j's low bits in qjob_slot)"
@@ -205,6 +205,7 @@ __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmI
         const double angle = (sr.pose[2] - a.lat.angle_off) + tid * a.lat.angle_res;
         a.ctrig[(size_t)b * a.nt_stride + tid] = make_double2(cos(angle), sin(angle));
     }
+    for (int i = tid; i < a.lat.nx * a.lat.ny; i += NT) a.probs[(size_t)b * a.lat.nx * a.lat.ny + i] = 0.0; // (score_hyp_kernel: atomic max)
     // coarse hypothesis cells + regularity flag
     int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
     int32_t *cy = cx + a.dim_stride;
