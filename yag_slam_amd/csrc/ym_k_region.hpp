@@ -30,6 +30,9 @@ namespace ym {
 #define YM_RG_G 13                            // hypotheses per lane: 13 bytes + 3 of misalignment = four dwords
 #define YM_RG_ZERO (4 * YM_RG_CLS)               // LDS offset of an all-zero patch: what the padding entries point at
 #define YM_RG_LDS_BYTES (YM_RG_ZERO + 26 * YM_RG_PITCH + 32)
+// bytes the host keeps past the last item's planes: a staged region may start up to (ROWS - 1) * 2 + 1 rows and 96 bytes
+// past the last cell of the second plane (never gathered, but read)
+#define YM_RG_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(half_pitch) + 256)
 #define YM_RG_MAX_BINS 8192
 #define YM_RG_MAX_ENTRIES 28672
 #define YM_RG_GROUP_BEAMS 640                 // 16-bit sums hold 640 beams of 100
@@ -183,26 +186,36 @@ __device__ __forceinline__ void rg_read4(const uint32_t (&ad)[4], uint32_t (&w)[
     w[2][0] = p2.x; w[2][1] = p2.y; w[2][2] = q2.x; w[2][3] = q2.y;
     w[3][0] = p3.x; w[3][1] = p3.y; w[3][2] = q3.x; w[3][3] = q3.y;
 }
-// Four patches E[u0 .. u0 + 4) (E = LDS origins, one per lane of this wave) into the packed 16-bit sums (acc[2j]:
+// Four patches (their LDS origins arrive in scalar registers: the entry list is read with scalar loads) into the packed 16-bit sums (acc[2j]:
 // hypotheses 4j, 4j + 2; acc[2j + 1]: 4j + 1, 4j + 3).  Patches 2i and 2i + 1 share their misalignment (bin_kernel): grid
 // bytes are at most 100, so their RAW dwords add without carries and one funnel serves both; the two funnelled pair sums
 // are split into even / odd bytes and added with one v_add3 each.
-__device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint32_t E, int u0) {
-    uint32_t w[4][4], ad[4], x[2][4];
+__device__ __forceinline__ void rg_read2(uint32_t ad0, uint32_t ad1, uint32_t (&w)[2][4]) {
+    rg_u32x2 p0, q0, p1, q1;
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %4 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read2_b32 %3, %5 offset0:2 offset1:3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1) : "v"(ad0 & ~3u), "v"(ad1 & ~3u) : "memory");
+    w[0][0] = p0.x; w[0][1] = p0.y; w[0][2] = q0.x; w[0][3] = q0.y;
+    w[1][0] = p1.x; w[1][1] = p1.y; w[1][2] = q1.x; w[1][3] = q1.y;
+}
+// one pair of patches with equal misalignment: raw dwords added, one funnel
+__device__ __forceinline__ void rg_pair(uint32_t lane_off, uint32_t e2 /* two 16-bit origins */, uint32_t (&x)[4]) {
+    const uint32_t ad0 = lane_off + (e2 & 0xffffu), ad1 = lane_off + (e2 >> 16);
+    uint32_t w[2][4], s[4];
+    rg_read2(ad0, ad1, w);
+    const uint32_t rr = ad0 & 3u;
 #pragma unroll
-    for (int u = 0; u < 4; u++) ad[u] = lane_off + (uint32_t)__builtin_amdgcn_readlane((int)E, u0 + u);
-    rg_read4(ad, w);
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t rr = ad[2 * h] & 3u;
-        uint32_t s[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) s[j] = w[2 * h][j] + w[2 * h + 1][j];
-        x[h][0] = __builtin_amdgcn_alignbyte(s[1], s[0], rr);
-        x[h][1] = __builtin_amdgcn_alignbyte(s[2], s[1], rr);
-        x[h][2] = __builtin_amdgcn_alignbyte(s[3], s[2], rr);
-        x[h][3] = __builtin_amdgcn_alignbyte(0u, s[3], rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
-    }
+    for (int j = 0; j < 4; j++) s[j] = w[0][j] + w[1][j];
+    x[0] = __builtin_amdgcn_alignbyte(s[1], s[0], rr);
+    x[1] = __builtin_amdgcn_alignbyte(s[2], s[1], rr);
+    x[2] = __builtin_amdgcn_alignbyte(s[3], s[2], rr);
+    x[3] = __builtin_amdgcn_alignbyte(0u, s[3], rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
+}
+__device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint2 ee /* four 16-bit origins, wave-uniform */) {
+    uint32_t x[2][4];
+    rg_pair(lane_off, ee.x, x[0]);
+    rg_pair(lane_off, ee.y, x[1]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char region[YM_RG_LDS_BYTES]; // four class images + the zero patch
     __shared__ int rlist[YM_RG_MAX_REGIONS];
     __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][3]; // per wave and listed region: first entry of beam group 0, of group 1, end
+    __shared__ uint2 elist[NW][64];                   // per wave: its first 256 entries of the region being gathered
     __shared__ int rcount;
     int p;
     const int b = xcd_item_of_block_2d(p);
@@ -274,69 +288,102 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
                 seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1]; seginfo[wave][i][2] = (unsigned short)srow[ng];
             }
         __syncthreads();
+        // copy task t = (class, row, 16-byte block): thread tid takes t = tid, tid + NT, ... (the last ones take task TASKS - 1
+        // again).  Its source offset inside a region is fixed, so a load is one instruction: uniform region base + that
+        // offset.  Nothing is range-checked: rows past the window and blocks past a plane row are other bytes of the
+        // planes buffer (the host allocates YM_RG_PLANES_SLACK bytes past the last item), and no patch the window holds
+        // ever reads them.
         uint4 v[PER];
-        // copy task t = (class, row, 16-byte block): thread tid takes t = tid, tid + NT, ...; 32-bit offsets from uniform bases
+        uint32_t src_rel[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t t = min((uint32_t)(tid + q * NT), (uint32_t)(TASKS - 1));
+            const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS; // rowidx = class * ROWS + row
+            const uint32_t cls = rowidx / YM_RG_ROWS, r = rowidx - cls * YM_RG_ROWS;
+            src_rel[q] = (cls & 1u) * (uint32_t)plane_bytes + (2u * r + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
+        }
         auto stage_load = [&](int R) {
             const int RX = R % a.nrx, RY = R / a.nrx;
-            const uint32_t xb0 = (uint32_t)(RX * YM_RG_W), y0 = (uint32_t)(2 * RY * YM_RG_H);
+            const uint8_t *src = planes + ((size_t)(2 * RY * YM_RG_H) * half_pitch + (size_t)RX * YM_RG_W); // (wave-uniform)
 #pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const uint32_t t = (uint32_t)(tid + q * NT);
-                const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS; // rowidx = class * ROWS + row
-                const uint32_t cls = rowidx / YM_RG_ROWS, r = rowidx - cls * YM_RG_ROWS;
-                const uint32_t Y = y0 + 2u * r + (cls >> 1), xb = xb0 + 16u * seg;
-                v[q] = make_uint4(0u, 0u, 0u, 0u);
-                if (t < (uint32_t)TASKS && Y < (uint32_t)a.g.win_w && xb + 16u <= (uint32_t)half_pitch)
-                    v[q] = *reinterpret_cast<const uint4 *>(planes + ((cls & 1u) * (uint32_t)plane_bytes + Y * (uint32_t)half_pitch + xb));
-            }
+            for (int q = 0; q < PER; q++) v[q] = *reinterpret_cast<const uint4 *>(src + src_rel[q]);
         };
         auto stage_store = [&]() {
 #pragma unroll
             for (int q = 0; q < PER; q++) {
-                const uint32_t t = (uint32_t)(tid + q * NT);
+                const uint32_t t = min((uint32_t)(tid + q * NT), (uint32_t)(TASKS - 1));
                 const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS;
-                if (t < (uint32_t)TASKS) {
-                    uint32_t *d = reinterpret_cast<uint32_t *>(region + rowidx * YM_RG_PITCH + 16u * seg); // class images are contiguous
-                    d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
-                }
+                uint32_t *d = reinterpret_cast<uint32_t *>(region + rowidx * YM_RG_PITCH + 16u * seg); // class images are contiguous
+                d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
             }
         };
-        // this wave's entries of a region: [s0, s1) beam group 0, [s1, s2) beam group 1; the first 128 in e0, e1
-        int s0 = 0, s1 = 0, s2 = 0;
-        unsigned e0 = 0, e1 = 0;
-        auto segment = [&](int ri, int &t0, int &t1, int &t2, unsigned &f0, unsigned &f1) {
-            t0 = t1 = t2 = 0; f0 = f1 = 0u;
+        // this wave's entries of a region: [s0, s1) beam group 0, [s1, s2) beam group 1 (multiples of four entries)
+        auto segment = [&](int ri, int &t0, int &t1, int &t2) {
+            t0 = t1 = t2 = 0;
             if (kvalid) {
                 t0 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][0]);
                 t1 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][1]);
                 t2 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][2]);
-                f0 = t0 + lane < t2 ? (unsigned)entries[t0 + lane] : 0u;
-                f1 = t0 + 64 + lane < t2 ? (unsigned)entries[t0 + 64 + lane] : 0u;
             }
+        };
+        // The first 256 entries of a wave's segment travel like the region itself: loaded into a register while the previous
+        // region is gathered, put into LDS between the barriers, read from there (a broadcast ds_read_b64 per four patches).
+        // No vector-memory wait inside the gather: that would also wait for the staging loads in flight.
+        const uint2 *__restrict__ entries4 = reinterpret_cast<const uint2 *>(entries); // four entries per element
+        uint2 ev = make_uint2(0u, 0u);
+        auto entries_load = [&](int t0, int t2) {
+            ev = make_uint2(0u, 0u);
+            if (t0 + 4 * lane < t2) ev = entries4[(t0 >> 2) + lane];
+        };
+        auto gather = [&](uint32_t (&sums)[8], int base, int lo, int hi) { // entries [lo, hi) of the segment that starts at base
+            const int lds_hi = min(hi, base + 256);
+            if (lo < lds_hi) {
+                const uint2 *el = elist[wave] + ((lo - base) >> 2);
+                const int n4 = (lds_hi - lo) >> 2;
+                uint2 ee = el[0];
+                for (int c = 0; c < n4; c++) {
+                    const uint2 nx = el[min(c + 1, n4 - 1)];
+                    rg_gather4(sums, lane_off, ee);
+                    ee = nx;
+                }
+            }
+            for (int c = max(lo, lds_hi); c < hi; c += 4) rg_gather4(sums, lane_off, entries4[c >> 2]); // (a very long segment)
         };
         const bool timing = a.stamps && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0;
         unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = timing ? wall_clock64() : 0ull;
 #define YM_RG_PHASE(i) do { if (timing) { const unsigned long long tn_ = wall_clock64(); tph[i] += tn_ - tl; tl = tn_; } } while (0)
+        int s0 = 0, s1 = 0, s2 = 0;
+        if (nlist > 0) {
+            segment(0, s0, s1, s2);
+            entries_load(s0, s2);
+            if (dev_mode != 4) { stage_load(rlist[0]); stage_store(); }
+            elist[wave][lane] = ev;
+        }
+        __syncthreads();
         for (int ri = 0; ri < nlist; ri++) {
-            // this wave's entries first: they are back before the staging loads issued after them
-            segment(ri, s0, s1, s2, e0, e1);
-            YM_RG_PHASE(0);
-            __syncthreads(); // every wave is done with the previous region
-            YM_RG_PHASE(1);
-            if (dev_mode != 4) { stage_load(rlist[ri]); stage_store(); }
-            YM_RG_PHASE(2);
-            __syncthreads();
-            YM_RG_PHASE(3);
-            if (dev_mode != 3) {
-                for (int c = s0; c < s2; c += 64) {
-                    const int j = (c - s0) >> 6;
-                    unsigned e = j == 0 ? e0 : e1;
-                    if (j >= 2) e = c + lane < s2 ? (unsigned)entries[c + lane] : 0u;
-                    const int hi = min(64, s2 - c), mid = min(max(s1 - c, 0), hi); // (multiples of 4)
-                    for (int u0 = 0; u0 < mid; u0 += 4) rg_gather4(acc[0], lane_off, e, u0);
-                    for (int u0 = mid; u0 < hi; u0 += 4) rg_gather4(acc[1], lane_off, e, u0);
-                }
+            // two-stage pipeline: the global loads of the next region are in flight (registers) while this one is gathered
+            const bool has_next = ri + 1 < nlist;
+            int n0 = 0, n1 = 0, n2 = 0;
+            if (has_next) {
+                segment(ri + 1, n0, n1, n2);
+                entries_load(n0, n2);
+                if (dev_mode != 4) stage_load(rlist[ri + 1]);
             }
+            YM_RG_PHASE(0);
+            if (dev_mode != 3) {
+                gather(acc[0], s0, s0, s1);
+                gather(acc[1], s0, s1, s2);
+            }
+            YM_RG_PHASE(1);
+            __syncthreads(); // every wave is done with region ri
+            YM_RG_PHASE(2);
+            if (has_next) {
+                if (dev_mode != 4) stage_store();
+                elist[wave][lane] = ev;
+            }
+            s0 = n0; s1 = n1; s2 = n2;
+            YM_RG_PHASE(3);
+            __syncthreads();
             YM_RG_PHASE(4);
         }
         if (timing) {
