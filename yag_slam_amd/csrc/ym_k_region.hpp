@@ -81,10 +81,11 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // never meets a ragged group.  An item whose padded list would not fit gets starts[nbins] = -1 and is scored by the
 // per-cell path of correlate_region_kernel.
 __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
-    __shared__ unsigned cnt[YM_RG_MAX_BINS][2]; // per bin four 16-bit counters (one per misalignment), later the runs' fill positions
+    constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
+    __shared__ unsigned cnt[YM_RG_MAX_BINS][2]; // per bin four 16-bit counters (one per misalignment), later the runs' first positions
     __shared__ unsigned short ent[YM_RG_MAX_ENTRIES];
     __shared__ int wave_tot[YM_BIN_THREADS / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const YmItemState &st = a.states[b];
     const int nq = st.nq, nt = a.lat.nt;
     const int total = nq * nt;
@@ -96,11 +97,24 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     int32_t *starts = a.starts + (size_t)b * a.starts_stride;
     for (int i = tid; i < a.nbins * 2; i += YM_BIN_THREADS) (&cnt[0][0])[i] = 0u;
     __syncthreads();
-    for (int p = tid; p < total; p += YM_BIN_THREADS) {
-        const int k = p / nq, i = p - k * nq;
-        const double2 cs = trig[k];
-        int bin; unsigned e;
-        if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e)) atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u)));
+    // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
+    // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
+    unsigned key[MAXP];  // bin << 16 | entry; 0xffffffff = no pair
+    unsigned short rank[MAXP];
+#pragma unroll
+    for (int q = 0; q < MAXP; q++) {
+        const int p = tid + q * YM_BIN_THREADS;
+        key[q] = 0xffffffffu;
+        rank[q] = 0;
+        if (p < total) {
+            const int k = p / nq, i = p - k * nq;
+            const double2 cs = trig[k];
+            int bin; unsigned e;
+            if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e)) {
+                key[q] = (unsigned)bin << 16 | e;
+                rank[q] = (unsigned short)((atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu);
+            }
+        }
     }
     __syncthreads();
     // exclusive scan of the padded bin sizes: thread t owns the bins [t * per, (t + 1) * per)
@@ -119,9 +133,9 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int v = __shfl_up(incl, d);
-            if ((tid & 63) >= d) incl += v;
+            if (lane >= d) incl += v;
         }
-        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        if (lane == 63) wave_tot[tid >> 6] = incl;
         __syncthreads();
         int base = 0, all = 0;
         for (int w = 0; w < YM_BIN_THREADS / 64; w++) {
@@ -153,12 +167,13 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
         if (!fits) return; // (block-uniform)
     }
     __syncthreads();
-    for (int p = tid; p < total; p += YM_BIN_THREADS) {
-        const int k = p / nq, i = p - k * nq;
-        const double2 cs = trig[k];
-        int bin; unsigned e;
-        if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e))
-            ent[(atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu] = (unsigned short)e;
+    // Pass 2: every pair to its run's first position + its rank
+#pragma unroll
+    for (int q = 0; q < MAXP; q++) {
+        if (key[q] == 0xffffffffu) continue;
+        const unsigned bin = key[q] >> 16, e = key[q] & 0xffffu;
+        const unsigned f = cnt[bin][(e >> 1) & 1u];
+        ent[((e & 1u) ? f >> 16 : f & 0xffffu) + rank[q]] = (unsigned short)e;
     }
     __syncthreads();
     uint32_t *out = reinterpret_cast<uint32_t *>(a.entries + (size_t)b * a.entries_stride);
