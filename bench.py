@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--cfg3-scans", type=int, default=CFG3_SCANS)
     ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
     ap.add_argument("--corr-chunks", type=int, default=0, help="development: beam chunks per angle in the correlate kernel")
-    ap.add_argument("--corr-region", type=int, default=0, help="development: 1 = direct correlate on batches too; >= 2 region kernel modes")
+    ap.add_argument("--corr-region", type=int, default=0, help="development: 1 = direct correlate on batches too")
     ap.add_argument("--corr-region-nw", type=int, default=0, help="development: waves per region-correlate block")
     ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
     ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
@@ -467,8 +467,7 @@ def main():
         assert all(p.meta["hypotheses"] == hyp_per_match for p in per)
         hyp_step = hyp_per_match * args.batch
         ref = m.match_scan(query, chains[0], True, True)
-        if not os.environ.get("YM_BENCH_TIMING_ONLY"):  # (development variants that skip work on purpose)
-            assert ref.response == per[0].response and ref.covariance == per[0].covariance
+        assert ref.response == per[0].response and ref.covariance == per[0].covariance
 
         for i in range(args.warmup):
             step(i)
@@ -521,18 +520,25 @@ def main():
             "collective": "all_gather of %d 64-byte best records per rank per step" % E if world > 1 else "none",
         }
         traffic = profile_json("traffic_correlate.json")
-        l1 = profile_json("l1_correlate.json")
+        issue = profile_json("issue_correlate.json")
+        region = LB >= 8 and args.corr_region != 1
+        kernel = "ym::correlate_region_kernel<7>" if region else "ym::correlate_kernel<2, 16, 4>"
+        if traffic and traffic.get("kernel") != kernel:
+            traffic = None
+        if issue and issue.get("kernel") != kernel:
+            issue = None
         step_alg = hyp_step * nq  # coarse + fine lattice points x one byte per valid beam
         line["roofline"] = {
-            "bound": "hbm", "kernel": "ym::correlate_kernel<2, 16, 4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic["hbm_bytes_per_launch"] if traffic and int(traffic.get("batch", 0)) == LB else None,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": corr_s * 1e6,
             "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
             # the whole step against the same roof: every kernel of the call, launch gaps and host work included
             "frac_step": step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            # what actually binds the kernel (its grid bands live in L2): the vector L1's lane-access rate
-            "l1_lane_access_rate": l1,
+            # what actually binds the kernel (the patches are gathered from LDS, the grid bands live in L2): VALU issue and
+            # LDS busy cycles from the committed counter pass
+            "issue_rate": issue,
         }
         del batches
         for lm in lanes[1:]:

@@ -46,32 +46,47 @@ def main():
         f = os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, src))
         if os.path.exists(f) and os.path.getsize(f) > 0:
             shutil.copy(f, os.path.join(prof, "%s_%s" % (short, src.replace("bench.json", "bench_line.json"))))
-    fetch, l2, tcp = kernel_means(tag, "fetch"), kernel_means(tag, "l2"), kernel_means(tag, "tcp")
+    fetch, l2, tcp, sq = kernel_means(tag, "fetch"), kernel_means(tag, "l2"), kernel_means(tag, "tcp"), kernel_means(tag, "sq")
     stats = {}
     f = os.path.join(REPO, "gpurun_out", "%s_stats" % tag, "%s_kernel_stats.csv" % tag)
     if os.path.exists(f):
         for r in csv.DictReader(open(f)):
             stats[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
     rows = []
-    for k in sorted(set(fetch) | set(l2) | set(tcp)):
+    for k in sorted(set(fetch) | set(l2) | set(tcp) | set(sq)):
         rows.append((k, fetch.get(k, {}).get("FETCH_SIZE", 0.0), l2.get(k, {}).get("TCC_HIT_sum", 0.0), l2.get(k, {}).get("TCC_MISS_sum", 0.0),
-                     tcp.get(k, {}).get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0), tcp.get(k, {}).get("TCP_TOTAL_ACCESSES_sum", 0.0)))
+                     tcp.get(k, {}).get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0), tcp.get(k, {}).get("TCP_TOTAL_ACCESSES_sum", 0.0),
+                     sq.get(k, {}).get("SQ_INSTS_VALU", 0.0), sq.get(k, {}).get("SQ_INSTS_LDS", 0.0),
+                     sq.get(k, {}).get("SQ_LDS_IDX_ACTIVE", 0.0), sq.get(k, {}).get("SQ_LDS_BANK_CONFLICT", 0.0)))
     pmc_csv = os.path.join(prof, "%s_pmc_batch%d.csv" % (short, batch))
     with open(pmc_csv, "w") as o:
-        o.write("# rocprofv3 --pmc FETCH_SIZE | --pmc TCC_HIT_sum TCC_MISS_sum | --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum "
-                "(three separate passes, nothing else traced): python3 bench.py --only cfg2x --steps 2 --warmup 1  (launch batch %d)\n" % batch)
+        o.write("# rocprofv3 --pmc FETCH_SIZE | --pmc TCC_HIT_sum TCC_MISS_sum | --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum | "
+                "--pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT (four separate passes, nothing else traced): "
+                "python3 bench.py --only cfg2x --steps 2 --warmup 1  (launch batch %d)\n" % batch)
         o.write("# means per launch.  FETCH_SIZE in KiB as reported; gfx950 counts half of a 16-B/lane stream (MI355X_MICROARCH.md): bytes ~= 2*1024*FETCH_SIZE\n")
-        o.write("kernel,FETCH_SIZE_KiB,TCC_HIT_sum,TCC_MISS_sum,l2_hit_rate,TCP_TOTAL_CACHE_ACCESSES_sum,TCP_TOTAL_ACCESSES_sum\n")
-        for k, fz, h, m, ca, ta in rows:
-            o.write("%s,%.1f,%.0f,%.0f,%.3f,%.0f,%.0f\n" % (k, fz, h, m, h / max(h + m, 1.0), ca, ta))
-    corr = [r for r in rows if "correlate_kernel<2, 16, 4>" in r[0]]
-    if corr:
-        k, fz, h, m, ca, ta = corr[0]
+        o.write("kernel,FETCH_SIZE_KiB,TCC_HIT_sum,TCC_MISS_sum,l2_hit_rate,TCP_TOTAL_CACHE_ACCESSES_sum,TCP_TOTAL_ACCESSES_sum,"
+                "SQ_INSTS_VALU,SQ_INSTS_LDS,SQ_LDS_IDX_ACTIVE,SQ_LDS_BANK_CONFLICT\n")
+        for k, fz, h, m, ca, ta, iv, il, la, lc in rows:
+            o.write("%s,%.1f,%.0f,%.0f,%.3f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f\n" % (k, fz, h, m, h / max(h + m, 1.0), ca, ta, iv, il, la, lc))
+    # the dominant kernel of the bench step: the region-staged correlate on batches (else the direct one)
+    dom = [r for r in rows if "correlate_region_kernel" in r[0]] or [r for r in rows if "correlate_kernel<2, 16, 4>" in r[0]]
+    if dom:
+        k, fz, h, m, ca, ta, iv, il, la, lc = dom[0]
         json.dump({"kernel": k, "batch": batch, "fetch_size_kib_per_launch": fz, "gfx950_wide_read_correction": 2.0,
                    "hbm_bytes_per_launch": fz * 1024 * 2.0, "l2_hit_rate": h / max(h + m, 1.0), "source": os.path.relpath(pmc_csv, REPO)},
                   open(os.path.join(prof, "traffic_correlate.json"), "w"), indent=1)
         dur = stats.get(k)
-        if dur and ca:
+        if dur and "region" in k and iv:
+            clk = dur * 1e-9 * CLOCK_HZ
+            json.dump({"kernel": k, "batch": batch, "kernel_us_under_rocprof": dur * 1e-3,
+                       "valu": {"counter": "SQ_INSTS_VALU", "per_launch": iv, "per_cu_clk": iv / (CU * clk), "peak_per_cu_clk": 1.0,
+                                "frac": iv / (CU * clk),
+                                "peak_source": "four 16-lane SIMDs per CU: one wave64 VALU instruction per clock per CU"},
+                       "lds": {"counter": "SQ_LDS_IDX_ACTIVE", "cycles_per_launch": la, "bank_conflict_cycles": lc,
+                               "frac": la / (CU * clk), "peak_source": "LDS busy cycles / (256 CUs x kernel clocks)"},
+                       "source": os.path.relpath(pmc_csv, REPO)},
+                      open(os.path.join(prof, "issue_correlate.json"), "w"), indent=1)
+        elif dur and ca:
             per_cu_clk = ca / (CU * dur * 1e-9 * CLOCK_HZ)
             json.dump({"kernel": k, "batch": batch, "counter": "TCP_TOTAL_CACHE_ACCESSES_sum", "per_launch": ca,
                        "kernel_us_under_rocprof": dur * 1e-3, "per_cu_clk": per_cu_clk,
@@ -81,8 +96,9 @@ def main():
                        "source": os.path.relpath(pmc_csv, REPO)},
                       open(os.path.join(prof, "l1_correlate.json"), "w"), indent=1)
     print(open(pmc_csv).read())
-    for n in ("traffic_correlate.json", "l1_correlate.json"):
-        print(n, open(os.path.join(prof, n)).read())
+    for n in ("traffic_correlate.json", "issue_correlate.json"):
+        if os.path.exists(os.path.join(prof, n)):
+            print(n, open(os.path.join(prof, n)).read())
 
 
 if __name__ == "__main__":

@@ -787,3 +787,43 @@ def test_merged_equal_offsets_are_exact():
     m.debug_option(13, 1)
     r = m.match_scan(nq, nb, False, False)
     assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]), o.sums(0)) and abs(r.response - ro["response"]) <= 1e-12
+
+
+def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
+    """Batches of 8+ items on lattices up to 26 x 32 gather their patches from LDS, region by region
+    (correlate_region_kernel + bin_kernel).  The integer sum volumes of every item must be those of the direct
+    correlate kernel (option 14 = 1) -- also through the region kernel's per-cell path (= 2, what an item with a
+    non-lattice hypothesis grid takes) and its "entry list does not fit" path (= 3) -- for the default lattice, a
+    lattice of one lane per row (nx = 13), ragged queries (1081 / 707 / 400 valid beams: two beam groups, a ragged
+    second group, one group) and ragged and reversed chains; and equal to the oracle's."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    cut = lambda s, n: PlainScan(s.ranges[:n], s.min_angle, s.angle_increment, s.min_range, 20.0, (3.0, 3.0, 0.0))
+    q707, q400 = cut(q, 707), cut(q, 400)
+    narrow = {"search_size": 0.24}  # 13 x 13 x 21: the second lane of every lattice row idles
+    chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:], nb[5:6]]  # (no empty chain: its response
+    # expansion would be the last call, and debug_sums reads the last call)
+    for cfg, queries in ((None, (q, q707, q400)), (narrow, (q,))):
+        for query in queries:
+            nquery = _mk_native(query)
+            vols = {}
+            for mode in (0, 1, 2, 3):
+                m = ScanMatcher(cfg)
+                m.debug_option(12, 1)  # keep the integer sums of batches
+                m.debug_option(14, mode)
+                per, best = m.match_scan_batch(nquery, chains, True, True)
+                dims = per[0].meta["coarse_dims"]
+                vols[mode] = ([m.debug_sums(0, item=i, dims=dims) for i in range(len(chains))], per, best)
+            for mode in (0, 2, 3):
+                for i in range(len(chains)):
+                    assert np.array_equal(vols[mode][0][i], vols[1][0][i]), (mode, i)
+                for a, b in zip(vols[mode][1], vols[1][1]):
+                    assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+                    assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+                assert vols[mode][2] == vols[1][2]
+            assert vols[0][0][0].any()
+            o = orc.Oracle(cfg, "karto")
+            o.match_scan(query, base, True, True)
+            assert np.array_equal(vols[0][0][0], o.sums(0))

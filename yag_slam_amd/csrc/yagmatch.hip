@@ -313,7 +313,7 @@ struct ym_matcher {
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
     int corr_dedup = 0;     // development / tests: 1 = always merge equal consecutive lookup offsets, 2 = never
-    int corr_region = 0;    // development / tests: 1 = never use the region-staged correlate, 2 = its per-cell path
+    int corr_region = 0;    // tests: 1 = never use the region-staged correlate, 2 = its per-cell path, 3 = its "list does not fit" path
     int corr_region_nw = 0; // development: waves (= angles) per region-correlate block
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)

@@ -55,7 +55,7 @@ struct RegionArgs {
     size_t partial_stride;
     int32_t nt_stride, dim_stride;
     int32_t nrx, nry, ng, nbins;
-    int32_t force_irregular; // development: take the per-cell path
+    int32_t force_irregular; // tests: 1 = take the per-cell path, 2 = bin_kernel reports that the padded list does not fit
     int32_t pad;
     unsigned long long *stamps;
 };
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
             all += wave_tot[w];
         }
         padded_total = all;
-        const bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride;
+        const bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride && a.force_irregular != 2;
         int run = base + incl - local;
         for (int j = 0; j < per; j++)
             if (first + j < a.nbins) {
@@ -278,7 +278,6 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
         for (int j = 0; j < 8; j++) acc[g][j] = 0u;
     YM_STAMP(a, 8);
     const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
-    const int dev_mode = a.force_irregular; // development (timing only): 3 = no gather, 4 = no staging
     if (regular) {
         const int k_lo = p * NW, k_hi = min(nt, k_lo + NW);
         const int nreg = a.nrx * a.nry;
@@ -371,7 +370,8 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
         if (nlist > 0) {
             segment(0, s0, s1, s2);
             entries_load(s0, s2);
-            if (dev_mode != 4) { stage_load(rlist[0]); stage_store(); }
+            stage_load(rlist[0]);
+            stage_store();
             elist[wave][lane] = ev;
         }
         __syncthreads();
@@ -382,18 +382,16 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
             if (has_next) {
                 segment(ri + 1, n0, n1, n2);
                 entries_load(n0, n2);
-                if (dev_mode != 4) stage_load(rlist[ri + 1]);
+                stage_load(rlist[ri + 1]);
             }
             YM_RG_PHASE(0);
-            if (dev_mode != 3) {
-                gather(acc[0], s0, s0, s1);
-                gather(acc[1], s0, s1, s2);
-            }
+            gather(acc[0], s0, s0, s1);
+            gather(acc[1], s0, s1, s2);
             YM_RG_PHASE(1);
             __syncthreads(); // every wave is done with region ri
             YM_RG_PHASE(2);
             if (has_next) {
-                if (dev_mode != 4) stage_store();
+                stage_store();
                 elist[wave][lane] = ev;
             }
             s0 = n0; s1 = n1; s2 = n2;
