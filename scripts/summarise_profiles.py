@@ -31,7 +31,7 @@ def kernel_means(tag, name):
 
 def main():
     tag, batch = sys.argv[1], int(sys.argv[2])
-    short = tag.replace("r02p", "r02_p")
+    short = tag[:3] + "_" + tag[3:] if len(tag) == 4 else tag
     prof = os.path.join(REPO, "profiles")
     for src, dst in (("stats", "bench_kernel_stats"), ("single", "single_match_kernel_stats"), ("stress", "stress_kernel_stats")):
         f = os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, src), "%s_kernel_stats.csv" % tag)
