@@ -524,7 +524,7 @@ def main():
         traffic = profile_json("traffic_correlate.json")
         issue = profile_json("issue_correlate.json")
         region = LB >= 8 and args.corr_region != 1
-        kernel = "ym::correlate_region_kernel<7>" if region else "ym::correlate_kernel<2, 16, 4>"
+        kernel = "ym::correlate_region_kernel<8>" if region else "ym::correlate_kernel<2, 16, 4>"
         if traffic and traffic.get("kernel") != kernel:
             traffic = None
         if issue and issue.get("kernel") != kernel:

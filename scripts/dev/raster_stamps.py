@@ -23,8 +23,6 @@ st = m.debug_stamps(False)
 t0 = min(v for v in st if v)
 names = {4: "raster start", 5: "raster bitmap done", 6: "raster row pass done", 7: "raster end", 8: "corr start", 9: "corr end",
          10: "score start", 11: "score end", 12: "fine start", 16: "final start", 19: "final end"}
-print("region kernel block 0 wave 0 (us): issue %.2f gather %.2f barrier1 %.2f store %.2f barrier2 %.2f regions %d" % tuple(
-    [st[20 + i] / 100.0 for i in range(5)] + [st[25]]))
 print("padded entries of item 0:", st[26])
 if len(sys.argv) > 2:
     m.debug_option(15, int(sys.argv[2]))

@@ -626,13 +626,16 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         const int half_w = (g.win_w + 1) / 2;
         P.rg_nrx = (half_w + YM_RG_W - 1) / YM_RG_W;
         P.rg_nry = (half_w + YM_RG_H - 1) / YM_RG_H;
-        P.rg_ng = (max_n + YM_RG_GROUP_BEAMS - 1) / YM_RG_GROUP_BEAMS;
-        P.rg_nbins = P.rg_nrx * P.rg_nry * lc.nt * P.rg_ng;
-        P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : (lc.nt % 7 == 0 || lc.nt > 48) ? 7 : 8;
+        // sets of 16-bit sums per (item, angle): room for the padding of the entry lists (an item that needs more is scored
+        // by the per-cell path)
+        P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
+        P.rg_nbins = P.rg_nrx * P.rg_nry * lc.nt;
+        // (measured, 21 angles: three blocks of 8 waves per CU beat blocks of 7 although the third block of an item idles 3 waves)
+        P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : 8;
         if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
         P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
         P.region = !yag && !staged && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 2 * YM_RG_G &&
-                   lc.ny <= 32 && P.rg_ng <= 2 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins <= YM_RG_MAX_BINS &&
+                   lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins <= YM_RG_MAX_BINS &&
                    P.rg_nrx * P.rg_nry <= YM_RG_MAX_REGIONS;
         if (getenv("YM_DEBUG_PLAN"))
             fprintf(stderr, "[ym] B %d region %d nbins %d nrx %d nry %d ng %d nw %d max_n %d nx %d ny %d nt %d dedup %d\n", B, (int)P.region, P.rg_nbins,

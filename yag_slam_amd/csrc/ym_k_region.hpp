@@ -35,7 +35,7 @@ namespace ym {
 #define YM_RG_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(half_pitch) + 256)
 #define YM_RG_MAX_BINS 8192
 #define YM_RG_MAX_ENTRIES 28672
-#define YM_RG_GROUP_BEAMS 640                 // 16-bit sums hold 640 beams of 100
+#define YM_RG_FLUSH 652                       // patches per set of 16-bit sums: 652 x 100 < 65536 (a multiple of four)
 #define YM_BIN_THREADS 1024
 
 struct RegionArgs {
@@ -49,9 +49,9 @@ struct RegionArgs {
     const YmItemState *states;
     uint16_t *entries;      // [B][entries_stride]: class | row in region | byte in region (2 + LOG_H + LOG_W bits), sorted by bin
     size_t entries_stride;
-    int32_t *starts;        // [B][starts_stride]: first entry of bin ((region * nt + angle) * ng + group); [nbins] = total
+    int32_t *starts;        // [B][starts_stride]: first entry of bin (region * nt + angle); [nbins] = total, or -1: no list
     size_t starts_stride;
-    uint16_t *partial;      // [B][ng][nt][64 lanes][16]
+    uint16_t *partial;      // [B][ng][nt][64 lanes][16]: ng sets of 16-bit sums, each of at most YM_RG_FLUSH patches
     size_t partial_stride;
     int32_t nt_stride, dim_stride;
     int32_t nrx, nry, ng, nbins;
@@ -68,7 +68,7 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
     const int xc = X >> 1, yc = Y >> 1;
     const int rx = xc >> YM_RG_LOG_W, ry = yc >> YM_RG_LOG_H;
     if (X < 0 || Y < 0 || rx >= a.nrx || ry >= a.nry) return false;
-    bin = ((ry * a.nrx + rx) * a.lat.nt + k) * a.ng + i / YM_RG_GROUP_BEAMS;
+    bin = (ry * a.nrx + rx) * a.lat.nt + k;
     entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS + (yc & (YM_RG_H - 1)) * YM_RG_PITCH + (xc & (YM_RG_W - 1)));
     return true;
 }
@@ -78,13 +78,14 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // Inside a bin the entries are sorted by their byte misalignment (entry & 3; class images and rows are multiples of 4
 // bytes), every run of equal misalignment is padded to an even length and the bin to a multiple of four with entries
 // that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
-// never meets a ragged group.  An item whose padded list would not fit gets starts[nbins] = -1 and is scored by the
-// per-cell path of correlate_region_kernel.
+// never meets a ragged group.  An item whose padded list would not fit -- the buffers, or one angle's share the ng sets of
+// 16-bit sums the gather may fill -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
 __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
     __shared__ unsigned cnt[YM_RG_MAX_BINS][2]; // per bin four 16-bit counters (one per misalignment), later the runs' first positions
     __shared__ unsigned short ent[YM_RG_MAX_ENTRIES];
     __shared__ int wave_tot[YM_BIN_THREADS / 64];
+    __shared__ int angle_tot[YM_MAX_COARSE_NT]; // padded entries per coarse angle
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const YmItemState &st = a.states[b];
     const int nq = st.nq, nt = a.lat.nt;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     const double2 *trig = a.ctrig + (size_t)b * a.nt_stride;
     int32_t *starts = a.starts + (size_t)b * a.starts_stride;
     for (int i = tid; i < a.nbins * 2; i += YM_BIN_THREADS) (&cnt[0][0])[i] = 0u;
+    if (tid < YM_MAX_COARSE_NT) angle_tot[tid] = 0;
     __syncthreads();
     // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
     // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
@@ -127,7 +129,9 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
             if (first + j < a.nbins) {
                 const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
                 const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
-                local += (((c[0] + 1) & ~1) + ((c[1] + 1) & ~1) + ((c[2] + 1) & ~1) + ((c[3] + 1) & ~1) + 3) & ~3;
+                const int padded = (((c[0] + 1) & ~1) + ((c[1] + 1) & ~1) + ((c[2] + 1) & ~1) + ((c[3] + 1) & ~1) + 3) & ~3;
+                local += padded;
+                if (padded) atomicAdd(&angle_tot[(first + j) % nt], padded);
             }
         int incl = local;
 #pragma unroll
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
             all += wave_tot[w];
         }
         padded_total = all;
-        const bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride && a.force_irregular != 2;
+        bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride && a.force_irregular != 2;
+        for (int k = 0; k < nt; k++) fits = fits && angle_tot[k] <= a.ng * YM_RG_FLUSH;
         int run = base + incl - local;
         for (int j = 0; j < per; j++)
             if (first + j < a.nbins) {
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
     constexpr int TASKS = 4 * YM_RG_ROWS * YM_RG_SEGS, PER = (TASKS + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned char region[YM_RG_LDS_BYTES]; // four class images + the zero patch
     __shared__ int rlist[YM_RG_MAX_REGIONS];
-    __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][3]; // per wave and listed region: first entry of beam group 0, of group 1, end
+    __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][2]; // per wave and listed region: its first entry and the end
     __shared__ uint2 elist[NW][64];                   // per wave: its first 256 entries of the region being gathered
     __shared__ int rcount;
     int p;
@@ -271,11 +276,19 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
     // idle lanes read what lane (row 0, same half) reads: the same address is a broadcast, any other address could share a
     // bank with a working lane
     const uint32_t lane_off = lds0 + (uint32_t)((job ? row : 0) * YM_RG_PITCH + (half * YM_RG_G < nx ? half * YM_RG_G : 0));
-    uint32_t acc[2][8];
+    uint32_t acc[8];
 #pragma unroll
-    for (int g = 0; g < 2; g++)
+    for (int j = 0; j < 8; j++) acc[j] = 0u;
+    // the 16-bit sums hold YM_RG_FLUSH patches: the wave counts what it has added and, when a set is full, writes it out as
+    // partial set number `flushed` and starts the next (score_kernel adds the sets)
+    int in_set = 0, flushed = 0;
+    auto flush = [&]() {
+        if (flushed < ng) store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)flushed * nt + k) * 64 + lane) * 16, acc);
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[g][j] = 0u;
+        for (int j = 0; j < 8; j++) acc[j] = 0u;
+        flushed++;
+        in_set = 0;
+    };
     YM_STAMP(a, 8);
     const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
     if (regular) {
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
             int n = 0;
             for (int R0 = 0; R0 < nreg; R0 += 64) {
                 const int R = R0 + lane;
-                const bool has = R < nreg && starts[((size_t)R * nt + k_lo) * ng] != starts[((size_t)R * nt + k_hi) * ng];
+                const bool has = R < nreg && starts[(size_t)R * nt + k_lo] != starts[(size_t)R * nt + k_hi];
                 const unsigned long long mask = __ballot(has);
                 if (has) rlist[n + __popcll(mask & ((1ull << lane) - 1ull))] = R;
                 n += __popcll(mask);
@@ -298,8 +311,8 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
         const int nlist = rcount;
         if (kvalid)
             for (int i = lane; i < nlist; i += 64) {
-                const int32_t *srow = starts + ((size_t)rlist[i] * nt + k) * ng;
-                seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1]; seginfo[wave][i][2] = (unsigned short)srow[ng];
+                const int32_t *srow = starts + (size_t)rlist[i] * nt + k;
+                seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1];
             }
         __syncthreads();
         // copy task t = (class, row, 16-byte block): thread tid takes t = tid, tid + NT, ... (the last ones take task TASKS - 1
@@ -331,13 +344,12 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
                 d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
             }
         };
-        // this wave's entries of a region: [s0, s1) beam group 0, [s1, s2) beam group 1 (multiples of four entries)
-        auto segment = [&](int ri, int &t0, int &t1, int &t2) {
-            t0 = t1 = t2 = 0;
+        // this wave's entries of a region: [t0, t2) (a multiple of four entries)
+        auto segment = [&](int ri, int &t0, int &t2) {
+            t0 = t2 = 0;
             if (kvalid) {
                 t0 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][0]);
-                t1 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][1]);
-                t2 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][2]);
+                t2 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][1]);
             }
         };
         // The first 256 entries of a wave's segment travel like the region itself: loaded into a register while the previous
@@ -349,26 +361,29 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
             ev = make_uint2(0u, 0u);
             if (t0 + 4 * lane < t2) ev = entries4[(t0 >> 2) + lane];
         };
-        auto gather = [&](uint32_t (&sums)[8], int base, int lo, int hi) { // entries [lo, hi) of the segment that starts at base
-            const int lds_hi = min(hi, base + 256);
+        auto gather = [&](int lo, int hi) { // entries [lo, hi)
+            const int lds_hi = min(hi, lo + 256);
             if (lo < lds_hi) {
-                const uint2 *el = elist[wave] + ((lo - base) >> 2);
+                const uint2 *el = elist[wave];
                 const int n4 = (lds_hi - lo) >> 2;
                 uint2 ee = el[0];
                 for (int c = 0; c < n4; c++) {
                     const uint2 nx = el[min(c + 1, n4 - 1)];
-                    rg_gather4(sums, lane_off, ee);
+                    rg_gather4(acc, lane_off, ee);
                     ee = nx;
+                    in_set += 4;
+                    if (in_set == YM_RG_FLUSH) flush();
                 }
             }
-            for (int c = max(lo, lds_hi); c < hi; c += 4) rg_gather4(sums, lane_off, entries4[c >> 2]); // (a very long segment)
+            for (int c = lds_hi; c < hi; c += 4) { // (a very long segment)
+                rg_gather4(acc, lane_off, entries4[c >> 2]);
+                in_set += 4;
+                if (in_set == YM_RG_FLUSH) flush();
+            }
         };
-        const bool timing = a.stamps && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0;
-        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = timing ? wall_clock64() : 0ull;
-#define YM_RG_PHASE(i) do { if (timing) { const unsigned long long tn_ = wall_clock64(); tph[i] += tn_ - tl; tl = tn_; } } while (0)
-        int s0 = 0, s1 = 0, s2 = 0;
+        int s0 = 0, s2 = 0;
         if (nlist > 0) {
-            segment(0, s0, s1, s2);
+            segment(0, s0, s2);
             entries_load(s0, s2);
             stage_load(rlist[0]);
             stage_store();
@@ -378,30 +393,20 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
         for (int ri = 0; ri < nlist; ri++) {
             // two-stage pipeline: the global loads of the next region are in flight (registers) while this one is gathered
             const bool has_next = ri + 1 < nlist;
-            int n0 = 0, n1 = 0, n2 = 0;
+            int n0 = 0, n2 = 0;
             if (has_next) {
-                segment(ri + 1, n0, n1, n2);
+                segment(ri + 1, n0, n2);
                 entries_load(n0, n2);
                 stage_load(rlist[ri + 1]);
             }
-            YM_RG_PHASE(0);
-            gather(acc[0], s0, s0, s1);
-            gather(acc[1], s0, s1, s2);
-            YM_RG_PHASE(1);
+            gather(s0, s2);
             __syncthreads(); // every wave is done with region ri
-            YM_RG_PHASE(2);
             if (has_next) {
                 stage_store();
                 elist[wave][lane] = ev;
             }
-            s0 = n0; s1 = n1; s2 = n2;
-            YM_RG_PHASE(3);
+            s0 = n0; s2 = n2;
             __syncthreads();
-            YM_RG_PHASE(4);
-        }
-        if (timing) {
-            for (int i = 0; i < 5; i++) a.stamps[20 + i] = tph[i];
-            a.stamps[25] = (unsigned long long)nlist;
         }
     } else if (kvalid && job) {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path over the window
@@ -412,29 +417,25 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
         const int nq = st.nq;
-        for (int j = 0; j < YM_RG_G; j++) {
-            const int ix = half * YM_RG_G + j;
-            if (ix >= nx) break;
-            const int base = cy[row] * a.g.pitch + cx[ix];
-            for (int g = 0; g < ng; g++) {
+        for (int g = 0; g < ng; g++) { // set g = the beams [g * FLUSH, (g + 1) * FLUSH)
+            for (int j = 0; j < YM_RG_G; j++) {
+                const int ix = half * YM_RG_G + j;
+                if (ix >= nx) break;
+                const int base = cy[row] * a.g.pitch + cx[ix];
                 unsigned sum = 0;
-                const int i1 = min(nq, (g + 1) * YM_RG_GROUP_BEAMS);
-                for (int i = g * YM_RG_GROUP_BEAMS; i < i1; i++) {
+                const int i1 = min(nq, (g + 1) * YM_RG_FLUSH);
+                for (int i = g * YM_RG_FLUSH; i < i1; i++) {
                     const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, a.g.pitch));
                     sum += idx < limit ? grid[idx] : 0u;
                 }
-                acc[g][2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
+                acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
             }
+            flush();
         }
     }
     YM_STAMP(a, 9);
     if (!kvalid) return;
-#pragma unroll
-    for (int g = 0; g < 2; g++) {
-        if (g >= ng) break;
-        uint16_t *out = a.partial + (size_t)b * a.partial_stride + (((size_t)g * nt + k) * 64 + lane) * 16;
-        store_partial16(out, acc[g]);
-    }
+    while (flushed < ng) flush(); // the set being filled, then empty ones
 }
 
 } // namespace ym
