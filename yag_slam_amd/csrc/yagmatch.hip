@@ -315,6 +315,7 @@ struct ym_matcher {
     int corr_dedup = 0;     // development / tests: 1 = always merge equal consecutive lookup offsets, 2 = never
     int corr_region = 0;    // tests: 1 = never use the region-staged correlate, 2 = its per-cell path, 3 = its "list does not fit" path
     int corr_region_nw = 0; // development: waves (= angles) per region-correlate block
+    size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
@@ -642,8 +643,9 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
                     P.rg_nrx, P.rg_nry, P.rg_ng, P.rg_nw, max_n, lc.nx, lc.ny, lc.nt, P.dedup);
         if (P.region) {
             P.n_groups = P.rg_ng;
-            // (+ the padding of every bin that holds work; an item that still does not fit takes the per-cell path)
-            P.rg_entries_stride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)lc.nt * max_n + 7 * (size_t)P.rg_nbins + 63) / 64 * 64);
+            // (+ the padding of the bins that hold work; an item that still does not fit takes the per-cell path)
+            // 10 % over the pairs themselves (measured on the bench scans: 5 %)
+            P.rg_entries_stride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)lc.nt * max_n * 11 / 10 + 63) / 64 * 64);
             P.rg_starts_stride = ((size_t)P.rg_nbins + 1 + 15) / 16 * 16;
         }
     }
@@ -1088,7 +1090,12 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
         r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
         r.force_irregular = m->corr_region >= 2 ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
-        hipLaunchKernelGGL(ym::bin_kernel, dim3(P.B), dim3(YM_BIN_THREADS), 0, st, r);
+        const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride);
+        if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+            m->bin_lds_limit = bin_lds;
+        }
+        hipLaunchKernelGGL(ym::bin_kernel, dim3(P.B), dim3(YM_BIN_THREADS), bin_lds, st, r);
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts, P.B);
         switch (P.rg_nw) {

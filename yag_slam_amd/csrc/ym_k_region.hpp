@@ -37,6 +37,7 @@ namespace ym {
 #define YM_RG_MAX_ENTRIES 28672
 #define YM_RG_FLUSH 652                       // patches per set of 16-bit sums: 652 x 100 < 65536 (a multiple of four)
 #define YM_BIN_THREADS 1024
+#define YM_BIN_LDS_BYTES(nbins, entries) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT) * 4 + (size_t)(nbins) * 8 + (size_t)(entries) * 2)
 
 struct RegionArgs {
     YmGeom g;
@@ -82,10 +83,13 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // 16-bit sums the gather may fill -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
 __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
-    __shared__ unsigned cnt[YM_RG_MAX_BINS][2]; // per bin four 16-bit counters (one per misalignment), later the runs' first positions
-    __shared__ unsigned short ent[YM_RG_MAX_ENTRIES];
-    __shared__ int wave_tot[YM_BIN_THREADS / 64];
-    __shared__ int angle_tot[YM_MAX_COARSE_NT]; // padded entries per coarse angle
+    // dynamic LDS (YM_BIN_LDS_BYTES: sized by the host so that two blocks share a CU on the usual lattice):
+    extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
+    int *wave_tot = reinterpret_cast<int *>(bin_smem);                                   // [YM_BIN_THREADS / 64]
+    int *angle_tot = wave_tot + YM_BIN_THREADS / 64;                                     // [YM_MAX_COARSE_NT] padded entries per coarse angle
+    unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(angle_tot + YM_MAX_COARSE_NT); // [nbins] four 16-bit counters (one per
+                                                                                         // misalignment), later the runs' first positions
+    unsigned short *ent = reinterpret_cast<unsigned short *>(cnt + a.nbins);             // [entries_stride]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const YmItemState &st = a.states[b];
     const int nq = st.nq, nt = a.lat.nt;
