@@ -10,11 +10,11 @@
 // in the image of one (column parity, row parity) class of window cells, and the 22 701 patches of an item
 // (1081 beams x 21 angles) lie along the walls.  So
 //   bin_kernel            sorts the (beam, angle) pairs of an item by the 64 x 64-byte REGION of class space their patch
-//                         starts in (key: region, angle, beam group), 16-bit entries;
+//                         starts in (key: region, angle), 16-bit entries;
 //   correlate_region_kernel  walks the regions that hold work: copies the region (+ the 26-byte patch margin) of all four
-//                         classes into LDS once -- 36 KB serve ~600 patches of 676 bytes each -- and every wave, which
+//                         classes into LDS once -- 36 KB serve ~800 patches of 676 bytes each -- and every wave, which
 //                         owns one angle, gathers its patches from there into packed 16-bit sums kept in registers.
-// The partial sums leave the kernel once per (angle, beam group), in lane order (score_kernel's layout 1).
+// The sums leave the kernel every YM_RG_FLUSH patches of a wave, in lane order (score_kernel's layout 1).
 #pragma once
 
 namespace ym {
