@@ -54,7 +54,6 @@ def parse_args(argv=None):
     ap.add_argument("--corr-region", type=int, default=0, help="development: 1 = direct correlate on batches too")
     ap.add_argument("--corr-region-nw", type=int, default=0, help="development: waves per region-correlate block")
     ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
-    ap.add_argument("--correlate-variant", type=int, default=-1, help="development: force a coarse correlate kernel form")
     return ap.parse_args(argv)
 
 
@@ -378,8 +377,6 @@ def main():
     m = ScanMatcher(None, device=local_rank)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
-    if args.correlate_variant >= 0:
-        m.debug_option(0, args.correlate_variant)
     if args.corr_u > 0:
         m.debug_option(3, args.corr_u)
     if args.corr_chunks:

@@ -227,7 +227,7 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
  * out[(slot*max_n + i)*2 + {0,1}] = wx, wy  or (INT32_MIN, INT32_MIN) for filtered points */
 int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int32_t *max_n);
 
-/* development aid.  option 0: coarse correlate kernel form (0 = global loads, default; 1 = experimental LDS staging);
+/* development aid.  (option 0 no longer exists.)
  * 2: rasterise every tile of the window; 3: beams in flight per lane in the correlate kernel (16 / 32);
  * 4: extra LDS bytes per correlate block; 5: beam chunks per angle; 6: finish stage (0 = by batch size,
  * 1 = fine + final kernels, 2 = one-block finish kernel); 7: point cache of resident base scans (0 = on, 1 = off,
@@ -235,7 +235,9 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * always through the global-memory kernel; 11: threads per finish block (256 / 1024, 0 = by batch size);
  * 12: keep the coarse integer sums of batches of 8 or more items for ym_debug_sums (single matches always do);
  * 13: merging of consecutive beams with the same lookup offset in the correlate kernel (0 = by grid coarseness, 1 = always,
- * 2 = never). */
+ * 2 = never); 14: coarse correlate of batches (0 = region-staged kernel where the lattice allows it, 1 = always the direct
+ * kernel, 2 = the region kernel's per-cell path, 3 = its "entry list does not fit" path); 15: waves per region-correlate
+ * block. */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.

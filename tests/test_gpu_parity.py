@@ -321,25 +321,21 @@ def test_stress_config_full_lattice():
     assert r.meta["coarse_dims"] == (201, 201, 46) and r.meta["hypotheses"] == 1858545
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-def test_lds_staged_correlate_is_bit_exact(variant):
-    # both forms of the coarse correlate (0 = global loads, 1 = experimental double-buffered LDS staging)
-    # must produce the same integer sums as the oracle
+def test_direct_correlate_sums_are_the_oracles():
+    # the direct (global-load) coarse correlate of a single match: the same integer sums as the oracle; and a batch of
+    # a few chains (longer beam chunks per wave) against single calls
     from oracle import oracle as orc
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()
     o = orc.Oracle(None, "karto")
     ro = o.match_scan(q, base, True, True)
     m = ScanMatcher()
-    m.debug_option(0, variant)
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     r = m.match_scan(nq, nb, True, True)
     assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]), o.sums(0))
     assert abs(r.response - ro["response"]) <= 1e-12
-    # multi-sub-chunk path (batch -> longer beam chunks per wave)
     per, best = m.match_scan_batch(nq, [nb[:5], nb[3:], nb], True, True)
     m2 = ScanMatcher()
-    m2.debug_option(0, 0)
     for ch, p in zip([nb[:5], nb[3:], nb], per):
         s = m2.match_scan(nq, ch, True, True)
         assert s.response == p.response and s.covariance == p.covariance

@@ -319,7 +319,6 @@ struct ym_matcher {
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
-    int use_lds_correlate = 0; // 0 = global-load kernel (default), 1 = experimental LDS-staged kernel
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
     Slot slots[kAsyncSlots + 1]; // last one serves the synchronous entry points
@@ -590,8 +589,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.ktiles = lc.nt;
     // a block = 4 waves = jw job-waves x cw chunk-waves: lattices with one (two) waves of lane jobs put four (two)
     // consecutive beam chunks into one block and add them up before the partial sum is written
-    const bool staged = P.sx == 2 && m->use_lds_correlate >= 1 && njobs <= 128;
-    P.cw = staged ? 1 : (m->corr_cw > 0 ? m->corr_cw : njobs <= 64 ? 4 : njobs <= 128 ? 2 : 1);
+    P.cw = m->corr_cw > 0 ? m->corr_cw : njobs <= 64 ? 4 : njobs <= 128 ? 2 : 1;
     P.job_blocks = (njobs + (4 / P.cw) * 64 - 1) / ((4 / P.cw) * 64);
     // split the beams so that roughly >= 2048 waves are in flight, chunks of 32..512 beams; a small lattice (one
     // working wave per block) does best with blocks of 64 beams even when the batch alone fills the chip
@@ -618,7 +616,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     {
         const double spacing = call.scans[call.items[0].query].beam_spacing;
         const bool likely = spacing > 0 && spacing < 0.6 * g.res;
-        P.dedup = (P.sx == 2 && chunk == 64 && !staged && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
+        P.dedup = (P.sx == 2 && chunk == 64 && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
     }
 
     // Batches on lattices of at most 26 x 32 (a lattice row = two lanes of 13 hypotheses): the patches are gathered from
@@ -635,7 +633,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : 8;
         if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
         P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
-        P.region = !yag && !staged && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 2 * YM_RG_G &&
+        P.region = !yag && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 2 * YM_RG_G &&
                    lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins <= YM_RG_MAX_BINS &&
                    P.rg_nrx * P.rg_nry <= YM_RG_MAX_REGIONS;
         if (getenv("YM_DEBUG_PLAN"))
@@ -1113,11 +1111,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     if ((rc = prof_begin(m, 0, &ev_k))) return rc;
     const dim3 grid_dim(P.job_blocks, a.nk * P.n_groups, P.B);
     const size_t pad_lds = (size_t)m->corr_pad_lds;
-    if (P.sx == 2 && m->use_lds_correlate >= 1 && P.njobs <= 128) {
-        a.tpb = m->use_lds_correlate; // development: 2 = skip the groups that do not fit LDS (timing only)
-        hipLaunchKernelGGL(ym::correlate_staged_kernel, dim3((P.njobs + 63) / 64, a.nk * P.n_chunks, P.B), dim3(256), 0, st, a);
-    }
-    else {
+    {
 #define YM_CORR_LAUNCH(SX, U, CW) hipLaunchKernelGGL((ym::correlate_kernel<SX, U, CW>), grid_dim, dim3(YM_CORR_THREADS), pad_lds, st, a)
 #define YM_CORR_BY_CW(SX, U)                                  \
     do {                                                      \
@@ -2133,7 +2127,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
 
 int ym_debug_option(ym_matcher *m, int option, int value) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
-    if (option == 0) m->use_lds_correlate = value;
+    if (option == 0) return set_err(YM_ERR_INVALID, "debug option 0 (an experimental correlate form) no longer exists");
     else if (option == 2) m->full_raster = value;
     else if (option == 3) m->corr_u = value;
     else if (option == 4) m->corr_pad_lds = value;
