@@ -24,6 +24,7 @@ t0 = min(v for v in st if v)
 names = {4: "raster start", 5: "raster bitmap done", 6: "raster row pass done", 7: "raster end", 8: "corr start", 9: "corr end",
          10: "score start", 11: "score end", 12: "fine start", 16: "final start", 19: "final end"}
 print("padded entries of item 0:", st[26])
+print("raster: listed tiles %d, with a cell in reach %d, hit chunks per tile %.1f (batch %d)" % (st[27], st[28], st[29] / max(st[27], 1), B))
 if len(sys.argv) > 2:
     m.debug_option(15, int(sys.argv[2]))
 for i, v in enumerate(st):

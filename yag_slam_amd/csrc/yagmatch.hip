@@ -661,7 +661,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->qlocal.ensure((size_t)B * max_n))) return rc;
     if ((rc = m->qnp.ensure(B))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
-    if ((rc = m->bbox.ensure((size_t)B * max_base * ((max_n + 63) / 64)))) return rc;
+    if ((rc = m->bbox.ensure((size_t)B * max_base * YM_N_BOXES(max_n)))) return rc;
     if ((rc = m->grid.ensure((size_t)B * P.grid_stride))) return rc;
     if ((rc = m->planes.ensure((size_t)B * P.grid_stride + YM_RG_PLANES_SLACK(g.pitch / 2)))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * P.nt_stride))) return rc;

@@ -23,7 +23,7 @@ struct PrepareArgs {
     double2 *qlocal;         // [query slots][max_n]
     int32_t *qnp;            // [query slots] number of point readings of the slot's query
     int2 *cells;             // [B][max_base][max_n]  window cell of every base point, NONE when filtered
-    int4 *bbox;              // [B][max_base][ceil(max_n/64)] window bounding box of 64 consecutive cells
+    int4 *bbox;              // [B][max_base][YM_N_BOXES(max_n)] window bounding box of YM_BOX_CELLS consecutive cells
     double2 *ctrig;          // [B][nt_stride] (cos, sin) of every coarse angle
     int32_t *hypcell;        // [B][2][dim_stride]
     double *probs;           // [B][ny*nx] cleared here, filled by the score stage
@@ -230,11 +230,11 @@ template <int NT, typename PT, typename GOV>
 __device__ __forceinline__ void prepare_cells(const PrepareArgs &a, int b, int slot, int np, bool yag, double vpx, double vpy,
                                               double off_x, double off_y, PT pt_of, GOV gov_of) {
     const int tid = threadIdx.x;
-    const int n_cchunks = (a.max_n + 63) / 64;
+    const int n_cchunks = YM_N_BOXES(a.max_n);
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
     int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
-    for (int i0 = 0; i0 < n_cchunks * 64; i0 += NT) {
-        const int i = i0 + tid; // a wave covers one 64-cell chunk
+    for (int i0 = 0; i0 < n_cchunks * YM_BOX_CELLS; i0 += NT) {
+        const int i = i0 + tid; // half a wave covers one chunk of YM_BOX_CELLS cells
         int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
         if (i < np) {
             bool keep = false;
@@ -266,16 +266,16 @@ __device__ __forceinline__ void prepare_cells(const PrepareArgs &a, int b, int s
         // bounding box of the chunk's rasterised cells: the raster kernel reads a chunk only when
         // this box touches its tile
         const bool has = c.x != YM_CELL_NONE;
-        const int x0 = wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = wave_reduce(has ? c.y : INT32_MAX, OpMinI());
-        const int x1 = wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
-        if ((tid & 63) == 0 && i / 64 < n_cchunks) bbox[i / 64] = make_int4(x0, y0, x1, y1);
+        const int x0 = half_wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = half_wave_reduce(has ? c.y : INT32_MAX, OpMinI());
+        const int x1 = half_wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = half_wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+        if ((tid & (YM_BOX_CELLS - 1)) == 0 && i / YM_BOX_CELLS < n_cchunks) bbox[i / YM_BOX_CELLS] = make_int4(x0, y0, x1, y1);
     }
 }
 
 // an unused chain slot of a ragged batch: no points (select_kernel walks every slot's cells), empty boxes
 template <int NT>
 __device__ __forceinline__ void clear_slot(const PrepareArgs &a, int b, int slot) {
-    const int n_cchunks = (a.max_n + 63) / 64;
+    const int n_cchunks = YM_N_BOXES(a.max_n);
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
     int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
     for (int i = threadIdx.x; i < a.max_n; i += NT) cells[i] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
@@ -295,10 +295,10 @@ __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, in
     const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
     const double vpx = qr.pose[0], vpy = qr.pose[1];
     const int tid = threadIdx.x;
-    const int n_cchunks = (a.max_n + 63) / 64;
+    const int n_cchunks = YM_N_BOXES(a.max_n);
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
     int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
-    for (int i0 = 0; i0 < n_cchunks * 64; i0 += Q * NT) {
+    for (int i0 = 0; i0 < n_cchunks * YM_BOX_CELLS; i0 += Q * NT) {
         int2 g[Q];
         double2 f[Q], t[Q], p[Q];
 #pragma unroll
@@ -317,7 +317,7 @@ __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, in
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int i = i0 + q * NT + tid; // a wave covers one 64-cell chunk
-            if (i0 + q * NT >= n_cchunks * 64) break; // block-uniform
+            if (i0 + q * NT >= n_cchunks * YM_BOX_CELLS) break; // block-uniform
             int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
             if (i < np && g[q].x >= 0 && g[q].y < np) {
                 const double fx = f[q].x, fy = f[q].y, cx = t[q].x, cy = t[q].y;
@@ -339,9 +339,9 @@ __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, in
             }
             if (i < a.max_n) cells[i] = c;
             const bool has = c.x != YM_CELL_NONE;
-            const int x0 = wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = wave_reduce(has ? c.y : INT32_MAX, OpMinI());
-            const int x1 = wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
-            if ((tid & 63) == 0 && i / 64 < n_cchunks) bbox[i / 64] = make_int4(x0, y0, x1, y1);
+            const int x0 = half_wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = half_wave_reduce(has ? c.y : INT32_MAX, OpMinI());
+            const int x1 = half_wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = half_wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+            if ((tid & (YM_BOX_CELLS - 1)) == 0 && i / YM_BOX_CELLS < n_cchunks) bbox[i / YM_BOX_CELLS] = make_int4(x0, y0, x1, y1);
         }
     }
 }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void cells_kernel(PrepareArgs a) {
 // writes the XCD's L2 back: measured 98 -> 771 us for the prepare kernel.  A kernel boundary is cheaper.)
 #define YM_TILES_THREADS 256
 struct TilesArgs {
-    const int4 *bbox;        // [B][max_base][ceil(max_n/64)]
+    const int4 *bbox;        // [B][max_base][YM_N_BOXES(max_n)]
     uint16_t *tile_list;     // [B][tile_cap] tile index (tiy * tiles_x + tix), | 0x8000 = only needs clearing
     int32_t *tile_count;     // [B]
     const uint8_t *tile_zero;// [B][tiles_y][tiles_x] 1 = the tile's memory is known to hold zeros
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
     __syncthreads();
     const int h = a.half_kernel;
     const int lx0 = a.launch[0], ly0 = a.launch[1], lx1 = a.launch[2], ly1 = a.launch[3];
-    const int n_boxes = a.max_base * ((a.max_n + 63) / 64);
+    const int n_boxes = a.max_base * YM_N_BOXES(a.max_n);
     const int4 *bbox = a.bbox + (size_t)b * n_boxes;
     for (int c = tid; c < n_boxes; c += NT) {
         const int4 bb = bbox[c];

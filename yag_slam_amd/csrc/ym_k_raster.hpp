@@ -7,7 +7,7 @@ namespace ym {
 // ================================================================== K2 raster
 struct RasterArgs {
     const int2 *cells;
-    const int4 *bbox;     // [B][max_base][ceil(max_n/64)]
+    const int4 *bbox;     // [B][max_base][YM_N_BOXES(max_n)]
     const YmItemState *states;
     YmGeom g;
     uint8_t *grid;        // [B][win_w rows][pitch]
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     const int tiy = tile / a.tiles_x, tix = tile - tiy * a.tiles_x;
     const int tx0 = tix * TW, ty0 = tiy * TH;
     YM_STAMP(a, 4);
-    // candidate chunks: 64 consecutive cells of one base scan whose bounding box touches tile + halo
-    const int n_cchunks = (a.max_n + 63) / 64;
+    // candidate chunks: YM_BOX_CELLS consecutive cells of one base scan whose bounding box touches tile + halo
+    const int n_cchunks = YM_N_BOXES(a.max_n);
     const int n_boxes = a.max_base * n_cchunks;
     const int4 *bbox = a.bbox + (size_t)b * n_boxes;
     const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         for (int y = y0; y < TH; y += NT / LPR) store8(y, 0u, 0u);
     };
     uint8_t *tz = a.tile_zero + ((size_t)b * a.tiles_y + tiy) * a.tiles_x + tix;
-    __shared__ int s_hits[256];
+    __shared__ int s_hits[256], s_left[256];
     __shared__ int s_nhits;
     if (entry & 0x8000u) { // no chunk reaches this tile, but its memory still holds an earlier call's bytes
         zero_tile();
@@ -119,11 +119,15 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         const int4 bb = bbox[c];
         if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
             const int at = atomicAdd(&s_nhits, 1);
-            if (at < 256) s_hits[at] = c;
+            if (at < 256) { // the chunk's first cell and how many it holds (the division once per hit, not per cell)
+                const int slot = c / n_cchunks, first = (c - slot * n_cchunks) * YM_BOX_CELLS;
+                s_hits[at] = slot * a.max_n + first;
+                s_left[at] = a.max_n - first;
+            }
         }
     }
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
-    for (int i = tid; i <= 2 * h * h; i += NT) lut[i] = a.lut[i];
+    for (int i = tid; i <= 2 * h * h + 1; i += NT) lut[i] = i <= 2 * h * h ? a.lut[i] : (unsigned char)0;
     __syncthreads();
     const int nhits = s_nhits;
     const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
@@ -131,18 +135,14 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     int any = 0;
     if (nhits <= 256) {
         // work item = (hit chunk, cell of the chunk); 4 items per thread in flight
-        const int nwork = nhits * 64;
+        const int nwork = nhits * YM_BOX_CELLS;
         for (int w0 = 0; w0 < nwork; w0 += 4 * NT) {
             int2 cc[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int w = w0 + u * NT + tid;
                 cc[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
-                if (w < nwork) {
-                    const int chunk = s_hits[w >> 6];
-                    const int slot = chunk / n_cchunks, i = (chunk - slot * n_cchunks) * 64 + (w & 63);
-                    if (i < a.max_n) cc[u] = cells[(size_t)slot * a.max_n + i];
-                }
+                if (w < nwork && (w % YM_BOX_CELLS) < s_left[w / YM_BOX_CELLS]) cc[u] = cells[s_hits[w / YM_BOX_CELLS] + (w % YM_BOX_CELLS)];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                 mask &= mask - 1;
                 const int chunk = c0 + (tid & ~63) + bit; // wave-uniform
                 const int slot = chunk / n_cchunks, ci = chunk - slot * n_cchunks;
-                const int i = ci * 64 + (tid & 63);
-                if (i < a.max_n) {
+                const int i = ci * YM_BOX_CELLS + (tid & 63);
+                if ((tid & 63) < YM_BOX_CELLS && i < a.max_n) {
                     const int2 c2 = cells[(size_t)slot * a.max_n + i];
                     const int lx = c2.x - lo_x, ly = c2.y - lo_y;
                     if (c2.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
@@ -182,6 +182,11 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     }
     any = __syncthreads_or(any);
     YM_STAMP(a, 5);
+    if (a.stamps && tid == 0) { // development statistics: listed tiles with work, those that hold a cell in reach, hit chunks
+        atomicAdd(a.stamps + 27, 1ull);
+        atomicAdd(a.stamps + 28, any ? 1ull : 0ull);
+        atomicAdd(a.stamps + 29, (unsigned long long)nhits);
+    }
     if (!any) {
         if (*tz == 0) {
             zero_tile();
@@ -194,28 +199,53 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
     // Work item = 8 consecutive cells of one (halo) row.  Walls are thin: most 8-cell groups see no bit within
     // reach at all and leave after one test.
-    const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
-    const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
-    for (int i = tid; i < OH * LPR; i += NT) {
-        const int ry = i / LPR, rx = (i % LPR) * 8;
-        const int w = rx >> 6, sft = rx & 63;
-        const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
-        const unsigned long long sw = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask; // bits rx .. rx + 7 + 2h
-        uint32_t out[2] = {0xffffffffu, 0xffffffffu};
-        if (sw) {
+    if (2 * h + 8 <= 32) {
+        // the usual kernels (h <= 12): the 8 cells of a group see 2h + 8 <= 32 bits of the bitmap row, 32-bit bit scans
+        const unsigned wmask = (1u << (2 * h + 1)) - 1u, lmask = (1u << h) - 1u;
+        const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
+        for (int i = tid; i < OH * LPR; i += NT) {
+            const int ry = i / LPR, rx = (i % LPR) * 8;
+            const int w = rx >> 6, sft = rx & 63;
+            const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
+            const unsigned sw = (unsigned)((sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask); // bits rx .. rx + 7 + 2h
+            uint32_t out[2] = {0xffffffffu, 0xffffffffu};
+            if (sw) {
+                out[0] = out[1] = 0u;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const unsigned long long win = (sw >> q) & wmask;
-                if (win) {
-                    const unsigned long long right = win >> h, left = win & lmask;
-                    const int dr = right ? (__ffsll((long long)right) - 1) : 255;
-                    const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
-                    const unsigned g = (unsigned)(dr < dl ? dr : dl);
-                    out[q >> 2] = (out[q >> 2] & ~(0xffu << (8 * (q & 3)))) | (g << (8 * (q & 3)));
+                for (int q = 0; q < 8; q++) { // (no branch per cell: hipcc turns each into a saveexec / branch pair)
+                    const unsigned win = (sw >> q) & wmask;
+                    const unsigned right = win >> h, left = win & lmask;
+                    const unsigned dr = right ? (unsigned)(__ffs((int)right) - 1) : 255u;
+                    const unsigned dl = left ? (unsigned)(h - 31 + __clz((int)left)) : 255u;
+                    out[q >> 2] |= (dr < dl ? dr : dl) << (8 * (q & 3));
                 }
             }
+            *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
         }
-        *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+    } else {
+        const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
+        const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
+        for (int i = tid; i < OH * LPR; i += NT) {
+            const int ry = i / LPR, rx = (i % LPR) * 8;
+            const int w = rx >> 6, sft = rx & 63;
+            const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
+            const unsigned long long sw = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask; // bits rx .. rx + 7 + 2h
+            uint32_t out[2] = {0xffffffffu, 0xffffffffu};
+            if (sw) {
+    #pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const unsigned long long win = (sw >> q) & wmask;
+                    if (win) {
+                        const unsigned long long right = win >> h, left = win & lmask;
+                        const int dr = right ? (__ffsll((long long)right) - 1) : 255;
+                        const int dl = left ? (h - 63 + __clzll((long long)left)) : 255;
+                        const unsigned g = (unsigned)(dr < dl ? dr : dl);
+                        out[q >> 2] = (out[q >> 2] & ~(0xffu << (8 * (q & 3)))) | (g << (8 * (q & 3)));
+                    }
+                }
+            }
+            *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+        }
     }
     __syncthreads();
     YM_STAMP(a, 6);
@@ -247,7 +277,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         uint32_t packed[2] = {0u, 0u};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const unsigned v = mn[q] <= max_d2 ? lut[mn[q]] : 0u;
+            const unsigned v = lut[mn[q] <= max_d2 ? mn[q] : max_d2 + 1u]; // (lut[max_d2 + 1] = 0: no branch per cell)
             packed[q >> 2] |= v << (8 * (q & 3));
         }
         store8(y, packed[0], packed[1]);
