@@ -823,3 +823,28 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             o = orc.Oracle(cfg, "karto")
             o.match_scan(query, base, True, True)
             assert np.array_equal(vols[0][0][0], o.sums(0))
+
+
+def test_raster_grid_shorter_than_the_tile_list():
+    """On batches the raster launches as many blocks per item as the longest tile list of the matcher's previous call
+    (+ 1/8); entries beyond the grid are rasterised by a second, small launch that walks them.  Forced grids of 1, 7 and
+    40 blocks per item (option 16) and the free-running matcher (first call: one block per tile; later calls: by the
+    hint) must produce the same windows and results."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:], nb[5:6]]
+    ref = None
+    for gx in (0, 0, 1, 7, 40):
+        m = ScanMatcher() if ref is None or gx else m
+        m.debug_option(16, gx)
+        per, best = m.match_scan_batch(nq, chains, True, True)
+        grids = [m.debug_grid(i)[0] for i in (0, 4, 8)]
+        if ref is None:
+            ref = (per, best, grids)
+            continue
+        for a, b in zip(per, ref[0]):
+            assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+        assert best == ref[1]
+        for g, r in zip(grids, ref[2]):
+            assert np.array_equal(g, r)

@@ -308,6 +308,8 @@ struct ym_matcher {
     DevBuf<unsigned> sel_scratch; // select on long chains: hash, states and neighbour lists in global memory
     DevBuf<uint16_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
+    DevBuf<int32_t> tile_max;        // [1] longest raster work list of the call
+    int32_t *tile_max_host = nullptr; // pinned: the raster kernel leaves that number here, the next call sizes its grid by it
     int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
@@ -316,6 +318,7 @@ struct ym_matcher {
     int corr_region = 0;    // tests: 1 = never use the region-staged correlate, 2 = its per-cell path, 3 = its "list does not fit" path
     int corr_region_nw = 0; // development: waves (= angles) per region-correlate block
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    int raster_gx = 0;      // tests: raster blocks per item (0 = by the previous call's longest work list)
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
@@ -952,6 +955,11 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     if (P.use_tile_list) {
         if ((rc = m->tile_list.ensure((size_t)B * P.tile_cap))) return rc;
         if ((rc = m->tile_count.ensure(B))) return rc;
+        if ((rc = m->tile_max.ensure(1))) return rc;
+        if (!m->tile_max_host) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->tile_max_host), sizeof(int32_t), hipHostMallocDefault));
+            *m->tile_max_host = 0;
+        }
     }
     return YM_OK;
 }
@@ -1018,6 +1026,8 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     if (P.use_tile_list) {
         ym::TilesArgs t;
         t.bbox = m->bbox.p; t.tile_list = m->tile_list.p; t.tile_count = m->tile_count.p; t.tile_zero = m->tile_zero.p;
+        t.tile_max = m->tile_max.p;
+        (void)hipMemsetAsync(m->tile_max.p, 0, sizeof(int32_t), st);
         t.max_n = P.max_n; t.max_base = P.max_base; t.half_kernel = g.half_kernel;
         t.tiles_x = P.tiles_x; t.tiles_y = P.tiles_y; t.tile_cap = P.tile_cap;
         for (int k = 0; k < 4; k++) t.launch[k] = P.launch[k];
@@ -1029,12 +1039,23 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
     a.tile_zero = m->tile_zero.p;
+    a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
     int rc;
     hipEvent_t ev_k = nullptr;
     if ((rc = prof_begin(m, 1, &ev_k))) return rc;
     if (P.ltx > 0 && P.lty > 0) {
-        if (P.use_tile_list) hipLaunchKernelGGL(ym::raster_kernel<128>, dim3(P.ltx * P.lty, P.B), dim3(128), 0, st, a);
-        else hipLaunchKernelGGL(ym::raster_kernel<256>, dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
+        // blocks per item: the longest work list an earlier call of this matcher reported (+ 1/8), at most one per tile of
+        // the sub-grid; the blocks stride over the list, so a stale or missing number only costs time
+        const int hint = m->tile_max_host ? *reinterpret_cast<volatile int32_t *>(m->tile_max_host) : 0;
+        const int gx = m->raster_gx > 0 ? std::min(P.ltx * P.lty, m->raster_gx)
+                                        : hint > 0 ? std::min(P.ltx * P.lty, hint + hint / 8 + 2) : P.ltx * P.lty;
+        a.first_overflow = gx;
+        if (P.use_tile_list) {
+            hipLaunchKernelGGL((ym::raster_kernel<128, false>), dim3(gx, P.B), dim3(128), 0, st, a);
+            if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true>), dim3(4, P.B), dim3(128), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((ym::raster_kernel<256, false>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
+        }
     }
     return prof_end(m, ev_k);
 }
@@ -1446,7 +1467,8 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->sel_scratch.release();
+    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->sel_scratch.release();
+    if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
     m->tmp_ranges_host.release(); m->kernel_f_dev.release(); m->map_pts.release(); m->cache_arena.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
@@ -2140,6 +2162,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 13) m->corr_dedup = value;
     else if (option == 14) m->corr_region = value;
     else if (option == 15) m->corr_region_nw = value;
+    else if (option == 16) m->raster_gx = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

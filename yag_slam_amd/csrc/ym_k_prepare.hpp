@@ -459,6 +459,7 @@ struct TilesArgs {
     const int4 *bbox;        // [B][max_base][YM_N_BOXES(max_n)]
     uint16_t *tile_list;     // [B][tile_cap] tile index (tiy * tiles_x + tix), | 0x8000 = only needs clearing
     int32_t *tile_count;     // [B]
+    int32_t *tile_max;       // longest list of the call (zeroed by the host before the launch)
     const uint8_t *tile_zero;// [B][tiles_y][tiles_x] 1 = the tile's memory is known to hold zeros
     int32_t max_n, max_base, half_kernel;
     int32_t tiles_x, tiles_y, tile_cap;
@@ -500,7 +501,10 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
         if (hit || tz[t] == 0) list[atomicAdd(&s_n, 1)] = (uint16_t)(t | (hit ? 0 : 0x8000));
     }
     __syncthreads();
-    if (tid == 0) a.tile_count[b] = s_n;
+    if (tid == 0) {
+        a.tile_count[b] = s_n;
+        if (s_n > *reinterpret_cast<volatile int32_t *>(a.tile_max)) atomicMax(a.tile_max, s_n); // (few blocks raise it)
+    }
 }
 
 // ================================================================== K1b select (only when the smear kernel has taps == 100 off-centre)

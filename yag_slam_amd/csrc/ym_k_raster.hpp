@@ -22,6 +22,9 @@ struct RasterArgs {
     const uint16_t *tile_list; // [B][tile_cap] work list built by tiles_kernel, or null: one block per sub-grid tile
     const int32_t *tile_count; // [B]
     int32_t tile_cap;
+    int32_t first_overflow;    // OVERFLOW launch: the first list entry the main launch's grid did not reach
+    const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
+    int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
     unsigned long long *stamps;
 };
 
@@ -35,7 +38,7 @@ struct RasterArgs {
 //   column pass m(y, x) = min over |dy| <= h of dy^2 + g(y+dy, x)^2        (8 cells per lane)
 // NT = 256: one tile row per thread, shortest latency (single match); NT = 128: two rows per thread, twice the
 // blocks per CU -- the tiles with work are latency-bound, so a batch gains (raster 160 -> 140 us on 256 items)
-template <int NT>
+template <int NT, bool OVERFLOW>
 __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF;
     constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
@@ -43,22 +46,16 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
     __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
     __shared__ unsigned char lut[2 * HM * HM + 8];
+    __shared__ unsigned colany[TW / 8][4]; // per 8-cell column group: bit ry = the row pass found a wall within reach in halo row ry
+    __shared__ int s_hits[256], s_left[256];
+    __shared__ int s_nhits;
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    // grid (tiles of the launched sub-grid, B).  With a work list (batches) block i takes entry i and the blocks
-    // past the list's end leave at once; without one (a few items: one more launch would cost more than it saves)
-    // block i is tile i of the sub-grid and finds out by itself whether any chunk box reaches it.
+    // grid (x, B).  With a work list (batches) block i takes entry i of its item's list; without one (a few items: one
+    // more launch would cost more than it saves) block i is tile i of the sub-grid and finds out by itself whether any
+    // chunk box reaches it.
     const bool listed = a.tile_list != nullptr;
-    unsigned entry;
-    if (listed) {
-        if ((int)blockIdx.x >= a.tile_count[b]) return;
-        entry = a.tile_list[(size_t)b * a.tile_cap + blockIdx.x];
-    } else {
-        const int sy = (int)blockIdx.x / a.ltx, sx = (int)blockIdx.x - sy * a.ltx;
-        // rotate the tile column by the row: a sub-grid width that is a multiple of 8 would otherwise pin every
-        // tile column (i.e. every wall) to one XCD
-        entry = (unsigned)((a.tile_y0 + sy) * a.tiles_x + a.tile_x0 + (sx + 3 * sy + 5 * b) % a.ltx);
-    }
+    auto one_tile = [&](unsigned entry, int bi) { // (bi = b; opaque to the optimiser in the list loop, see below)
     const int tile = (int)(entry & 0x7fffu);
     const int h = a.g.half_kernel;
     const int OW = TW + 2 * h, OH = TH + 2 * h;
@@ -68,13 +65,13 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     // candidate chunks: YM_BOX_CELLS consecutive cells of one base scan whose bounding box touches tile + halo
     const int n_cchunks = YM_N_BOXES(a.max_n);
     const int n_boxes = a.max_base * n_cchunks;
-    const int4 *bbox = a.bbox + (size_t)b * n_boxes;
+    const int4 *bbox = a.bbox + (size_t)bi * n_boxes;
     const int lo_x = tx0 - h, hi_x = tx0 + TW + h - 1, lo_y = ty0 - h, hi_y = ty0 + TH + h - 1;
-    uint8_t *grid = a.grid + (size_t)b * a.grid_stride;
+    uint8_t *grid = a.grid + (size_t)bi * a.grid_stride;
     // thread -> 8 consecutive cells (x8 ..) of tile rows y0, y0 + NT / LPR, ...
     const int y0 = tid / LPR, x8 = (tid % LPR) * 8;
     const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
-    uint8_t *planes = a.planes + (size_t)b * a.grid_stride;
+    uint8_t *planes = a.planes + (size_t)bi * a.grid_stride;
     // the window row-major and its even / odd column planes (v_perm_b32 byte gathers) for 8 cells of tile row y
     auto store8 = [&](int y, uint32_t p0, uint32_t p1) {
         if (ty0 + y < a.g.win_w) {
@@ -87,9 +84,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     auto zero_tile = [&]() {
         for (int y = y0; y < TH; y += NT / LPR) store8(y, 0u, 0u);
     };
-    uint8_t *tz = a.tile_zero + ((size_t)b * a.tiles_y + tiy) * a.tiles_x + tix;
-    __shared__ int s_hits[256], s_left[256];
-    __shared__ int s_nhits;
+    uint8_t *tz = a.tile_zero + ((size_t)bi * a.tiles_y + tiy) * a.tiles_x + tix;
     if (entry & 0x8000u) { // no chunk reaches this tile, but its memory still holds an earlier call's bytes
         zero_tile();
         if (tid == 0) *tz = 1;
@@ -127,10 +122,11 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         }
     }
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
+    if (tid < (TW / 8) * 4) (&colany[0][0])[tid] = 0u;
     for (int i = tid; i <= 2 * h * h + 1; i += NT) lut[i] = i <= 2 * h * h ? a.lut[i] : (unsigned char)0;
     __syncthreads();
     const int nhits = s_nhits;
-    const int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
+    const int2 *cells = a.cells + (size_t)bi * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
     if (nhits <= 256) {
@@ -208,9 +204,8 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
             const int w = rx >> 6, sft = rx & 63;
             const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
             const unsigned sw = (unsigned)((sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask); // bits rx .. rx + 7 + 2h
-            uint32_t out[2] = {0xffffffffu, 0xffffffffu};
-            if (sw) {
-                out[0] = out[1] = 0u;
+            if (sw) { // (a group without a wall in reach writes nothing: the column pass only reads flagged rows)
+                uint32_t out[2] = {0u, 0u};
 #pragma unroll
                 for (int q = 0; q < 8; q++) { // (no branch per cell: hipcc turns each into a saveexec / branch pair)
                     const unsigned win = (sw >> q) & wmask;
@@ -219,8 +214,9 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                     const unsigned dl = left ? (unsigned)(h - 31 + __clz((int)left)) : 255u;
                     out[q >> 2] |= (dr < dl ? dr : dl) << (8 * (q & 3));
                 }
+                *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+                atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
             }
-            *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
         }
     } else {
         const unsigned long long wmask = (1ull << (2 * h + 1)) - 1ull, lmask = (1ull << h) - 1ull;
@@ -230,8 +226,8 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
             const int w = rx >> 6, sft = rx & 63;
             const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
             const unsigned long long sw = (sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask; // bits rx .. rx + 7 + 2h
-            uint32_t out[2] = {0xffffffffu, 0xffffffffu};
             if (sw) {
+                uint32_t out[2] = {0xffffffffu, 0xffffffffu};
     #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const unsigned long long win = (sw >> q) & wmask;
@@ -243,24 +239,32 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                         out[q >> 2] = (out[q >> 2] & ~(0xffu << (8 * (q & 3)))) | (g << (8 * (q & 3)));
                     }
                 }
+                *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+                atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
             }
-            *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
         }
     }
     __syncthreads();
     YM_STAMP(a, 6);
     // column pass: 8 cells per lane as four pairs of 16-bit lanes (cells 0|2, 1|3, 4|6, 5|7): the candidate
     // g*g + dy*dy is at most 255^2 + h^2 < 65536, so one v_pk_mad_u16 + one v_pk_min_u16 serve two cells.
-    // A row whose 8 distances are all "none" contributes nothing.
+    // Only the halo rows in which the row pass found a wall within reach of this column group are visited (bit scan of
+    // the group's row mask): walls are thin, most (row, group) pairs have none and write zeros at once.
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const unsigned max_d2 = (unsigned)(2 * h * h);
+    const unsigned *ca = colany[x8 / 8];
+    const unsigned long long ca_lo = (unsigned long long)ca[0] | (unsigned long long)ca[1] << 32, ca_hi = ca[2]; // (y + 2h <= 71)
+    const unsigned long long tapmask = (1ull << (2 * h + 1)) - 1ull;
     for (int y = y0; y < TH; y += NT / LPR) {
         us2 mn2[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
-        for (int dy = -h; dy <= h; dy++) {
-            const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + h + dy) * TW + x8]);
-            if ((gg.x & gg.y) == 0xffffffffu) continue;
+        unsigned long long m = (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask; // bit t: halo row y + t, dy = t - h
+        while (m) {
+            const int t = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const int dy = t - h;
+            const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + t) * TW + x8]);
             const unsigned short d2 = (unsigned short)(dy * dy);
             const us2 dd = (us2){d2, d2};
             const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
@@ -283,6 +287,29 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         store8(y, packed[0], packed[1]);
     }
     YM_STAMP(a, 7);
+    }; // one_tile
+    if (listed) {
+        // The grid's x size is a guess (the longest list of the previous call + 1/8, yagmatch.hip): launching one block per
+        // tile of the sub-grid cost 80 us per 1024 items in blocks that only found the list exhausted.  Block x takes entry
+        // x; what a longer list holds beyond the grid is done by the OVERFLOW instantiation, a second launch of a few blocks
+        // per item that walk the rest (its loop keeps every per-item constant in registers: 106 SGPRs, 9 spilled -- not
+        // something the one-tile-per-block kernel should pay for).
+        const int count = a.tile_count[b];
+        if (!OVERFLOW) {
+            if (blockIdx.x == 0 && b == 0 && tid == 0 && a.tile_max_host) *a.tile_max_host = *a.tile_max;
+            if ((int)blockIdx.x < count) one_tile(a.tile_list[(size_t)b * a.tile_cap + blockIdx.x], b);
+        } else {
+            for (int e = a.first_overflow + (int)blockIdx.x; e < count; e += (int)gridDim.x) {
+                one_tile(a.tile_list[(size_t)b * a.tile_cap + e], b);
+                __syncthreads(); // (the LDS tables are reused)
+            }
+        }
+    } else {
+        const int sy = (int)blockIdx.x / a.ltx, sx = (int)blockIdx.x - sy * a.ltx;
+        // rotate the tile column by the row: a sub-grid width that is a multiple of 8 would otherwise pin every
+        // tile column (i.e. every wall) to one XCD
+        one_tile((unsigned)((a.tile_y0 + sy) * a.tiles_x + a.tile_x0 + (sx + 3 * sy + 5 * b) % a.ltx), b);
+    }
 }
 
 }  // namespace ym
