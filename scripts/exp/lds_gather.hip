@@ -105,7 +105,11 @@ static void run(const char *name, int pitch, int nw, int lanemap, int blocks) {
     free(h); hipFree(out); hipFree(cyc);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1) { // extra pitches for the lane map the kernel uses: lds_gather 132 148 164 ...
+        for (int i = 1; i < argc; i++) run<2>("2 x read2_b32", atoi(argv[i]), 16, 1, 256);
+        return 0;
+    }
     const int pitches[] = {100, 116, 104, 112};
     for (int nw : {8, 16}) {
         for (int p : pitches) {

@@ -19,10 +19,8 @@
 
 namespace ym {
 
-#define YM_RG_LOG_W 6
-#define YM_RG_LOG_H 6
-#define YM_RG_W (1 << YM_RG_LOG_W)            // region width and height in class bytes (128 x 128 window cells)
-#define YM_RG_H (1 << YM_RG_LOG_H)
+#define YM_RG_W 64                            // region width and height in class bytes (128 x 160 window cells): what three
+#define YM_RG_H 80                            // blocks per CU leave room for in LDS
 #define YM_RG_PITCH 100                       // LDS bytes per staged row: 25 dwords, odd -> 26 rows on 26 distinct banks
 #define YM_RG_ROWS (YM_RG_H + 26)             // + the patch height
 #define YM_RG_SEGS 6                          // 16-byte blocks staged per row (96 >= 64 + 26 + 3)
@@ -34,10 +32,11 @@ namespace ym {
 // past the last cell of the second plane (never gathered, but read)
 #define YM_RG_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(half_pitch) + 256)
 #define YM_RG_MAX_BINS 8192
+#define YM_RG_MAX_REGIONS 96                   // regions with work a block of correlate_region_kernel can list
 #define YM_RG_MAX_ENTRIES 28672
 #define YM_RG_FLUSH 652                       // patches per set of 16-bit sums: 652 x 100 < 65536 (a multiple of four)
 #define YM_BIN_THREADS 1024
-#define YM_BIN_LDS_BYTES(nbins, entries) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT) * 4 + (size_t)(nbins) * 8 + (size_t)(entries) * 2)
+#define YM_BIN_LDS_BYTES(nbins, entries) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT + YM_RG_MAX_BINS / 32 + 1) * 4 + (size_t)(nbins) * 8 + (size_t)(entries) * 2)
 
 struct RegionArgs {
     YmGeom g;
@@ -67,10 +66,10 @@ struct RegionArgs {
 __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int cx0, int cy0, int k, int i, int &bin, unsigned &entry) {
     const int X = cx0 + cell.x, Y = cy0 + cell.y;
     const int xc = X >> 1, yc = Y >> 1;
-    const int rx = xc >> YM_RG_LOG_W, ry = yc >> YM_RG_LOG_H;
+    const int rx = xc / YM_RG_W, ry = yc / YM_RG_H;
     if (X < 0 || Y < 0 || rx >= a.nrx || ry >= a.nry) return false;
     bin = (ry * a.nrx + rx) * a.lat.nt + k;
-    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS + (yc & (YM_RG_H - 1)) * YM_RG_PITCH + (xc & (YM_RG_W - 1)));
+    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS + (yc - ry * YM_RG_H) * YM_RG_PITCH + (xc - rx * YM_RG_W));
     return true;
 }
 
@@ -79,15 +78,17 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // Inside a bin the entries are sorted by their byte misalignment (entry & 3; class images and rows are multiples of 4
 // bytes), every run of equal misalignment is padded to an even length and the bin to a multiple of four with entries
 // that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
-// never meets a ragged group.  An item whose padded list would not fit -- the buffers, or one angle's share the ng sets of
-// 16-bit sums the gather may fill -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
+// never meets a ragged group.  An item whose padded list would not fit -- the buffers, one angle's share the ng sets of
+// 16-bit sums the gather may fill, or more regions with work than a correlate block can list -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
 __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
     // dynamic LDS (YM_BIN_LDS_BYTES: sized by the host so that two blocks share a CU on the usual lattice):
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
     int *wave_tot = reinterpret_cast<int *>(bin_smem);                                   // [YM_BIN_THREADS / 64]
     int *angle_tot = wave_tot + YM_BIN_THREADS / 64;                                     // [YM_MAX_COARSE_NT] padded entries per coarse angle
-    unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(angle_tot + YM_MAX_COARSE_NT); // [nbins] four 16-bit counters (one per
+    unsigned *region_bits = reinterpret_cast<unsigned *>(angle_tot + YM_MAX_COARSE_NT);    // [YM_RG_MAX_BINS / 32] regions that hold a patch
+    int *regions_used = reinterpret_cast<int *>(region_bits + YM_RG_MAX_BINS / 32);
+    unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(regions_used + 1);             // [nbins] four 16-bit counters (one per
                                                                                          // misalignment), later the runs' first positions
     unsigned short *ent = reinterpret_cast<unsigned short *>(cnt + a.nbins);             // [entries_stride]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     int32_t *starts = a.starts + (size_t)b * a.starts_stride;
     for (int i = tid; i < a.nbins * 2; i += YM_BIN_THREADS) (&cnt[0][0])[i] = 0u;
     if (tid < YM_MAX_COARSE_NT) angle_tot[tid] = 0;
+    if (tid < YM_RG_MAX_BINS / 32) region_bits[tid] = 0u;
+    if (tid == 0) *regions_used = 0;
     __syncthreads();
     // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
     // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
@@ -135,7 +138,11 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
                 const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
                 const int padded = (((c[0] + 1) & ~1) + ((c[1] + 1) & ~1) + ((c[2] + 1) & ~1) + ((c[3] + 1) & ~1) + 3) & ~3;
                 local += padded;
-                if (padded) atomicAdd(&angle_tot[(first + j) % nt], padded);
+                if (padded) {
+                    atomicAdd(&angle_tot[(first + j) % nt], padded);
+                    const int R = (first + j) / nt;
+                    atomicOr(&region_bits[R >> 5], 1u << (R & 31));
+                }
             }
         int incl = local;
 #pragma unroll
@@ -145,6 +152,8 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
         }
         if (lane == 63) wave_tot[tid >> 6] = incl;
         __syncthreads();
+        if (tid < YM_RG_MAX_BINS / 32 && region_bits[tid]) atomicAdd(regions_used, __popc(region_bits[tid]));
+        __syncthreads();
         int base = 0, all = 0;
         for (int w = 0; w < YM_BIN_THREADS / 64; w++) {
             if (w < (tid >> 6)) base += wave_tot[w];
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
         padded_total = all;
         bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride && a.force_irregular != 2;
         for (int k = 0; k < nt; k++) fits = fits && angle_tot[k] <= a.ng * YM_RG_FLUSH;
+        fits = fits && *regions_used <= YM_RG_MAX_REGIONS; // (what a block of correlate_region_kernel can list)
         int run = base + incl - local;
         for (int j = 0; j < per; j++)
             if (first + j < a.nbins) {
@@ -252,7 +262,6 @@ __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off
 // The walk over the regions is a two-stage pipeline: while region i is gathered, the global loads of region i + 1 are in
 // flight (registers) together with the wave's first 128 entries of it; they go to LDS between the two barriers that end
 // the gather.
-#define YM_RG_MAX_REGIONS 128
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a) {
     constexpr int NT = 64 * NW;
