@@ -820,6 +820,17 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
                     assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
                 assert vols[mode][2] == vols[1][2]
             assert vols[0][0][0].any()
+            # without the kept sums the region kernel also scores them itself (responses, block maxima, per-cell maxima
+            # through LDS); option 17 = 2 leaves that to the score kernel: identical results either way
+            res = []
+            for fuse in (0, 2):
+                m = ScanMatcher(cfg)
+                m.debug_option(17, fuse)
+                res.append(m.match_scan_batch(nquery, chains, True, True))
+            for a, b, c in zip(res[0][0], res[1][0], vols[1][1]):
+                assert a.response == b.response == c.response and a.covariance == b.covariance == c.covariance
+                assert a.meta == b.meta == c.meta
+            assert res[0][1] == res[1][1] == vols[1][2]
             o = orc.Oracle(cfg, "karto")
             o.match_scan(query, base, True, True)
             assert np.array_equal(vols[0][0][0], o.sums(0))

@@ -165,6 +165,7 @@ struct CallPlan {
     int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
     // batches on small lattices: the region-staged correlate (ym_k_region.hpp)
     bool region = false;
+    bool fuse_score = false;  // the region correlate also scores (no score_kernel launch)
     int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1;
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // yagpy lattice bounds
@@ -319,6 +320,7 @@ struct ym_matcher {
     int corr_region_nw = 0; // development: waves (= angles) per region-correlate block
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
     int raster_gx = 0;      // tests: raster blocks per item (0 = by the previous call's longest work list)
+    int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
@@ -685,6 +687,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
     P.resp = call.ext_resp ? call.ext_resp : m->resp.p;
     P.probs = call.ext_probs ? call.ext_probs : m->probs.p;
+    P.fuse_score = P.region && !m->keep_sums && m->corr_fuse_score != 2;
     P.k_begin = call.slice ? std::max(0, call.k_begin) : 0;
     P.k_end = call.slice ? std::min(lc.nt, call.k_end) : lc.nt;
     if (call.slice && (yag || B != 1)) return set_err(YM_ERR_UNSUPPORTED, "angle-sliced matches are single Karto matches");
@@ -1109,6 +1112,8 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
         r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
         r.force_irregular = m->corr_region >= 2 ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
+        r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
+        r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
         const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride);
         if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
@@ -1167,6 +1172,7 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
     a.k_begin = P.k_begin; a.k_end = P.k_end;
     a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's maxima are recomputed once the volume is whole
+    if (P.fuse_score) return; // the region correlate has scored its sums itself
     if (P.B >= 8) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
     else if (P.k_end > P.k_begin)
         hipLaunchKernelGGL(ym::score_hyp_kernel, dim3(P.cell_blocks, P.k_end - P.k_begin, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
@@ -2163,6 +2169,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 14) m->corr_region = value;
     else if (option == 15) m->corr_region_nw = value;
     else if (option == 16) m->raster_gx = value;
+    else if (option == 17) m->corr_fuse_score = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

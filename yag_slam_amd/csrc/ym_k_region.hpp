@@ -56,7 +56,13 @@ struct RegionArgs {
     int32_t nt_stride, dim_stride;
     int32_t nrx, nry, ng, nbins;
     int32_t force_irregular; // tests: 1 = take the per-cell path, 2 = bin_kernel reports that the padded list does not fit
-    int32_t pad;
+    int32_t fuse_score;      // 1: the wave that holds an angle's sums also scores them (what score_kernel does otherwise)
+    double *resp;            // [B][nt][ny][nx]                         (fuse_score)
+    size_t sums_stride;
+    double *blockmax;        // [B][n_blocks], block = (angle, YM_SCORE_THREADS cells)
+    double *probs;           // [B][ny*nx] max over theta per (x, y); zeroed by the prepare stage
+    size_t probs_stride;
+    int32_t n_blocks, pad;
     unsigned long long *stamps;
 };
 
@@ -447,8 +453,58 @@ __global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a)
         }
     }
     YM_STAMP(a, 9);
-    if (!kvalid) return;
-    while (flushed < ng) flush(); // the set being filled, then empty ones
+    if (!a.fuse_score) {
+        if (!kvalid) return;
+        while (flushed < ng) flush(); // the set being filled, then empty ones
+        return;
+    }
+    // ---- score (score_kernel's arithmetic, statement for statement): this wave holds the last set of its angle's sums in
+    // registers and wrote the earlier ones itself; response, penalty, block maxima; the per-(x, y) maximum over theta goes
+    // through LDS (the region buffer is free now) so that only one atomic per cell and block reaches memory
+    unsigned long long *pmax = reinterpret_cast<unsigned long long *>(region); // [ny * nx] fp64 bit patterns, >= 0
+    const int nxy = nx * ny;
+    __syncthreads(); // every wave has left the region walk
+    for (int i = tid; i < nxy; i += NT) pmax[i] = 0ull;
+    __syncthreads();
+    if (kvalid) {
+        unsigned tot[YM_RG_G];
+#pragma unroll
+        for (int j = 0; j < YM_RG_G; j++) tot[j] = (acc[2 * (j >> 2) + (j & 1)] >> (16 * ((j >> 1) & 1))) & 0xffffu;
+        for (int f = 0; f < min(flushed, ng); f++) { // the sets this lane wrote out earlier
+            const uint16_t *pp = a.partial + (size_t)b * a.partial_stride + (((size_t)f * nt + k) * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < YM_RG_G; j++) tot[j] += pp[j];
+        }
+        const double ct = st.center[2];
+        const int nq = st.nq;
+        const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
+        const double y = -a.lat.off_y + row * a.lat.step_y;
+        const int ncb = (nxy + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
+        double bmax0 = -1.0, bmax1 = -1.0; // block maxima this lane contributes to (its 13 cells span at most 2 blocks)
+        const int c0 = row * nx + half * YM_RG_G, cb0 = job ? c0 / YM_SCORE_THREADS : 0;
+#pragma unroll
+        for (int j = 0; j < YM_RG_G; j++) {
+            const int ix = half * YM_RG_G + j;
+            if (job && ix < nx) {
+                const double x = -a.lat.off_x + ix * a.lat.step_x;
+                const double r = hyp_response(a.g, a.lat.penalize, tot[j], nq, x * x + y * y, angle, ct);
+                const int c = row * nx + ix;
+                a.resp[(size_t)b * a.sums_stride + (size_t)k * nxy + c] = r;
+                if (c / YM_SCORE_THREADS == cb0) bmax0 = r > bmax0 ? r : bmax0;
+                else bmax1 = r > bmax1 ? r : bmax1;
+                if (r > 0.0) atomicMax(&pmax[c], (unsigned long long)__double_as_longlong(r));
+            }
+        }
+        // block maxima of this angle: blockmax[k * ncb + cb]
+        for (int cb = 0; cb < ncb; cb++) {
+            const double mine = !job ? -1.0 : cb == cb0 ? bmax0 : cb == cb0 + 1 ? bmax1 : -1.0;
+            const double m = wave_reduce(mine, OpMaxD());
+            if (lane == 0) a.blockmax[(size_t)b * a.n_blocks + (size_t)k * ncb + cb] = m;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nxy; i += NT)
+        if (pmax[i]) atomicMax(reinterpret_cast<unsigned long long *>(a.probs) + (size_t)b * a.probs_stride + i, pmax[i]);
 }
 
 } // namespace ym
