@@ -859,3 +859,32 @@ def test_raster_grid_shorter_than_the_tile_list():
         assert best == ref[1]
         for g, r in zip(grids, ref[2]):
             assert np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("nx", [3, 7, 12, 13, 14, 15, 21, 25, 26])
+def test_region_correlate_lattice_widths(nx):
+    """The region correlate splits a lattice row into two lanes of 13 hypotheses: every width from one short lane to
+    two full ones (and the first width that needs the second lane), sums against the direct kernel, results with the
+    fused scoring against single calls."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    cfg = {"search_size": (nx - 1) * 0.02, "coarse_search_angle_offset": 0.07 if nx < 13 else 0.349}
+    chains = [nb, nb[:4], nb[3:], nb[::-1], nb[2:7], nb[5:], nb[:8], nb[1:9]]
+    vols = []
+    for mode in (0, 1):
+        m = ScanMatcher(cfg)
+        m.debug_option(12, 1)
+        m.debug_option(14, mode)
+        per, best = m.match_scan_batch(nq, chains, True, True)
+        dims = per[0].meta["coarse_dims"]
+        assert dims[0] == nx and dims[1] == nx
+        vols.append([m.debug_sums(0, item=i, dims=dims) for i in range(len(chains))])
+    for a, b in zip(*vols):
+        assert np.array_equal(a, b)
+    m = ScanMatcher(cfg)
+    per, best = m.match_scan_batch(nq, chains, True, True)
+    singles = [m.match_scan(nq, ch, True, True) for ch in chains]
+    for a, b in zip(per, singles):
+        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+    assert best == int(np.argmax([s.response for s in singles]))
