@@ -639,7 +639,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
         P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
         P.region = !yag && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 2 * YM_RG_G &&
-                   lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins <= YM_RG_MAX_BINS;
+                   lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         static const bool debug_plan = getenv("YM_DEBUG_PLAN") != nullptr; // development aid: which correlate a call takes
         if (debug_plan)
             fprintf(stderr, "[ym] B %d region %d nbins %d nrx %d nry %d ng %d nw %d max_n %d nx %d ny %d nt %d dedup %d\n", B, (int)P.region, P.rg_nbins,

@@ -114,20 +114,24 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     __syncthreads();
     // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
     // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
-    unsigned key[MAXP];  // bin << 16 | entry; 0xffffffff = no pair
-    unsigned short rank[MAXP];
+    // (29 bits of bin and entry + the rank's low 3 bits in one register, its other 8 bits four to a register: 35 registers
+    // for 28 pairs, so that two blocks share a CU; the host keeps max_n below 2048 on this path)
+    unsigned key[MAXP];          // rank & 7 << 29 | bin << 16 | entry; 0xffffffff = no pair
+    unsigned rank_hi[(MAXP + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (MAXP + 3) / 4; q++) rank_hi[q] = 0u;
 #pragma unroll
     for (int q = 0; q < MAXP; q++) {
         const int p = tid + q * YM_BIN_THREADS;
         key[q] = 0xffffffffu;
-        rank[q] = 0;
         if (p < total) {
             const int k = p / nq, i = p - k * nq;
             const double2 cs = trig[k];
             int bin; unsigned e;
             if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e)) {
-                key[q] = (unsigned)bin << 16 | e;
-                rank[q] = (unsigned short)((atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu);
+                const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
+                key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
+                rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
             }
         }
     }
@@ -196,9 +200,10 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
 #pragma unroll
     for (int q = 0; q < MAXP; q++) {
         if (key[q] == 0xffffffffu) continue;
-        const unsigned bin = key[q] >> 16, e = key[q] & 0xffffu;
+        const unsigned bin = (key[q] >> 16) & 0x1fffu, e = key[q] & 0xffffu;
+        const unsigned rank = key[q] >> 29 | ((rank_hi[q >> 2] >> (8 * (q & 3))) & 0xffu) << 3;
         const unsigned f = cnt[bin][(e >> 1) & 1u];
-        ent[((e & 1u) ? f >> 16 : f & 0xffffu) + rank[q]] = (unsigned short)e;
+        ent[((e & 1u) ? f >> 16 : f & 0xffffu) + rank] = (unsigned short)e;
     }
     __syncthreads();
     uint32_t *out = reinterpret_cast<uint32_t *>(a.entries + (size_t)b * a.entries_stride);
