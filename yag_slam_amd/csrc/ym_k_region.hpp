@@ -257,10 +257,32 @@ __device__ __forceinline__ void rg_pair(uint32_t lane_off, uint32_t e2 /* two 16
     x[2] = __builtin_amdgcn_alignbyte(s[3], s[2], rr);
     x[3] = __builtin_amdgcn_alignbyte(0u, s[3], rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
 }
+__device__ __forceinline__ void rg_funnel_pair(const rg_u32x2 &pa, const rg_u32x2 &qa, const rg_u32x2 &pb, const rg_u32x2 &qb, uint32_t rr,
+                                               uint32_t (&x)[4]) {
+    const uint32_t s0 = pa.x + pb.x, s1 = pa.y + pb.y, s2 = qa.x + qb.x, s3 = qa.y + qb.y; // raw dwords of two patches: bytes <= 200
+    x[0] = __builtin_amdgcn_alignbyte(s1, s0, rr);
+    x[1] = __builtin_amdgcn_alignbyte(s2, s1, rr);
+    x[2] = __builtin_amdgcn_alignbyte(s3, s2, rr);
+    x[3] = __builtin_amdgcn_alignbyte(0u, s3, rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
+}
+// All eight reads of the four patches are issued at once; the first pair is funnelled while the second pair's reads are
+// still in flight (LDS reads return in order: lgkmcnt(4) = the first four are back).
 __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint2 ee /* four 16-bit origins, wave-uniform */) {
+    const uint32_t ad0 = lane_off + (ee.x & 0xffffu), ad1 = lane_off + (ee.x >> 16), ad2 = lane_off + (ee.y & 0xffffu), ad3 = lane_off + (ee.y >> 16);
+    rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %4, %10 offset1:1\n\tds_read2_b32 %5, %10 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %6, %11 offset1:1\n\tds_read2_b32 %7, %11 offset0:2 offset1:3\n\t"
+                 "s_waitcnt lgkmcnt(4)"
+                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
+                 : "v"(ad0 & ~3u), "v"(ad1 & ~3u), "v"(ad2 & ~3u), "v"(ad3 & ~3u)
+                 : "memory");
     uint32_t x[2][4];
-    rg_pair(lane_off, ee.x, x[0]);
-    rg_pair(lane_off, ee.y, x[1]);
+    rg_funnel_pair(p0, q0, p1, q1, ad0 & 3u, x[0]);
+    // (the second pair's registers are written by the LDS until here: they pass through this statement and nothing else)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p2), "+v"(q2), "+v"(p3), "+v"(q3) : : "memory");
+    rg_funnel_pair(p2, q2, p3, q3, ad2 & 3u, x[1]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
@@ -274,7 +296,7 @@ __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off
 // flight (registers) together with the wave's first 128 entries of it; they go to LDS between the two barriers that end
 // the gather.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void correlate_region_kernel(RegionArgs a) {
+__global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three blocks per CU: 80 VGPRs */) void correlate_region_kernel(RegionArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int TASKS = 4 * YM_RG_ROWS * YM_RG_SEGS, PER = (TASKS + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned char region[YM_RG_LDS_BYTES]; // four class images + the zero patch
