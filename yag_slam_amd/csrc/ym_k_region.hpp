@@ -9,12 +9,13 @@
 // They can be: the hypotheses of one beam are every other cell of every other row, i.e. a DENSE 26 x 26 block of bytes
 // in the image of one (column parity, row parity) class of window cells, and the 22 701 patches of an item
 // (1081 beams x 21 angles) lie along the walls.  So
-//   bin_kernel            sorts the (beam, angle) pairs of an item by the 64 x 64-byte REGION of class space their patch
+//   bin_kernel            sorts the (beam, angle) pairs of an item by the 64 x 80-byte REGION of class space their patch
 //                         starts in (key: region, angle), 16-bit entries;
 //   correlate_region_kernel  walks the regions that hold work: copies the region (+ the 26-byte patch margin) of all four
-//                         classes into LDS once -- 36 KB serve ~800 patches of 676 bytes each -- and every wave, which
+//                         classes into LDS once -- 42 KB serve ~1000 patches of 676 bytes each -- and every wave, which
 //                         owns one angle, gathers its patches from there into packed 16-bit sums kept in registers.
-// The sums leave the kernel every YM_RG_FLUSH patches of a wave, in lane order (score_kernel's layout 1).
+// The sums leave the registers every YM_RG_FLUSH patches of a wave, in lane order (score_kernel's layout 1); on batches
+// whose integer sums nobody asked for the wave scores them itself at the end (fuse_score).
 #pragma once
 
 namespace ym {
@@ -47,7 +48,7 @@ struct RegionArgs {
     const double2 *ctrig;   // [B][nt_stride]
     const int32_t *hypcell; // [B][2][dim_stride]
     const YmItemState *states;
-    uint16_t *entries;      // [B][entries_stride]: class | row in region | byte in region (2 + LOG_H + LOG_W bits), sorted by bin
+    uint16_t *entries;      // [B][entries_stride]: LDS offset of the patch's first byte in the staged region, sorted by bin
     size_t entries_stride;
     int32_t *starts;        // [B][starts_stride]: first entry of bin (region * nt + angle); [nbins] = total, or -1: no list
     size_t starts_stride;
