@@ -239,7 +239,9 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * kernel, 2 = the region kernel's per-cell path, 3 = its "entry list does not fit" path); 15: waves per region-correlate
  * block; 16: raster blocks per item on batches (0 = sized by the previous call's longest tile list; the rest of a list is
  * walked by a second, small launch); 17: 2 = the region-staged correlate leaves the scoring of its sums to the score kernel
- * (0: it scores them itself unless option 12 asks for the integer sums). */
+ * (0: it scores them itself unless option 12 asks for the integer sums); 18: room in the raster's per-tile hit lists on
+ * batches, in entries per tile (0 = 32; -1 = no lists: every raster block scans the item's chunk boxes, as it does for an item
+ * whose lists do not fit). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.

@@ -840,15 +840,18 @@ def test_raster_grid_shorter_than_the_tile_list():
     """On batches the raster launches as many blocks per item as the longest tile list of the matcher's previous call
     (+ 1/8); entries beyond the grid are rasterised by a second, small launch that walks them.  Forced grids of 1, 7 and
     40 blocks per item (option 16) and the free-running matcher (first call: one block per tile; later calls: by the
-    hint) must produce the same windows and results."""
+    hint) must produce the same windows and results -- as must every size of the per-tile hit lists."""
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:], nb[5:6]]
     ref = None
-    for gx in (0, 0, 1, 7, 40):
-        m = ScanMatcher() if ref is None or gx else m
+    for gx, hits in ((0, 0), (0, 0), (1, 0), (7, 0), (40, 0), (0, -1), (0, 1), (0, 4)):
+        # (hits: room in the per-tile lists of chunk boxes the tiles kernel builds, option 18; -1 = none, 1 and 4 per tile =
+        # the lists of most / some items do not fit and their raster blocks scan the boxes themselves)
+        m = ScanMatcher() if ref is None or gx or hits else m
         m.debug_option(16, gx)
+        m.debug_option(18, hits)
         per, best = m.match_scan_batch(nq, chains, True, True)
         grids = [m.debug_grid(i)[0] for i in (0, 4, 8)]
         if ref is None:

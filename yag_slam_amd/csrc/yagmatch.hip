@@ -184,6 +184,8 @@ struct CallPlan {
     // raster coverage
     int launch[4] = {0, 0, -1, -1}, ltx = 0, lty = 0, tile_cap = 1;
     bool use_tile_list = false;
+    bool use_tile_hits = false;
+    int hit_cap = 0;
     unsigned long long *stamps = nullptr;
     // batches: heavy work once per distinct scan (points_kernel), then the light cells_kernel
     bool split_prepare = false;
@@ -310,6 +312,8 @@ struct ym_matcher {
     DevBuf<uint16_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
     DevBuf<int32_t> tile_max;        // [1] longest raster work list of the call
+    DevBuf<uint16_t> tile_hits;      // per tile of the raster's rectangle: the chunk boxes that reach it
+    DevBuf<int32_t> tile_hit_start;
     int32_t *tile_max_host = nullptr; // pinned: the raster kernel leaves that number here, the next call sizes its grid by it
     int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
@@ -320,6 +324,7 @@ struct ym_matcher {
     int corr_region_nw = 0; // development: waves (= angles) per region-correlate block
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
     int raster_gx = 0;      // tests: raster blocks per item (0 = by the previous call's longest work list)
+    int raster_hits_per_tile = 0; // tests: room in the per-tile hit lists (0 = 32 per tile, -1 = no lists)
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
@@ -959,6 +964,15 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
         if ((rc = m->tile_list.ensure((size_t)B * P.tile_cap))) return rc;
         if ((rc = m->tile_count.ensure(B))) return rc;
         if ((rc = m->tile_max.ensure(1))) return rc;
+        // hit lists per tile (32 per tile on average is four times what the bench scans need; an item that needs more
+        // is scanned by the raster blocks themselves)
+        P.use_tile_hits = P.max_base * YM_N_BOXES(P.max_n) < 65536 && P.tile_cap <= 8192;
+        P.hit_cap = (m->raster_hits_per_tile > 0 ? m->raster_hits_per_tile : 32) * P.tile_cap;
+        if (m->raster_hits_per_tile < 0) P.use_tile_hits = false;
+        if (P.use_tile_hits) {
+            if ((rc = m->tile_hits.ensure((size_t)B * P.hit_cap))) return rc;
+            if ((rc = m->tile_hit_start.ensure((size_t)B * (P.tile_cap + 1)))) return rc;
+        }
         if (!m->tile_max_host) {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->tile_max_host), sizeof(int32_t), hipHostMallocDefault));
             *m->tile_max_host = 0;
@@ -1030,11 +1044,13 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
         ym::TilesArgs t;
         t.bbox = m->bbox.p; t.tile_list = m->tile_list.p; t.tile_count = m->tile_count.p; t.tile_zero = m->tile_zero.p;
         t.tile_max = m->tile_max.p;
+        t.hits = P.use_tile_hits ? m->tile_hits.p : nullptr; t.hit_start = m->tile_hit_start.p; t.hit_cap = P.hit_cap;
         (void)hipMemsetAsync(m->tile_max.p, 0, sizeof(int32_t), st);
         t.max_n = P.max_n; t.max_base = P.max_base; t.half_kernel = g.half_kernel;
         t.tiles_x = P.tiles_x; t.tiles_y = P.tiles_y; t.tile_cap = P.tile_cap;
         for (int k = 0; k < 4; k++) t.launch[k] = P.launch[k];
-        hipLaunchKernelGGL(ym::tiles_kernel, dim3(P.B), dim3(YM_TILES_THREADS), (size_t)4 * ((P.tiles_x * P.tiles_y + 31) / 32), st, t);
+        hipLaunchKernelGGL(ym::tiles_kernel, dim3(P.B), dim3(YM_TILES_THREADS),
+                           (size_t)4 * ((P.tiles_x * P.tiles_y + 31) / 32) + (P.use_tile_hits ? (size_t)4 * P.tile_cap : 0), st, t);
     }
     ym::RasterArgs a;
     a.tiles_x = P.tiles_x; a.tiles_y = P.tiles_y; a.tile_x0 = P.launch[0]; a.tile_y0 = P.launch[1]; a.ltx = P.ltx;
@@ -1043,6 +1059,7 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
     a.tile_zero = m->tile_zero.p;
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
+    a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.hit_start = m->tile_hit_start.p; a.hit_cap = P.hit_cap; a.lty = P.lty;
     int rc;
     hipEvent_t ev_k = nullptr;
     if ((rc = prof_begin(m, 1, &ev_k))) return rc;
@@ -1473,7 +1490,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->sel_scratch.release();
+    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->tile_hit_start.release(); m->sel_scratch.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
@@ -2170,6 +2187,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 15) m->corr_region_nw = value;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_fuse_score = value;
+    else if (option == 18) m->raster_hits_per_tile = value;
     else if (option == 7) { // point cache: 0 = on (default), 1 = off, 2 = drop every entry now
         m->cache_off = value == 1;
         m->cache_entries.clear();

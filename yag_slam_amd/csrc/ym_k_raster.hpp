@@ -23,6 +23,9 @@ struct RasterArgs {
     const int32_t *tile_count; // [B]
     int32_t tile_cap;
     int32_t first_overflow;    // OVERFLOW launch: the first list entry the main launch's grid did not reach
+    const uint16_t *hits;      // [B][hit_cap] per sub-grid tile the chunk boxes that reach it (tiles_kernel), or null
+    const int32_t *hit_start;  // [B][tile_cap + 1]; [0] = -1: this item has no lists
+    int32_t hit_cap, lty;
     const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
     int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
     unsigned long long *stamps;
@@ -90,7 +93,16 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         if (tid == 0) *tz = 1;
         return;
     }
-    if (tid == 0) s_nhits = 0;
+    // with hit lists (batches) the chunks that reach this tile are known: no scan of the item's boxes
+    const int32_t *hstart = a.hits ? a.hit_start + (size_t)bi * (a.tile_cap + 1) : nullptr;
+    int h0 = 0, hn = -1;
+    if (hstart && hstart[0] >= 0) {
+        const int ti = (tiy - a.tile_y0) * a.ltx + (tix - a.tile_x0);
+        h0 = hstart[ti];
+        hn = hstart[ti + 1] - h0;
+        if (hn > 256) hn = -1; // (more than the list holds: scan)
+    }
+    if (tid == 0) s_nhits = hn >= 0 ? hn : 0;
     if (!listed) { // decide "no box at all" before touching LDS
         int my_hits = 0;
         for (int c = tid; c < n_boxes; c += NT) {
@@ -110,6 +122,15 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         __syncthreads();
     }
     // chunks whose box touches tile + halo, compacted so that the cell loads of several chunks are in flight together
+    if (hn >= 0) {
+        const uint16_t *hl = a.hits + (size_t)bi * a.hit_cap + h0;
+        for (int i = tid; i < hn; i += NT) {
+            const int c = hl[i];
+            const int slot = c / n_cchunks, first = (c - slot * n_cchunks) * YM_BOX_CELLS;
+            s_hits[i] = slot * a.max_n + first;
+            s_left[i] = a.max_n - first;
+        }
+    } else
     for (int c = tid; c < n_boxes; c += NT) {
         const int4 bb = bbox[c];
         if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
