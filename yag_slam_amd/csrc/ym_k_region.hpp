@@ -287,7 +287,8 @@ __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
-        acc[2 * j + 1] = acc[2 * j + 1] + __builtin_amdgcn_perm(0u, x[0][j], 0x0c030c01u) + __builtin_amdgcn_perm(0u, x[1][j], 0x0c030c01u);
+        if (j < 3) // (acc[7] would hold hypotheses 13 and 15 of the lane: there are only 13)
+            acc[2 * j + 1] = acc[2 * j + 1] + __builtin_amdgcn_perm(0u, x[0][j], 0x0c030c01u) + __builtin_amdgcn_perm(0u, x[1][j], 0x0c030c01u);
     }
 }
 
