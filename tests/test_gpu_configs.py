@@ -205,3 +205,46 @@ def test_angle_sliced_match_equals_the_whole_match(which):
     finally:
         dist.destroy_process_group()
 
+
+
+def test_cfg2_batch_512_distinct_chains_region_correlate_against_direct_and_oracle():
+    """The bench's metric workload in small: the cfg2 query against 512 distinct 10-scan chains (the bench's own noisy
+    copies of the base scans, seeds 100000 + chain) in ONE enqueue, penalty and refinement on.  Batches of this lattice take
+    the region-staged correlate with its own scoring; every one of the 512 results must be the direct correlate's
+    (option 14 = 1), bit for bit, a seeded sample of 24 chains the oracle's, and the same call in two enqueues of 256 the
+    same again (workspace items reused by other chains)."""
+    from oracle import oracle as orc
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n_chains = 512
+    scene = synth.Scene()
+    q, _ = synth.single_match_scans(scene)
+    base_poses, q_truth, q_prior = synth.single_match_poses()
+    exact = [scene.cast(*p) for p in base_poses]
+    chains = []
+    for c in range(n_chains):
+        rng = np.random.default_rng(100000 + c)
+        chains.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
+    m = ScanMatcher()
+    per, best = m.match_scan_batch(q, chains, True, True)
+    assert len(per) == n_chains and all(tuple(p.meta["coarse_dims"]) == (26, 26, 21) for p in per)
+    md = ScanMatcher()
+    md.debug_option(14, 1)
+    perd, bestd = md.match_scan_batch(q, chains, True, True)
+    assert best == bestd == int(np.argmax([p.response for p in per]))
+    for a, b in zip(per, perd):
+        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+    o = orc.Oracle(None, "karto")
+    pq = _plain(q)
+    for c in sorted(np.random.default_rng(512).choice(n_chains, size=24, replace=False).tolist()):
+        ro = o.match_scan(pq, [_plain(s) for s in chains[c]], True, True)
+        r = per[c]
+        assert abs(r.response - ro["response"]) <= 1e-12, (c, r.response, ro["response"])
+        bp = r.best_pose
+        np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], ro["pose"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
+        assert r.meta["hypotheses"] == ro["hypotheses"] and r.meta["expansions"] == ro["expansions"]
+    for lo in (256, 0):
+        half, _ = m.match_scan_batch(q, chains[lo:lo + 256], True, True)
+        assert all(a.response == b.response and a.covariance == b.covariance for a, b in zip(per[lo:lo + 256], half))
