@@ -214,50 +214,14 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
 
 // The 16 bytes at LDS byte address `addr` (any alignment): two ds_read2_b32 at the dword below + a byte funnel.
 // (A ds_read_b128 at a 4-byte-aligned address is legal on gfx950 but takes 64 clk per wave, lds_gather.hip.)
-// Issue and wait are ONE asm statement: the outputs of an asm that only issues a read are not valid when the statement
-// ends, and the compiler is free to copy them right there.
+// The registers an asm statement that only ISSUES a read names as outputs are not written when the statement ends, and
+// the compiler is free to copy them right there (seen: wrong sums): every such register is either waited for inside
+// the issuing statement or passes through the statement that waits for it ("+v") before anything else touches it.
 typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void rg_read4(const uint32_t (&ad)[4], uint32_t (&w)[4][4]) {
-    rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
-    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"
-                 "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"
-                 "ds_read2_b32 %4, %10 offset1:1\n\tds_read2_b32 %5, %10 offset0:2 offset1:3\n\t"
-                 "ds_read2_b32 %6, %11 offset1:1\n\tds_read2_b32 %7, %11 offset0:2 offset1:3\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
-                 : "v"(ad[0] & ~3u), "v"(ad[1] & ~3u), "v"(ad[2] & ~3u), "v"(ad[3] & ~3u)
-                 : "memory");
-    w[0][0] = p0.x; w[0][1] = p0.y; w[0][2] = q0.x; w[0][3] = q0.y;
-    w[1][0] = p1.x; w[1][1] = p1.y; w[1][2] = q1.x; w[1][3] = q1.y;
-    w[2][0] = p2.x; w[2][1] = p2.y; w[2][2] = q2.x; w[2][3] = q2.y;
-    w[3][0] = p3.x; w[3][1] = p3.y; w[3][2] = q3.x; w[3][3] = q3.y;
-}
-// Four patches (their LDS origins arrive in scalar registers: the entry list is read with scalar loads) into the packed 16-bit sums (acc[2j]:
-// hypotheses 4j, 4j + 2; acc[2j + 1]: 4j + 1, 4j + 3).  Patches 2i and 2i + 1 share their misalignment (bin_kernel): grid
+// Four patches (their LDS origins: four 16-bit entries, the same in every lane -- a broadcast read of the wave's entry list)
+// into the packed 16-bit sums (acc[2j]: hypotheses 4j, 4j + 2; acc[2j + 1]: 4j + 1, 4j + 3).  Patches 2i and 2i + 1 share their misalignment (bin_kernel): grid
 // bytes are at most 100, so their RAW dwords add without carries and one funnel serves both; the two funnelled pair sums
 // are split into even / odd bytes and added with one v_add3 each.
-__device__ __forceinline__ void rg_read2(uint32_t ad0, uint32_t ad1, uint32_t (&w)[2][4]) {
-    rg_u32x2 p0, q0, p1, q1;
-    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %4 offset0:2 offset1:3\n\t"
-                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read2_b32 %3, %5 offset0:2 offset1:3\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1) : "v"(ad0 & ~3u), "v"(ad1 & ~3u) : "memory");
-    w[0][0] = p0.x; w[0][1] = p0.y; w[0][2] = q0.x; w[0][3] = q0.y;
-    w[1][0] = p1.x; w[1][1] = p1.y; w[1][2] = q1.x; w[1][3] = q1.y;
-}
-// one pair of patches with equal misalignment: raw dwords added, one funnel
-__device__ __forceinline__ void rg_pair(uint32_t lane_off, uint32_t e2 /* two 16-bit origins */, uint32_t (&x)[4]) {
-    const uint32_t ad0 = lane_off + (e2 & 0xffffu), ad1 = lane_off + (e2 >> 16);
-    uint32_t w[2][4], s[4];
-    rg_read2(ad0, ad1, w);
-    const uint32_t rr = ad0 & 3u;
-#pragma unroll
-    for (int j = 0; j < 4; j++) s[j] = w[0][j] + w[1][j];
-    x[0] = __builtin_amdgcn_alignbyte(s[1], s[0], rr);
-    x[1] = __builtin_amdgcn_alignbyte(s[2], s[1], rr);
-    x[2] = __builtin_amdgcn_alignbyte(s[3], s[2], rr);
-    x[3] = __builtin_amdgcn_alignbyte(0u, s[3], rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
-}
 __device__ __forceinline__ void rg_funnel_pair(const rg_u32x2 &pa, const rg_u32x2 &qa, const rg_u32x2 &pb, const rg_u32x2 &qb, uint32_t rr,
                                                uint32_t (&x)[4]) {
     const uint32_t s0 = pa.x + pb.x, s1 = pa.y + pb.y, s2 = qa.x + qb.x, s3 = qa.y + qb.y; // raw dwords of two patches: bytes <= 200
