@@ -198,6 +198,9 @@ struct CallPlan {
 
 struct Slot {
     PinnedBuf desc;    // YmScanRef[] + YmItem[] staged for the H2D copy
+    DevBuf<unsigned char> desc_dev;         // the slot's descriptor on the device ...
+    std::vector<unsigned char> desc_shadow; // ... and what was last copied there: a call whose descriptor is byte for byte
+                                            // the slot's previous one (the same resident batch again) skips the 4 MB copy
     PinnedBuf result;  // YmItemState[] landed by the D2H copy
     hipEvent_t done = nullptr;
     bool in_flight = false;
@@ -884,11 +887,19 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
     }
     P.inline_desc = (P.B == 1 && P.nscans <= YM_INLINE_SCANS && !P.split_prepare);
     if (!P.inline_desc) {
-        if ((rc = m->desc_dev.ensure(P.desc_bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(m->desc_dev.p, slot.desc.p, P.desc_bytes, hipMemcpyHostToDevice, m->stream));
-        P.d_scans = reinterpret_cast<const YmScanRef *>(m->desc_dev.p);
-        P.d_items = reinterpret_cast<const YmItem *>(m->desc_dev.p + P.scans_bytes);
-        P.d_jobs = reinterpret_cast<const int32_t *>(m->desc_dev.p + P.scans_bytes + items_bytes);
+        // (the slot's previous call is complete -- a slot is handed out again only after it was collected -- so both its
+        //  pinned buffer and its device copy are free to be rewritten)
+        const bool same = slot.desc_dev.p && slot.desc_shadow.size() == P.desc_bytes &&
+                          std::memcmp(slot.desc_shadow.data(), slot.desc.p, P.desc_bytes) == 0;
+        if (!same) {
+            slot.desc_shadow.clear();
+            if ((rc = slot.desc_dev.ensure(P.desc_bytes))) return rc;
+            HIP_TRY(hipMemcpyAsync(slot.desc_dev.p, slot.desc.p, P.desc_bytes, hipMemcpyHostToDevice, m->stream));
+            if (P.desc_bytes >= (size_t)1 << 16) slot.desc_shadow.assign(slot.desc.p, slot.desc.p + P.desc_bytes); // (small ones: just copy)
+        }
+        P.d_scans = reinterpret_cast<const YmScanRef *>(slot.desc_dev.p);
+        P.d_items = reinterpret_cast<const YmItem *>(slot.desc_dev.p + P.scans_bytes);
+        P.d_jobs = reinterpret_cast<const int32_t *>(slot.desc_dev.p + P.scans_bytes + items_bytes);
         P.d_job_slot = P.d_jobs + P.n_jobs;
     }
     return YM_OK;
@@ -1497,6 +1508,7 @@ void ym_destroy(ym_matcher *m) {
     m->tmp_ranges_host.release(); m->kernel_f_dev.release(); m->map_pts.release(); m->cache_arena.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
     for (Slot &s : m->slots) {
         s.desc.release();
+        s.desc_dev.release();
         s.result.release();
         if (s.done) (void)hipEventDestroy(s.done);
     }
