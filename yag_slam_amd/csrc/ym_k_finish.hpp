@@ -26,22 +26,30 @@ struct ScoreArgs {
     unsigned long long *stamps;
 };
 
-__device__ __forceinline__ double hyp_response(const YmGeom &g, int penalize, unsigned sum, int nq, double sq_dist,
-                                               double angle, double center_t) {
+// Karto's distance penalty of a lattice cell (CorrelateScan): depends on the cell only
+__device__ __forceinline__ double dist_penalty(const YmGeom &g, double sq_dist) {
+    double dp = 1.0 - (YM_PENALTY_GAIN * sq_dist / g.dist_var);
+    return dp > g.min_dist_pen ? dp : g.min_dist_pen;
+}
+// response of one hypothesis from its integer sum, with the cell's distance penalty already known
+__device__ __forceinline__ double hyp_response_dp(const YmGeom &g, int penalize, unsigned sum, int nq, double dp,
+                                                  double angle, double center_t) {
     double response = 0.0;
     if (nq != 0) {
         response = (double)sum;
         response /= (double)(nq * YM_OCCUPIED);
     }
     if (penalize && !kt_double_equal(response, 0.0)) {
-        double dp = 1.0 - (YM_PENALTY_GAIN * sq_dist / g.dist_var);
-        dp = dp > g.min_dist_pen ? dp : g.min_dist_pen;
         const double sq_ang = (angle - center_t) * (angle - center_t);
         double ap = 1.0 - (YM_PENALTY_GAIN * sq_ang / g.ang_var);
         ap = ap > g.min_ang_pen ? ap : g.min_ang_pen;
         response *= (dp * ap);
     }
     return response;
+}
+__device__ __forceinline__ double hyp_response(const YmGeom &g, int penalize, unsigned sum, int nq, double sq_dist,
+                                               double angle, double center_t) {
+    return hyp_response_dp(g, penalize, sum, nq, dist_penalty(g, sq_dist), angle, center_t);
 }
 
 // One thread per (x, y) lattice cell, walking the coarse angles [k_begin, k_end): add the chunk-group partials,

@@ -456,8 +456,15 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     // through LDS (the region buffer is free now) so that only one atomic per cell and block reaches memory
     unsigned long long *pmax = reinterpret_cast<unsigned long long *>(region); // [ny * nx] fp64 bit patterns, >= 0
     const int nxy = nx * ny;
+    double *dpen = reinterpret_cast<double *>(region) + ((nxy + 1) & ~1); // [ny * nx] distance penalty of every cell: once
+                                                                           // per block, not once per wave (an fp64 division)
     __syncthreads(); // every wave has left the region walk
-    for (int i = tid; i < nxy; i += NT) pmax[i] = 0ull;
+    for (int i = tid; i < nxy; i += NT) {
+        pmax[i] = 0ull;
+        const int iy = i / nx, ix = i - iy * nx;
+        const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
+        dpen[i] = dist_penalty(a.g, x * x + y * y);
+    }
     __syncthreads();
     if (kvalid) {
         unsigned tot[YM_RG_G];
@@ -471,7 +478,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         const double ct = st.center[2];
         const int nq = st.nq;
         const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
-        const double y = -a.lat.off_y + row * a.lat.step_y;
         const int ncb = (nxy + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
         double bmax0 = -1.0, bmax1 = -1.0; // block maxima this lane contributes to (its 13 cells span at most 2 blocks)
         const int c0 = row * nx + half * YM_RG_G, cb0 = job ? c0 / YM_SCORE_THREADS : 0;
@@ -479,9 +485,8 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         for (int j = 0; j < YM_RG_G; j++) {
             const int ix = half * YM_RG_G + j;
             if (job && ix < nx) {
-                const double x = -a.lat.off_x + ix * a.lat.step_x;
-                const double r = hyp_response(a.g, a.lat.penalize, tot[j], nq, x * x + y * y, angle, ct);
                 const int c = row * nx + ix;
+                const double r = hyp_response_dp(a.g, a.lat.penalize, tot[j], nq, dpen[c], angle, ct);
                 a.resp[(size_t)b * a.sums_stride + (size_t)k * nxy + c] = r;
                 if (c / YM_SCORE_THREADS == cb0) bmax0 = r > bmax0 ? r : bmax0;
                 else bmax1 = r > bmax1 ? r : bmax1;
