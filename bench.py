@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
     ap.add_argument("--corr-chunks", type=int, default=0, help="development: beam chunks per angle in the correlate kernel")
     ap.add_argument("--corr-region", type=int, default=0, help="development: 1 = direct correlate on batches too")
-    ap.add_argument("--corr-region-nw", type=int, default=0, help="development: waves per region-correlate block")
+    ap.add_argument("--corr-region-na", type=int, default=0, help="development: jobs per wave of the gather correlate")
     ap.add_argument("--corr-pad-lds", type=int, default=0, help="development: extra LDS bytes per correlate block")
     return ap.parse_args(argv)
 
@@ -385,8 +385,8 @@ def main():
         m.debug_option(4, args.corr_pad_lds)
     if args.corr_region:
         m.debug_option(14, args.corr_region)
-    if args.corr_region_nw:
-        m.debug_option(15, args.corr_region_nw)
+    if args.corr_region_na:
+        m.debug_option(15, args.corr_region_na)
 
     def barrier():
         torch.cuda.synchronize()

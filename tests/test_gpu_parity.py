@@ -786,21 +786,30 @@ def test_merged_equal_offsets_are_exact():
 
 
 def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
-    """Batches of 8+ items on lattices up to 26 x 32 gather their patches from LDS, region by region
-    (correlate_region_kernel + bin_kernel).  The integer sum volumes of every item must be those of the direct
-    correlate kernel (option 14 = 1) -- also through the region kernel's per-cell path (= 2, what an item with a
-    non-lattice hypothesis grid takes) and its "entry list does not fit" path (= 3) -- for the default lattice, a
-    lattice of one lane per row (nx = 13), ragged queries (1081 / 707 / 400 valid beams: two beam groups, a ragged
-    second group, one group) and ragged and reversed chains; and equal to the oracle's."""
+    """Batches of 8+ items on lattices up to 48 x 64 gather their patches from LDS, region by region (gather_kernel + the
+    gbin kernels that sort a query's (beam, angle) pairs once per call).  The integer sum volumes of every item must be
+    those of the direct correlate kernel (option 14 = 1) -- also through the gather kernel's per-cell path (= 2, what an
+    item with a non-lattice hypothesis grid takes) and its "lists do not fit" path (= 3) -- for the default lattice, a
+    lattice of one lane per row (nx = 13), ragged queries (1081 / 707 / 400 valid beams: a set of 16-bit sums written out
+    mid-way, or none) and ragged and reversed chains; and equal to the oracle's.  Then the same with the work forced into
+    other shapes: the angles of an item shared out over 1, 2, 3 and 21 blocks (option 17), 1 to 4 jobs per wave (15), regions
+    cut into chunks of 64 units (19), and an LDS budget that makes the regions small (20)."""
     from oracle import oracle as orc
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     cut = lambda s, n: PlainScan(s.ranges[:n], s.min_angle, s.angle_increment, s.min_range, 20.0, (3.0, 3.0, 0.0))
     q707, q400 = cut(q, 707), cut(q, 400)
-    narrow = {"search_size": 0.24}  # 13 x 13 x 21: the second lane of every lattice row idles
+    narrow = {"search_size": 0.24}  # 13 x 13 x 21: one lane per lattice row
     chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:], nb[5:6]]  # (no empty chain: its response
     # expansion would be the last call, and debug_sums reads the last call)
+
+    def same(a, b):
+        for x, y in zip(a[1], b[1]):
+            assert x.response == y.response and x.covariance == y.covariance and x.meta == y.meta
+            assert (x.best_pose.x, x.best_pose.y, x.best_pose.euler[-1]) == (y.best_pose.x, y.best_pose.y, y.best_pose.euler[-1])
+        assert a[2] == b[2]
+
     for cfg, queries in ((None, (q, q707, q400)), (narrow, (q,))):
         for query in queries:
             nquery = _mk_native(query)
@@ -815,25 +824,30 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             for mode in (0, 2, 3):
                 for i in range(len(chains)):
                     assert np.array_equal(vols[mode][0][i], vols[1][0][i]), (mode, i)
-                for a, b in zip(vols[mode][1], vols[1][1]):
-                    assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
-                    assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
-                assert vols[mode][2] == vols[1][2]
+                same(vols[mode], vols[1])
             assert vols[0][0][0].any()
-            # without the kept sums the region kernel also scores them itself (responses, block maxima, per-cell maxima
-            # through LDS); option 17 = 2 leaves that to the score kernel: identical results either way
-            res = []
-            for fuse in (0, 2):
-                m = ScanMatcher(cfg)
-                m.debug_option(17, fuse)
-                res.append(m.match_scan_batch(nquery, chains, True, True))
-            for a, b, c in zip(res[0][0], res[1][0], vols[1][1]):
-                assert a.response == b.response == c.response and a.covariance == b.covariance == c.covariance
-                assert a.meta == b.meta == c.meta
-            assert res[0][1] == res[1][1] == vols[1][2]
+            # without the kept sums (the production form)
+            m = ScanMatcher(cfg)
+            res = m.match_scan_batch(nquery, chains, True, True)
+            same((None,) + tuple(res), vols[1])
             o = orc.Oracle(cfg, "karto")
             o.match_scan(query, base, True, True)
             assert np.array_equal(vols[0][0][0], o.sums(0))
+    ref = None
+    for opts in ({}, {17: 1}, {17: 2}, {17: 3}, {17: 21}, {15: 1, 17: 2}, {15: 2}, {15: 4}, {19: 64}, {20: 20000}, {20: 12000, 19: 64, 17: 2}):
+        m = ScanMatcher()
+        m.debug_option(12, 1)
+        for k, v in opts.items():
+            m.debug_option(k, v)
+        per, best = m.match_scan_batch(nq, chains, True, True)
+        dims = per[0].meta["coarse_dims"]
+        got = ([m.debug_sums(0, item=i, dims=dims) for i in range(len(chains))], per, best)
+        if ref is None:
+            ref = got
+            continue
+        for a, b in zip(got[0], ref[0]):
+            assert np.array_equal(a, b), opts
+        same(got, ref)
 
 
 def test_raster_grid_shorter_than_the_tile_list():
@@ -864,15 +878,15 @@ def test_raster_grid_shorter_than_the_tile_list():
             assert np.array_equal(g, r)
 
 
-@pytest.mark.parametrize("nx", [3, 7, 12, 13, 14, 15, 21, 25, 26])
+@pytest.mark.parametrize("nx", [3, 7, 13, 16, 17, 26, 27, 32, 33, 41, 47])
 def test_region_correlate_lattice_widths(nx):
-    """The region correlate splits a lattice row into two lanes of 13 hypotheses: every width from one short lane to
-    two full ones (and the first width that needs the second lane), sums against the direct kernel, results with the
-    fused scoring against single calls."""
+    """The gather correlate gives a lane 16 x-adjacent hypotheses of one lattice row, a wave up to 32 rows of two such
+    segments; lattices past 32 rows or two segments take two or three waves per angle: every shape from one short lane to
+    three full segments over 47 rows, sums against the direct kernel, results against single calls."""
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
-    cfg = {"search_size": (nx - 1) * 0.02, "coarse_search_angle_offset": 0.07 if nx < 13 else 0.349}
+    cfg = {"search_size": (nx - 1) * 0.02, "coarse_search_angle_offset": 0.07 if (nx < 13 or nx > 33) else 0.349}
     chains = [nb, nb[:4], nb[3:], nb[::-1], nb[2:7], nb[5:], nb[:8], nb[1:9]]
     vols = []
     for mode in (0, 1):
@@ -891,3 +905,39 @@ def test_region_correlate_lattice_widths(nx):
     for a, b in zip(per, singles):
         assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
     assert best == int(np.argmax([s.response for s in singles]))
+
+
+def test_region_correlate_on_the_loop_config_with_multiplicities():
+    """BASELINE configs[3]'s lattice (41 x 41 x 21 on 5 cm cells): two waves per angle, and neighbouring beams fall into one
+    cell, so the lists hold patches with multiplicities 1..4 and more (runs of 5+ beams are cut).  Sum volumes of a batch
+    against the direct kernel with and without its own run merging, against the oracle, and with the gather's work forced
+    into other shapes; a short-range query (runs of 10+ beams per cell) as well."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    near = PlainScan(np.minimum(q.ranges, 0.6), q.min_angle, q.angle_increment, q.min_range, 20.0, (3.0, 3.0, 0.0))
+    chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:]]
+    for query in (q, near):
+        nquery = _mk_native(query)
+        ref = None
+        for opts in ({14: 1, 13: 2}, {14: 1, 13: 1}, {}, {14: 2}, {17: 2}, {17: 3, 15: 1}, {19: 64}, {20: 30000}):
+            m = ScanMatcher(None, loop=True)
+            m.debug_option(12, 1)
+            for k, v in opts.items():
+                m.debug_option(k, v)
+            per, best = m.match_scan_batch(nquery, chains, False, False)
+            dims = per[0].meta["coarse_dims"]
+            assert tuple(dims) == (41, 41, 21)
+            got = ([m.debug_sums(0, item=i, dims=dims) for i in range(len(chains))], per, best)
+            if ref is None:
+                ref = got
+                continue
+            for a, b in zip(got[0], ref[0]):
+                assert np.array_equal(a, b), opts
+            for x, y in zip(got[1], ref[1]):
+                assert x.response == y.response and x.covariance == y.covariance and x.meta == y.meta, opts
+            assert got[2] == ref[2]
+        o = orc.Oracle(None, "karto", loop=True)
+        o.match_scan(query, base, False, False)
+        assert np.array_equal(ref[0][0], o.sums(0))
