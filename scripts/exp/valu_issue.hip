@@ -3,7 +3,7 @@
 // SIMD?  (DESIGN.md priced the region correlate against 1.0 per CU and clock; MI355X_MICROARCH.md says four SIMD-32,
 // i.e. 2.0 for v_fma_f32.)  Every kernel is a loop of 64 independent instructions of ONE opcode over eight destination
 // registers; all 256 CUs run it, with 1, 2, 4 or 8 waves per SIMD.  Reported: wave-instructions per CU and shader clock
-// (s_memtime ticks of the slowest wave) and the clock the chip held (s_memtime / s_memrealtime).
+// (wall time of the launch by HIP events x the clock the chip held, s_memtime / s_memrealtime inside the kernel).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -102,6 +102,39 @@ __global__ __launch_bounds__(1024) void k_mix(uint32_t *out, int iters, unsigned
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
 }
 
+// scalar-ALU streams: 64 independent s_add_u32 / s_and_b32 / s_bfe_u32 on eight SGPRs; and a stream that alternates one
+// scalar and one vector instruction (do they issue side by side?)
+#define DEFINE_SKERNEL(NAME, INSTR, NV)                                                                                    \
+    __global__ __launch_bounds__(1024) void k_##NAME(uint32_t *out, int iters, unsigned long long *ticks) {              \
+        uint32_t r0 = blockIdx.x, r1 = r0 * 3u, r2 = r0 * 5u, r3 = r0 * 7u, r4 = r0 * 11u, r5 = r0 * 13u, r6 = r0 * 17u,   \
+                 r7 = r0 * 19u;                                                                                            \
+        uint32_t v0 = threadIdx.x, v1 = v0 * 3u, v2 = v0 * 5u, v3 = v0 * 7u, v4 = v0 * 11u, v5 = v0 * 13u, v6 = v0 * 17u, v7 = v0 * 19u; \
+        uint32_t a = 0x00ff00ffu + blockIdx.x;                                                                             \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                        \
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();                                                    \
+        for (int i = 0; i < iters; i++) {                                                                                  \
+            asm volatile(BODY64(INSTR)                                                                                     \
+                         : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3), "+s"(r4), "+s"(r5), "+s"(r6), "+s"(r7), "+v"(v0), "+v"(v1), \
+                           "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)                                      \
+                         : "s"(a) : "scc");                                                                                \
+        }                                                                                                                  \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                        \
+        const unsigned long long w1 = __builtin_amdgcn_s_memrealtime();                                                    \
+        if ((threadIdx.x & 63) == 0) {                                                                                     \
+            const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                         \
+            ticks[2 * w] = t1 - t0;                                                                                        \
+            ticks[2 * w + 1] = w1 - w0;                                                                                    \
+        }                                                                                                                  \
+        out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7 ^ v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7; \
+    }
+#define S_ADD(i) "s_add_u32 %" #i ", %" #i ", %16\n\t"
+#define S_AND(i) "s_and_b32 %" #i ", %" #i ", %16\n\t"
+#define S_BFE(i) "s_bfe_u32 %" #i ", %" #i ", 0x80008\n\t"
+#define S_V_PAIR(i) "s_add_u32 %" #i ", %" #i ", %16\n\tv_add_u32 %1" #i ", %1" #i ", %16\n\t"
+DEFINE_SKERNEL(s_add, S_ADD, 0)
+DEFINE_SKERNEL(s_and, S_AND, 0)
+DEFINE_SKERNEL(s_bfe, S_BFE, 0)
+
 typedef void (*kern_t)(uint32_t *, int, unsigned long long *);
 struct Entry { const char *name; kern_t k; int per_iter; };
 
@@ -113,6 +146,7 @@ int main(int argc, char **argv) {
         {"v_and_or_b32", k_and_or, 64}, {"v_bfe_u32", k_bfe, 64}, {"v_add_u32_sdwa(byte)", k_add_u32_sdwa, 64},
         {"v_add_u16_sdwa(byte->word1,preserve)", k_add_u16_sdwa, 64}, {"v_dot4_u32_u8", k_dot4_u32_u8, 64}, {"v_sad_u8", k_sad_u8, 64},
         {"v_mov_b32_dpp", k_mov_dpp, 64}, {"v_lshrrev_b32", k_lshrrev, 64}, {"region-correlate mix (6 ops)", k_mix, 48},
+        {"s_add_u32 (scalar)", k_s_add, 64}, {"s_and_b32 (scalar)", k_s_and, 64}, {"s_bfe_u32 (scalar)", k_s_bfe, 64},
     };
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -129,18 +163,24 @@ int main(int argc, char **argv) {
         double ghz = 0;
         for (int wps : {1, 2, 4, 8}) {
             const int threads = wps >= 4 ? 1024 : 256 * wps, blocks = cus * (wps == 8 ? 2 : 1);
-            for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, iters, ticks);
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, iters, ticks);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, iters, ticks);
+            hipEventRecord(e1, 0);
             hipDeviceSynchronize();
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            hipEventDestroy(e0); hipEventDestroy(e1);
             const size_t nw = (size_t)blocks * threads / 64;
             hipMemcpy(h.data(), ticks, nw * 16, hipMemcpyDeviceToHost);
-            std::vector<unsigned long long> t(nw);
             double sum_t = 0, sum_w = 0;
-            for (size_t i = 0; i < nw; i++) { t[i] = h[2 * i]; sum_t += (double)h[2 * i]; sum_w += (double)h[2 * i + 1]; }
-            std::sort(t.begin(), t.end());
-            const double med = (double)t[nw / 2];
-            // waves per CU x instructions per wave / clocks the median wave took (all waves of a CU run concurrently)
-            printf(" %10.3f", (double)(4 * wps) * e.per_iter * iters / med);
-            if (wps == 4) ghz = sum_t / sum_w * 0.1;
+            for (size_t i = 0; i < nw; i++) { sum_t += (double)h[2 * i]; sum_w += (double)h[2 * i + 1]; }
+            const double clock_hz = sum_t / sum_w * 1e8; // shader clocks per 100 MHz tick, averaged over the waves
+            // all instructions of the launch / (wall time of the launch in shader clocks x CUs)
+            printf(" %10.3f", (double)nw * e.per_iter * iters / (ms * 1e-3 * clock_hz * cus));
+            if (wps == 4) ghz = clock_hz * 1e-9;
         }
         printf("   %.2f\n", ghz);
     }

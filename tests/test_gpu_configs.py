@@ -228,13 +228,14 @@ def test_cfg2_batch_512_distinct_chains_region_correlate_against_direct_and_orac
     m = ScanMatcher()
     per, best = m.match_scan_batch(q, chains, True, True)
     assert len(per) == n_chains and all(tuple(p.meta["coarse_dims"]) == (26, 26, 21) for p in per)
-    md = ScanMatcher()
-    md.debug_option(14, 1)
-    perd, bestd = md.match_scan_batch(q, chains, True, True)
-    assert best == bestd == int(np.argmax([p.response for p in per]))
-    for a, b in zip(per, perd):
-        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
-        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+    for mode in (1, 4):  # the direct kernel; the general gather correlate
+        md = ScanMatcher()
+        md.debug_option(14, mode)
+        perd, bestd = md.match_scan_batch(q, chains, True, True)
+        assert best == bestd == int(np.argmax([p.response for p in per]))
+        for a, b in zip(per, perd):
+            assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+            assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
     o = orc.Oracle(None, "karto")
     pq = _plain(q)
     for c in sorted(np.random.default_rng(512).choice(n_chains, size=24, replace=False).tolist()):

@@ -786,14 +786,15 @@ def test_merged_equal_offsets_are_exact():
 
 
 def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
-    """Batches of 8+ items on lattices up to 48 x 64 gather their patches from LDS, region by region (gather_kernel + the
-    gbin kernels that sort a query's (beam, angle) pairs once per call).  The integer sum volumes of every item must be
-    those of the direct correlate kernel (option 14 = 1) -- also through the gather kernel's per-cell path (= 2, what an
-    item with a non-lattice hypothesis grid takes) and its "lists do not fit" path (= 3) -- for the default lattice, a
-    lattice of one lane per row (nx = 13), ragged queries (1081 / 707 / 400 valid beams: a set of 16-bit sums written out
-    mid-way, or none) and ragged and reversed chains; and equal to the oracle's.  Then the same with the work forced into
-    other shapes: the angles of an item shared out over 1, 2, 3 and 21 blocks (option 17), 1 to 4 jobs per wave (15), regions
-    cut into chunks of 64 units (19), and an LDS budget that makes the regions small (20)."""
+    """Batches of 8+ items gather their patches from LDS, region by region: correlate_region_kernel + bin_kernel on lattices
+    up to 26 x 32, gather_kernel + the gbin kernels on other lattices up to 48 x 64 -- and, forced by option 14 = 4, here too;
+    both sort a query's (beam, angle) pairs once per call.  The integer sum volumes of every item must be those of the
+    direct correlate kernel (option 14 = 1) -- also through the per-cell path (= 2, what an item with a non-lattice
+    hypothesis grid takes) and the "lists do not fit" path (= 3) -- for the default lattice, a lattice of one lane per row
+    (nx = 13), ragged queries (1081 / 707 / 400 valid beams: a set of 16-bit sums written out mid-way, or none) and ragged
+    and reversed chains; and equal to the oracle's.  Then the gather kernel with its work forced into other shapes: the
+    angles of an item shared out over 1, 2, 3 and 21 blocks (option 17), 1 to 4 angles per wave (15), regions cut into chunks
+    of 64 units (19), an LDS budget that makes the regions small (20), its per-cell kernel."""
     from oracle import oracle as orc
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()
@@ -814,29 +815,34 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
         for query in queries:
             nquery = _mk_native(query)
             vols = {}
-            for mode in (0, 1, 2, 3):
+            for mode in (0, 1, 2, 3, 4):
                 m = ScanMatcher(cfg)
                 m.debug_option(12, 1)  # keep the integer sums of batches
                 m.debug_option(14, mode)
                 per, best = m.match_scan_batch(nquery, chains, True, True)
                 dims = per[0].meta["coarse_dims"]
                 vols[mode] = ([m.debug_sums(0, item=i, dims=dims) for i in range(len(chains))], per, best)
-            for mode in (0, 2, 3):
+            for mode in (0, 2, 3, 4):
                 for i in range(len(chains)):
                     assert np.array_equal(vols[mode][0][i], vols[1][0][i]), (mode, i)
                 same(vols[mode], vols[1])
             assert vols[0][0][0].any()
-            # without the kept sums (the production form)
-            m = ScanMatcher(cfg)
-            res = m.match_scan_batch(nquery, chains, True, True)
-            same((None,) + tuple(res), vols[1])
+            # without the kept sums (the production form: the region correlate scores its sums itself; option 21 = 2 leaves
+            # that to the score kernel), through either kernel
+            for opts in ({}, {21: 2}, {14: 4}):
+                m = ScanMatcher(cfg)
+                for k, v in opts.items():
+                    m.debug_option(k, v)
+                res = m.match_scan_batch(nquery, chains, True, True)
+                same((None,) + tuple(res), vols[1])
             o = orc.Oracle(cfg, "karto")
             o.match_scan(query, base, True, True)
             assert np.array_equal(vols[0][0][0], o.sums(0))
     ref = None
-    for opts in ({}, {17: 1}, {17: 2}, {17: 3}, {17: 21}, {15: 1, 17: 2}, {15: 2}, {15: 4}, {19: 64}, {20: 20000}, {20: 12000, 19: 64, 17: 2}):
+    for opts in ({}, {17: 1}, {17: 2}, {17: 3}, {17: 21}, {15: 1, 17: 2}, {15: 2}, {15: 4}, {19: 64}, {20: 30000}, {20: 20000, 19: 64, 17: 2}):
         m = ScanMatcher()
         m.debug_option(12, 1)
+        m.debug_option(14, 4)
         for k, v in opts.items():
             m.debug_option(k, v)
         per, best = m.match_scan_batch(nq, chains, True, True)

@@ -163,7 +163,13 @@ struct CallPlan {
     int sx = 2, ngx = 0, nx_pad = 0, njobs = 0, tpb = 1, job_blocks = 0, ktiles = 0, n_chunks = 1, chunk = 0, corr_u = 16;
     int dedup = 0;            // merge consecutive beams with equal lookup offsets (coarse grids)
     int cw = 1, n_groups = 1; // chunk-waves per correlate block, chunk groups (= partial sums per hypothesis)
-    // batches on lattices up to 48 x 64: the LDS gather correlate (ym_k_gather.hpp), which also scores its sums
+    // batches on the default-sized lattices (up to 26 x 32): the region-staged correlate (ym_k_region.hpp)
+    bool region26 = false;
+    bool fuse_score = false;  // ... also scores (no score_kernel launch)
+    int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1;
+    size_t rg_entries_stride = 0, rg_starts_stride = 0;
+    // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
+    // always scores its sums
     bool region = false;
     int ga_W = 0, ga_H = 0, ga_P = 0, ga_rows = 0, ga_nrx = 0, ga_nry = 0, ga_nseg = 1, ga_np = 1, ga_ng = 1, ga_parts = 1, ga_kpp = 1;
     int ga_na = 1, ga_nwv = 1, ga_cap = 512, ga_nbins2 = 0, n_qslots = 1;
@@ -289,6 +295,11 @@ struct ym_matcher {
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
     DevBuf<uint16_t> partial;  // per beam-chunk partial sums of the coarse lattice
+    DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
+    DevBuf<int32_t> rg_starts;
+    size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
+    int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     // gather correlate: per query slot of a call the (beam, angle) units sorted by region, the bin table, the work
     // lists and the counters they are built with; the lane -> (row, segment) table of the lattice
     DevBuf<uint32_t> ga_units;
@@ -332,7 +343,8 @@ struct ym_matcher {
     int corr_pad_lds = 0; // development: extra dynamic LDS per correlate block (limits blocks per CU)
     int corr_cw = 0;      // development: force the chunk-waves per correlate block (1, 2, 4)
     int corr_dedup = 0;     // development / tests: 1 = always merge equal consecutive lookup offsets, 2 = never
-    int corr_region = 0;    // tests: 1 = never use the gather correlate, 2 = its per-cell path, 3 = its "lists do not fit" path
+    int corr_region = 0;    // tests: 1 = neither LDS correlate, 2 = their per-cell path, 3 = their "lists do not fit" path, 4 = the gather
+                            // correlate also where the region correlate would run
     int corr_region_na = 0; // development: jobs (angle, lattice part) per wave of the gather correlate (1..4)
     int corr_region_parts = 0; // development / tests: blocks per item of the gather correlate (each takes a share of the angles)
     int corr_region_cap = 0;   // tests: units per LDS buffer (a multiple of 64; small values force chunked regions)
@@ -642,9 +654,33 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.dedup = (P.sx == 2 && chunk == 64 && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
     }
 
-    // Batches on lattices of at most 48 x 64: the patches are gathered from LDS, region by region (ym_k_gather.hpp).
-    // Single matches keep the direct kernel: a region walk is one long chain.
-    P.region = !yag && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
+    // Batches on lattices of at most 26 x 32 (a lattice row = two lanes of 13 hypotheses) without merged offsets: the
+    // patches are gathered from LDS, region by region (ym_k_region.hpp).  Single matches keep the direct kernel: a region
+    // walk is one long chain.
+    {
+        const int half_w = (g.win_w + 1) / 2;
+        P.rg_nrx = (half_w + YM_RG_W - 1) / YM_RG_W;
+        P.rg_nry = (half_w + YM_RG_H - 1) / YM_RG_H;
+        // sets of 16-bit sums per (item, angle): room for the padding of the entry lists (an item that needs more is scored
+        // by the per-cell path)
+        P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
+        P.rg_nbins = P.rg_nrx * P.rg_nry * lc.nt;
+        // (measured, 21 angles: three blocks of 8 waves per CU beat blocks of 7 although the third block of an item idles 3 waves)
+        P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : 8;
+        if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
+        P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
+        P.region26 = !yag && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
+                     lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
+        if (P.region26) {
+            P.n_groups = P.rg_ng;
+            // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
+            // 10 % over the pairs themselves (measured on the bench scans: 5 %)
+            P.rg_entries_stride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)lc.nt * max_n * 11 / 10 + 63) / 64 * 64);
+            P.rg_starts_stride = ((size_t)P.rg_nbins + 1 + 15) / 16 * 16;
+        }
+    }
+    // Other batches on lattices of at most 48 x 64: the general form (ym_k_gather.hpp).
+    P.region = !P.region26 && !yag && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
     if (P.region) {
         // lanes: a lane owns 16 x-adjacent hypotheses of one lattice row; a group of 32 lanes = up to 32 rows of one
         // segment (conflict-free LDS reads), or the rows past 32 of several segments; a wave = two groups
@@ -681,36 +717,41 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         }
     }
     if (P.region) {
-        // blocks per item: one (every region staged once) when the batch alone fills the chip, else the angles are shared
-        // out; jobs (angle, lattice part) per block -> jobs per wave and waves per block
-        int parts = m->corr_region_parts > 0 ? m->corr_region_parts : std::max(1, (768 + B - 1) / B);
+        // blocks per item and angles per wave (their sums live in registers: NA x NP x 8).  Measured on MI355X (4096 items,
+        // profiles/r03_gather_sweep.md): one angle per wave and about eight angles per block -- the copy of a region costs a
+        // block one memory round trip per work item, which only more resident blocks hide -- beat fewer, larger blocks
+        // although every block of an item stages the item's regions again
+        int parts = m->corr_region_parts > 0 ? m->corr_region_parts : (lc.nt + 7) / 8;
         parts = std::min(parts, lc.nt);
+        const int na_max = P.ga_np == 1 ? 4 : P.ga_np == 2 ? 2 : 1;
         for (;; parts++) {
             P.ga_kpp = (lc.nt + parts - 1) / parts;
-            const int jobs = P.ga_kpp * P.ga_np;
-            P.ga_na = m->corr_region_na > 0 ? std::min(4, m->corr_region_na) : std::min(3, (jobs + 7) / 8);
-            if ((jobs + P.ga_na - 1) / P.ga_na > 16) P.ga_na = 4;
-            P.ga_nwv = (jobs + P.ga_na - 1) / P.ga_na;
+            P.ga_na = m->corr_region_na > 0 ? std::min(na_max, m->corr_region_na) : 1;
+            if ((P.ga_kpp + P.ga_na - 1) / P.ga_na > 16 && m->corr_region_na <= 0) P.ga_na = na_max;
+            P.ga_nwv = (P.ga_kpp + P.ga_na - 1) / P.ga_na;
             if (P.ga_nwv <= 16) break;
         }
+        if (P.ga_nwv == 7) P.ga_nwv = 8; // (an eighth wave shares the copy work)
         P.ga_parts = (lc.nt + P.ga_kpp - 1) / P.ga_kpp;
-        P.ga_cap = m->corr_region_cap > 0 ? (m->corr_region_cap + 63) / 64 * 64 : 512;
-        // regions: the class image of a region (+ the patch margin) must fit a block's LDS twice; fewest staged bytes wins
+        P.ga_cap = std::min(64 * P.ga_nwv, m->corr_region_cap > 0 ? (m->corr_region_cap + 63) / 64 * 64 : 512); // (one unit per thread and copy)
+        // regions: a thread copies PER 16-byte chunks of the class image of a region (+ the patch margin) per work item;
+        // the fewest staged bytes win
+        const int per = YM_GA_PER;
         const int blocks_per_cu = std::max(1, std::min(3, 32 / P.ga_nwv));
         const size_t budget = m->corr_region_lds > 0 ? (size_t)m->corr_region_lds : (size_t)(160 * 1024) / blocks_per_cu - 512;
+        const int tasks = per * 64 * P.ga_nwv;
         const int half_w = (g.win_w + 1) / 2;
         double best = 1e300;
         for (int nrx = 1; nrx <= 256; nrx++) {
             const int W = (half_w + nrx - 1) / nrx;
             if (nrx > 1 && (half_w + nrx - 2) / (nrx - 1) == W) continue;
-            int pq = (W + YM_GA_G * P.ga_nseg + 3 + 7) / 8;
-            if (pq % 2 == 0) pq++;
-            const int Pp = 8 * pq;
+            const int cpr = (W + YM_GA_G * P.ga_nseg + 3 + 15) / 16, Pp = 16 * cpr + 8;
             for (int nry = 1; nry <= 256; nry++) {
                 const int H = (half_w + nry - 1) / nry, rows = H + lc.ny;
-                if ((size_t)Pp * rows > 65528 || YM_GA_LDS_BYTES(Pp, rows, P.ga_cap, P.ga_kpp) > budget) continue;
+                const int rows_lds = (tasks + cpr - 1) / cpr + 1; // what the block's copy tasks cover
+                if (cpr * rows > tasks || (size_t)Pp * rows > 65528 || YM_GA_LDS_BYTES(Pp, rows_lds, P.ga_cap, P.ga_kpp) > budget) continue;
                 const double cost = (double)nrx * nry * Pp * rows;
-                if (cost < best) { best = cost; P.ga_W = W; P.ga_H = H; P.ga_P = Pp; P.ga_rows = rows; P.ga_nrx = nrx; P.ga_nry = nry; }
+                if (cost < best) { best = cost; P.ga_W = W; P.ga_H = H; P.ga_P = Pp; P.ga_rows = rows_lds; P.ga_nrx = nrx; P.ga_nry = nry; }
                 break; // (more rows of regions only add margins)
             }
         }
@@ -724,15 +765,15 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.ga_ng = max_n / (YM_GA_FLUSH - 16) + 1; // sets of 16-bit sums a wave may have to write out per job
         P.ga_nbins2 = P.ga_nrx * P.ga_nry * 4 * lc.nt * 2;
         P.ga_units_stride = ((size_t)lc.nt * max_n + 128 + 63) / 64 * 64;
-        P.ga_starts_stride = ((size_t)P.ga_nbins2 + 1 + 64 + 15) / 16 * 16;
+        P.ga_starts_stride = ((size_t)2 * P.ga_nbins2 + 1 + 64 + 15) / 16 * 16;
         P.ga_work_stride = 1 + 3 * ((size_t)P.ga_nrx * P.ga_nry * 4 + P.ga_units_stride / P.ga_cap + 1);
         P.n_groups = P.ga_ng;
     }
     {
         static const bool debug_plan = getenv("YM_DEBUG_PLAN") != nullptr; // development aid: which correlate a call takes
         if (debug_plan)
-            fprintf(stderr, "[ym] B %d gather %d W %d H %d P %d rows %d nrx %d nry %d nseg %d np %d parts %d kpp %d na %d nwv %d lds %zu max_n %d nx %d ny %d nt %d\n",
-                    B, (int)P.region, P.ga_W, P.ga_H, P.ga_P, P.ga_rows, P.ga_nrx, P.ga_nry, P.ga_nseg, P.ga_np, P.ga_parts, P.ga_kpp, P.ga_na,
+            fprintf(stderr, "[ym] B %d region %d gather %d W %d H %d P %d rows %d nrx %d nry %d nseg %d np %d parts %d kpp %d na %d nwv %d lds %zu max_n %d nx %d ny %d nt %d\n",
+                    B, (int)P.region26, (int)P.region, P.ga_W, P.ga_H, P.ga_P, P.ga_rows, P.ga_nrx, P.ga_nry, P.ga_nseg, P.ga_np, P.ga_parts, P.ga_kpp, P.ga_na,
                     P.ga_nwv, P.ga_lds, max_n, lc.nx, lc.ny, lc.nt);
     }
 
@@ -740,7 +781,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.dim_stride = std::max(lc.nx, lc.ny);
     P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
-    P.partial_stride = P.region ? (size_t)P.ga_ng * lc.nt * P.ga_np * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
+    P.partial_stride = P.region26 ? (size_t)P.rg_ng * lc.nt * 64 * 16 : P.region ? (size_t)P.ga_ng * lc.nt * P.ga_np * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
     P.cell_blocks = (lc.nx * lc.ny + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
     P.score_blocks = P.cell_blocks * lc.nt; // block maxima per (angle, block of cells)
 
@@ -751,7 +792,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * YM_N_BOXES(max_n)))) return rc;
     if ((rc = m->grid.ensure((size_t)B * P.grid_stride))) return rc;
-    if ((rc = m->planes.ensure((size_t)B * P.grid_stride + YM_GA_PLANES_SLACK(g.pitch / 2, std::max(P.ga_H, P.ga_nry), lc.ny, P.ga_P)))) return rc;
+    if ((rc = m->planes.ensure((size_t)B * P.grid_stride + std::max(YM_RG_PLANES_SLACK(g.pitch / 2), YM_GA_PLANES_SLACK(g.pitch / 2, std::max(P.ga_rows, P.ga_nry + P.ga_H), lc.ny, P.ga_P))))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * P.nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * P.dim_stride))) return rc;
@@ -766,6 +807,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
     P.resp = call.ext_resp ? call.ext_resp : m->resp.p;
     P.probs = call.ext_probs ? call.ext_probs : m->probs.p;
+    P.fuse_score = P.region26 && !m->keep_sums && m->corr_fuse_score != 2;
     P.k_begin = call.slice ? std::max(0, call.k_begin) : 0;
     P.k_end = call.slice ? std::min(lc.nt, call.k_end) : lc.nt;
     if (call.slice && (yag || B != 1)) return set_err(YM_ERR_UNSUPPORTED, "angle-sliced matches are single Karto matches");
@@ -916,12 +958,17 @@ int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P) {
         if (base_used[i] && call.scans[i].stale) { jobs.push_back(i); job_slot.push_back(0); }
     P.n_jobs = (int)jobs.size();
     P.n_qslots = n_q;
+    if (P.region26) { // the region correlate's lists: one per query slot
+        int rc;
+        if ((rc = m->rg_entries.ensure((size_t)n_q * P.rg_entries_stride))) return rc;
+        if ((rc = m->rg_starts.ensure((size_t)n_q * P.rg_starts_stride))) return rc;
+    }
     if (P.region) { // the gather correlate's lists: one set per query slot
         int rc;
         if ((rc = m->ga_units.ensure((size_t)n_q * P.ga_units_stride))) return rc;
         if ((rc = m->ga_starts.ensure((size_t)n_q * P.ga_starts_stride))) return rc;
         if ((rc = m->ga_work.ensure((size_t)n_q * P.ga_parts * P.ga_work_stride))) return rc;
-        if ((rc = m->ga_counters.ensure((size_t)n_q * P.ga_nbins2 * YM_GA_CLS))) return rc;
+        if ((rc = m->ga_counters.ensure((size_t)n_q * 4 * P.ga_nbins2 * YM_GA_CLS))) return rc;
     }
     return YM_OK;
 }
@@ -1215,6 +1262,35 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     if (a.nk == 0) return YM_OK; // an empty angle slice
     int rc;
     hipEvent_t ev_k = nullptr;
+    if (P.region26) {
+        ym::RegionArgs r;
+        r.g = P.g; r.lat = P.lc; r.grid = m->grid.p; r.planes = m->planes.p; r.grid_stride = P.grid_stride; r.ctrig = m->ctrig.p;
+        r.hypcell = m->hypcell.p; r.states = m->states.p; r.qrep = P.d_qrep; r.entries = m->rg_entries.p; r.entries_stride = P.rg_entries_stride;
+        r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
+        r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
+        r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
+        r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
+        r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
+        const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride);
+        if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+            m->bin_lds_limit = bin_lds;
+        }
+        hipLaunchKernelGGL(ym::bin_kernel, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r); // once per query slot
+        if ((rc = prof_begin(m, 0, &ev_k))) return rc;
+        const dim3 rgrid(P.rg_parts, P.B);
+        switch (P.rg_nw) {
+        case 4: hipLaunchKernelGGL(ym::correlate_region_kernel<4>, rgrid, dim3(256), 0, st, r); break;
+        case 5: hipLaunchKernelGGL(ym::correlate_region_kernel<5>, rgrid, dim3(320), 0, st, r); break;
+        case 6: hipLaunchKernelGGL(ym::correlate_region_kernel<6>, rgrid, dim3(384), 0, st, r); break;
+        case 7: hipLaunchKernelGGL(ym::correlate_region_kernel<7>, rgrid, dim3(448), 0, st, r); break;
+        case 10: hipLaunchKernelGGL(ym::correlate_region_kernel<10>, rgrid, dim3(640), 0, st, r); break;
+        case 11: hipLaunchKernelGGL(ym::correlate_region_kernel<11>, rgrid, dim3(704), 0, st, r); break;
+        case 16: hipLaunchKernelGGL(ym::correlate_region_kernel<16>, rgrid, dim3(1024), 0, st, r); break;
+        default: hipLaunchKernelGGL(ym::correlate_region_kernel<8>, rgrid, dim3(512), 0, st, r); break;
+        }
+        return prof_end(m, ev_k);
+    }
     if (P.region) {
         ym::GatherArgs r;
         std::memset(&r, 0, sizeof r);
@@ -1225,31 +1301,44 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         r.partial = m->partial.p; r.partial_stride = P.partial_stride; r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride;
         r.W = P.ga_W; r.H = P.ga_H; r.P = P.ga_P; r.rows = P.ga_rows; r.nrx = P.ga_nrx; r.nry = P.ga_nry; r.nseg = P.ga_nseg; r.NP = P.ga_np;
         r.ng = P.ga_ng; r.parts = P.ga_parts; r.kpp = P.ga_kpp; r.unit_cap = P.ga_cap;
-        r.force_irregular = m->corr_region >= 2 ? m->corr_region - 1 : 0; r.stamps = P.stamps;
+        r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.stamps = P.stamps;
         r.sums = m->keep_sums ? m->sums.p : nullptr; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
         r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
         // the lists: once per query slot of the call (they depend on the query alone)
-        HIP_TRY(hipMemsetAsync(m->ga_counters.p, 0, (size_t)P.n_qslots * P.ga_nbins2 * YM_GA_CLS * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(m->ga_counters.p, 0, (size_t)P.n_qslots * 4 * P.ga_nbins2 * YM_GA_CLS * sizeof(uint32_t), st));
         const dim3 pgrid(((unsigned)P.lc.nt * P.max_n + YM_GBIN_THREADS - 1) / YM_GBIN_THREADS, P.n_qslots);
         hipLaunchKernelGGL(ym::gbin_pieces_kernel<false>, pgrid, dim3(YM_GBIN_THREADS), 0, st, r);
         hipLaunchKernelGGL(ym::gbin_scan_kernel, dim3(P.n_qslots), dim3(1024), 0, st, r);
         hipLaunchKernelGGL(ym::gbin_pieces_kernel<true>, pgrid, dim3(YM_GBIN_THREADS), 0, st, r);
         if (P.ga_lds > m->ga_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
             const int want = (int)std::min<size_t>(160 * 1024, P.ga_lds);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::gather_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::gather_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::gather_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::gather_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+            const void *kernels[14] = {
+#define YM_GA_BOTH(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER>), reinterpret_cast<const void *>(ym::gather_percell_kernel<NA, NP>)
+                YM_GA_BOTH(1, 1), YM_GA_BOTH(2, 1), YM_GA_BOTH(3, 1), YM_GA_BOTH(4, 1), YM_GA_BOTH(1, 2), YM_GA_BOTH(2, 2), YM_GA_BOTH(1, 3)};
+#undef YM_GA_BOTH
+            for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, want));
             m->ga_lds_limit = P.ga_lds;
         }
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.ga_parts, P.B), rblock(64 * P.ga_nwv);
-        switch (P.ga_na) {
-        case 1: hipLaunchKernelGGL(ym::gather_kernel<1>, rgrid, rblock, P.ga_lds, st, r); break;
-        case 2: hipLaunchKernelGGL(ym::gather_kernel<2>, rgrid, rblock, P.ga_lds, st, r); break;
-        case 3: hipLaunchKernelGGL(ym::gather_kernel<3>, rgrid, rblock, P.ga_lds, st, r); break;
-        default: hipLaunchKernelGGL(ym::gather_kernel<4>, rgrid, rblock, P.ga_lds, st, r); break;
-        }
+        // gather_kernel takes the items whose lists exist and whose hypothesis cells form a lattice (all of them, but for fp
+        // rounding accidents and oversized lists), gather_percell_kernel the others: each returns at once from the other's
+        // items
+#define YM_GA_LAUNCH(NA, NP)                                                                                               \
+    do {                                                                                                                   \
+        hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER>), rgrid, rblock, P.ga_lds, st, r);                        \
+        hipLaunchKernelGGL((ym::gather_percell_kernel<NA, NP>), rgrid, rblock, P.ga_lds, st, r);                           \
+    } while (0)
+        if (P.ga_np == 1) {
+            if (P.ga_na == 1) YM_GA_LAUNCH(1, 1);
+            else if (P.ga_na == 2) YM_GA_LAUNCH(2, 1);
+            else if (P.ga_na == 3) YM_GA_LAUNCH(3, 1);
+            else YM_GA_LAUNCH(4, 1);
+        } else if (P.ga_np == 2) {
+            if (P.ga_na == 1) YM_GA_LAUNCH(1, 2);
+            else YM_GA_LAUNCH(2, 2);
+        } else YM_GA_LAUNCH(1, 3);
+#undef YM_GA_LAUNCH
         return prof_end(m, ev_k);
     }
     if ((rc = prof_begin(m, 0, &ev_k))) return rc;
@@ -1287,9 +1376,9 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
     a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
     a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
-    a.k_begin = P.k_begin; a.k_end = P.k_end; a.pad = 0;
+    a.k_begin = P.k_begin; a.k_end = P.k_end; a.lane_layout = P.region26 ? 1 : 0;
     a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's maxima are recomputed once the volume is whole
-    if (P.region) return; // the gather correlate has scored its sums itself
+    if (P.region || P.fuse_score) return; // the LDS correlates score their sums themselves
     if (P.B >= 8) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
     else if (P.k_end > P.k_begin)
         hipLaunchKernelGGL(ym::score_hyp_kernel, dim3(P.cell_blocks, P.k_end - P.k_begin, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
@@ -1591,7 +1680,7 @@ void ym_destroy(ym_matcher *m) {
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->tile_hit_start.release(); m->sel_scratch.release();
-    m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
+    m->rg_entries.release(); m->rg_starts.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
@@ -2286,9 +2375,10 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 12) m->keep_sums = value;
     else if (option == 13) m->corr_dedup = value;
     else if (option == 14) m->corr_region = value;
-    else if (option == 15) m->corr_region_na = value;
+    else if (option == 15) m->corr_region_na = m->corr_region_nw = value;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
+    else if (option == 21) m->corr_fuse_score = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;

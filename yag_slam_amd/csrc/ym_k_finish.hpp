@@ -21,7 +21,8 @@ struct ScoreArgs {
     int32_t n_chunks, nx_pad, n_blocks;
     int32_t k_begin, k_end;   // the coarse angles this launch scores (a slice, or all)
     int32_t write_blockmax;
-    int32_t pad;
+    int32_t lane_layout;      // 1: partial sums as correlate_region_kernel leaves them, [group][angle][lane][16] with
+                              // lane = 32 * (ix / 13) + iy, slot ix % 13 (0: [group][angle][iy][nx_pad])
     unsigned long long *stamps;
 };
 
@@ -68,9 +69,10 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_kernel(ScoreArgs a) {
     const double sq_dist = x * x + y * y;
     const double ct = st.center[2];
     const int nq = st.nq;
-    const size_t kstride = (size_t)ny * a.nx_pad;
+    const size_t kstride = a.lane_layout ? (size_t)64 * 16 : (size_t)ny * a.nx_pad;
     const size_t cstride = (size_t)nt * kstride;
-    const uint16_t *p0 = a.partial + (size_t)b * a.partial_stride + (size_t)iy * a.nx_pad + ix;
+    const uint16_t *p0 = a.partial + (size_t)b * a.partial_stride +
+                         (a.lane_layout ? (size_t)((32 * (ix / 13) + iy) * 16 + ix % 13) : (size_t)iy * a.nx_pad + ix);
     double best = 0.0;
     YM_STAMP(a, 10);
     for (int k = a.k_begin; k < a.k_end; k++) {

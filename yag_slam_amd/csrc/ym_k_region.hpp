@@ -1,0 +1,511 @@
+// ym_k_region.hpp -- K4r: the coarse correlate of BATCHES on lattices up to 26 x 32, staged through LDS region by region
+// (round 2 form, tuned for the default 26 x 26 x 21 lattice; ym_k_gather.hpp is the general form: wider lattices, patches
+// with multiplicities, any number of readings).
+// Part of ym_kernels.hpp (include that, not this file).
+//
+// correlate_kernel (ym_k_correlate.hpp) gathers every (beam, angle) patch straight from the column planes and is bound
+// by the vector L1: a quad of lanes costs one clock per 128-byte line it touches, 34 line visits per (beam, angle) wave
+// load on a 26 x 26 lattice.  The LDS serves the same 16 bytes per lane in 8 clocks
+// (scripts/exp/lds_gather.hip: two ds_read2_b32 per lane at a 4-byte-aligned address, rows 25 dwords apart, the two
+// halves of a lattice row in the two halves of the wave: conflict-free, 128 B/clk) -- if the bytes are in LDS.
+// They can be: the hypotheses of one beam are every other cell of every other row, i.e. a DENSE 26 x 26 block of bytes
+// in the image of one (column parity, row parity) class of window cells, and the 22 701 patches of an item
+// (1081 beams x 21 angles) lie along the walls.  So
+//   bin_kernel            sorts the (beam, angle) pairs of an item by the 64 x 80-byte REGION of class space their patch
+//                         starts in (key: region, angle), 16-bit entries;
+//   correlate_region_kernel  walks the regions that hold work: copies the region (+ the 26-byte patch margin) of all four
+//                         classes into LDS once -- 42 KB serve ~1000 patches of 676 bytes each -- and every wave, which
+//                         owns one angle, gathers its patches from there into packed 16-bit sums kept in registers.
+// The sums leave the registers every YM_RG_FLUSH patches of a wave, in lane order (score_kernel's layout 1); on batches
+// whose integer sums nobody asked for the wave scores them itself at the end (fuse_score).
+#pragma once
+
+namespace ym {
+
+#define YM_RG_W 64                            // region width and height in class bytes (128 x 160 window cells): what three
+#define YM_RG_H 80                            // blocks per CU leave room for in LDS
+#define YM_RG_PITCH 100                       // LDS bytes per staged row: 25 dwords, odd -> 26 rows on 26 distinct banks
+#define YM_RG_ROWS (YM_RG_H + 26)             // + the patch height
+#define YM_RG_SEGS 6                          // 16-byte blocks staged per row (96 >= 64 + 26 + 3)
+#define YM_RG_CLS (YM_RG_PITCH * YM_RG_ROWS)  // bytes per class image
+#define YM_RG_G 13                            // hypotheses per lane: 13 bytes + 3 of misalignment = four dwords
+#define YM_RG_ZERO (4 * YM_RG_CLS)               // LDS offset of an all-zero patch: what the padding entries point at
+#define YM_RG_LDS_BYTES (YM_RG_ZERO + 26 * YM_RG_PITCH + 32)
+// bytes the host keeps past the last item's planes: a staged region may start up to (ROWS - 1) * 2 + 1 rows and 96 bytes
+// past the last cell of the second plane (never gathered, but read)
+#define YM_RG_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(half_pitch) + 256)
+#define YM_RG_MAX_BINS 8192
+#define YM_RG_MAX_REGIONS 96                   // regions with work a block of correlate_region_kernel can list
+#define YM_RG_MAX_ENTRIES 28672
+#define YM_RG_FLUSH 652                       // patches per set of 16-bit sums: 652 x 100 < 65536 (a multiple of four)
+#define YM_BIN_THREADS 1024
+#define YM_BIN_LDS_BYTES(nbins, entries) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT + YM_RG_MAX_BINS / 32 + 1) * 4 + (size_t)(nbins) * 8 + (size_t)(entries) * 2)
+
+struct RegionArgs {
+    YmGeom g;
+    YmLattice lat;
+    const uint8_t *grid;
+    const uint8_t *planes;
+    size_t grid_stride;
+    const double2 *ctrig;   // [B][nt_stride]
+    const int32_t *hypcell; // [B][2][dim_stride]
+    const YmItemState *states;
+    const int32_t *qrep;    // [n_qslots] an item that uses the query slot
+    uint16_t *entries;      // [Q][entries_stride]: LDS offset of the patch's first byte in the staged region, sorted by bin; one
+    size_t entries_stride;  // list per QUERY SLOT of the call (the pairs depend on the query alone, not on the chain)
+    int32_t *starts;        // [Q][starts_stride]: first entry of bin (region * nt + angle); [nbins] = total, or -1: no list
+    size_t starts_stride;
+    uint16_t *partial;      // [B][ng][nt][64 lanes][16]: ng sets of 16-bit sums, each of at most YM_RG_FLUSH patches
+    size_t partial_stride;
+    int32_t nt_stride, dim_stride;
+    int32_t nrx, nry, ng, nbins;
+    int32_t force_irregular; // tests: 1 = take the per-cell path, 2 = bin_kernel reports that the padded list does not fit
+    int32_t fuse_score;      // 1: the wave that holds an angle's sums also scores them (what score_kernel does otherwise)
+    double *resp;            // [B][nt][ny][nx]                         (fuse_score)
+    size_t sums_stride;
+    double *blockmax;        // [B][n_blocks], block = (angle, YM_SCORE_THREADS cells)
+    double *probs;           // [B][ny*nx] max over theta per (x, y); zeroed by the prepare stage
+    size_t probs_stride;
+    int32_t n_blocks, pad;
+    unsigned long long *stamps;
+};
+
+// the bin of one (beam, angle) pair and its entry = the LDS offset of the patch's first byte once the region is staged;
+// false if the patch origin is outside the regions (never for a patch the window holds; kept so that nothing is ever
+// written out of bounds)
+__device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int cx0, int cy0, int k, int i, int &bin, unsigned &entry) {
+    const int X = cx0 + cell.x, Y = cy0 + cell.y;
+    const int xc = X >> 1, yc = Y >> 1;
+    const int rx = xc / YM_RG_W, ry = yc / YM_RG_H;
+    if (X < 0 || Y < 0 || rx >= a.nrx || ry >= a.nry) return false;
+    bin = (ry * a.nrx + rx) * a.lat.nt + k;
+    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS + (yc - ry * YM_RG_H) * YM_RG_PITCH + (xc - rx * YM_RG_W));
+    return true;
+}
+
+// grid (Q): one block per query slot of the call.  YM_BIN_THREADS threads.  Counting sort in LDS: count, scan, place (the order inside a bin is arbitrary: the
+// sums are integers).  GridIndexLookup::ComputeOffsets for every coarse angle happens here.
+// Inside a bin the entries are sorted by their byte misalignment (entry & 3; class images and rows are multiples of 4
+// bytes), every run of equal misalignment is padded to an even length and the bin to a multiple of four with entries
+// that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
+// never meets a ragged group.  An item whose padded list would not fit -- the buffers, one angle's share the ng sets of
+// 16-bit sums the gather may fill, or more regions with work than a correlate block can list -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
+__global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
+    constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
+    // dynamic LDS (YM_BIN_LDS_BYTES: sized by the host so that two blocks share a CU on the usual lattice):
+    extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
+    int *wave_tot = reinterpret_cast<int *>(bin_smem);                                   // [YM_BIN_THREADS / 64]
+    int *angle_tot = wave_tot + YM_BIN_THREADS / 64;                                     // [YM_MAX_COARSE_NT] padded entries per coarse angle
+    unsigned *region_bits = reinterpret_cast<unsigned *>(angle_tot + YM_MAX_COARSE_NT);    // [YM_RG_MAX_BINS / 32] regions that hold a patch
+    int *regions_used = reinterpret_cast<int *>(region_bits + YM_RG_MAX_BINS / 32);
+    unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(regions_used + 1);             // [nbins] four 16-bit counters (one per
+                                                                                         // misalignment), later the runs' first positions
+    unsigned short *ent = reinterpret_cast<unsigned short *>(cnt + a.nbins);             // [entries_stride]
+    const int qs = blockIdx.x, b = a.qrep[qs], tid = threadIdx.x, lane = tid & 63;
+    const YmItemState &st = a.states[b];
+    const int nq = st.nq, nt = a.lat.nt;
+    const int total = nq * nt;
+    const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    const int cx0 = cx[0], cy0 = cx[a.dim_stride];
+    const double off_x = st.off_x, off_y = st.off_y;
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+    const double2 *trig = a.ctrig + (size_t)b * a.nt_stride;
+    int32_t *starts = a.starts + (size_t)qs * a.starts_stride;
+    for (int i = tid; i < a.nbins * 2; i += YM_BIN_THREADS) (&cnt[0][0])[i] = 0u;
+    if (tid < YM_MAX_COARSE_NT) angle_tot[tid] = 0;
+    if (tid < YM_RG_MAX_BINS / 32) region_bits[tid] = 0u;
+    if (tid == 0) *regions_used = 0;
+    __syncthreads();
+    // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
+    // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
+    // (29 bits of bin and entry + the rank's low 3 bits in one register, its other 8 bits four to a register: 35 registers
+    // for 28 pairs, so that two blocks share a CU; the host keeps max_n below 2048 on this path)
+    unsigned key[MAXP];          // rank & 7 << 29 | bin << 16 | entry; 0xffffffff = no pair
+    unsigned rank_hi[(MAXP + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (MAXP + 3) / 4; q++) rank_hi[q] = 0u;
+#pragma unroll
+    for (int q = 0; q < MAXP; q++) {
+        const int p = tid + q * YM_BIN_THREADS;
+        key[q] = 0xffffffffu;
+        if (p < total) {
+            const int k = p / nq, i = p - k * nq;
+            const double2 cs = trig[k];
+            int bin; unsigned e;
+            if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e)) {
+                const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
+                key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
+                rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the padded bin sizes: thread t owns the bins [t * per, (t + 1) * per)
+    const int per = (a.nbins + YM_BIN_THREADS - 1) / YM_BIN_THREADS;
+    const int first = tid * per;
+    int padded_total;
+    {
+        int local = 0;
+        for (int j = 0; j < per; j++)
+            if (first + j < a.nbins) {
+                const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
+                const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
+                const int padded = (((c[0] + 1) & ~1) + ((c[1] + 1) & ~1) + ((c[2] + 1) & ~1) + ((c[3] + 1) & ~1) + 3) & ~3;
+                local += padded;
+                if (padded) {
+                    atomicAdd(&angle_tot[(first + j) % nt], padded);
+                    const int R = (first + j) / nt;
+                    atomicOr(&region_bits[R >> 5], 1u << (R & 31));
+                }
+            }
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        if (tid < YM_RG_MAX_BINS / 32 && region_bits[tid]) atomicAdd(regions_used, __popc(region_bits[tid]));
+        __syncthreads();
+        int base = 0, all = 0;
+        for (int w = 0; w < YM_BIN_THREADS / 64; w++) {
+            if (w < (tid >> 6)) base += wave_tot[w];
+            all += wave_tot[w];
+        }
+        padded_total = all;
+        bool fits = all <= YM_RG_MAX_ENTRIES && all <= (int)a.entries_stride && a.force_irregular != 2;
+        for (int k = 0; k < nt; k++) fits = fits && angle_tot[k] <= a.ng * YM_RG_FLUSH;
+        fits = fits && *regions_used <= YM_RG_MAX_REGIONS; // (what a block of correlate_region_kernel can list)
+        int run = base + incl - local;
+        for (int j = 0; j < per; j++)
+            if (first + j < a.nbins) {
+                const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
+                const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
+                starts[first + j] = run;
+                int pos = run;
+                unsigned fill[4];
+                for (int r = 0; r < 4; r++) { // run r: its entries from pos on (placed below), then the padding
+                    fill[r] = (unsigned)pos;
+                    if (fits && (c[r] & 1)) ent[pos + c[r]] = (unsigned short)(YM_RG_ZERO + r);
+                    pos += (c[r] + 1) & ~1;
+                }
+                if (fits && ((pos - run) & 3)) { ent[pos] = (unsigned short)YM_RG_ZERO; ent[pos + 1] = (unsigned short)YM_RG_ZERO; }
+                pos = run + ((pos - run + 3) & ~3);
+                cnt[first + j][0] = fill[0] | fill[1] << 16;
+                cnt[first + j][1] = fill[2] | fill[3] << 16;
+                run = pos;
+            }
+        if (tid == 0) { starts[a.nbins] = fits ? all : -1; if (a.stamps && qs == 0) a.stamps[26] = (unsigned long long)all; }
+        if (!fits) return; // (block-uniform)
+    }
+    __syncthreads();
+    // Pass 2: every pair to its run's first position + its rank
+#pragma unroll
+    for (int q = 0; q < MAXP; q++) {
+        if (key[q] == 0xffffffffu) continue;
+        const unsigned bin = (key[q] >> 16) & 0x1fffu, e = key[q] & 0xffffu;
+        const unsigned rank = key[q] >> 29 | ((rank_hi[q >> 2] >> (8 * (q & 3))) & 0xffu) << 3;
+        const unsigned f = cnt[bin][(e >> 1) & 1u];
+        ent[((e & 1u) ? f >> 16 : f & 0xffffu) + rank] = (unsigned short)e;
+    }
+    __syncthreads();
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.entries + (size_t)qs * a.entries_stride);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ent);
+    for (int i = tid; i < (padded_total + 1) / 2; i += YM_BIN_THREADS) out[i] = src[i];
+}
+
+// The 16 bytes at LDS byte address `addr` (any alignment): two ds_read2_b32 at the dword below + a byte funnel.
+// (A ds_read_b128 at a 4-byte-aligned address is legal on gfx950 but takes 64 clk per wave, lds_gather.hip.)
+// The registers an asm statement that only ISSUES a read names as outputs are not written when the statement ends, and
+// the compiler is free to copy them right there (seen: wrong sums): every such register is either waited for inside
+// the issuing statement or passes through the statement that waits for it ("+v") before anything else touches it.
+typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
+// Four patches (their LDS origins: four 16-bit entries, the same in every lane -- a broadcast read of the wave's entry list)
+// into the packed 16-bit sums (acc[2j]: hypotheses 4j, 4j + 2; acc[2j + 1]: 4j + 1, 4j + 3).  Patches 2i and 2i + 1 share their misalignment (bin_kernel): grid
+// bytes are at most 100, so their RAW dwords add without carries and one funnel serves both; the two funnelled pair sums
+// are split into even / odd bytes and added with one v_add3 each.
+__device__ __forceinline__ void rg_funnel_pair(const rg_u32x2 &pa, const rg_u32x2 &qa, const rg_u32x2 &pb, const rg_u32x2 &qb, uint32_t rr,
+                                               uint32_t (&x)[4]) {
+    const uint32_t s0 = pa.x + pb.x, s1 = pa.y + pb.y, s2 = qa.x + qb.x, s3 = qa.y + qb.y; // raw dwords of two patches: bytes <= 200
+    x[0] = __builtin_amdgcn_alignbyte(s1, s0, rr);
+    x[1] = __builtin_amdgcn_alignbyte(s2, s1, rr);
+    x[2] = __builtin_amdgcn_alignbyte(s3, s2, rr);
+    x[3] = __builtin_amdgcn_alignbyte(0u, s3, rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
+}
+// All eight reads of the four patches are issued at once; the first pair is funnelled while the second pair's reads are
+// still in flight (LDS reads return in order: lgkmcnt(4) = the first four are back).
+__device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint2 ee /* four 16-bit origins, wave-uniform */) {
+    const uint32_t ad0 = lane_off + (ee.x & 0xffffu), ad1 = lane_off + (ee.x >> 16), ad2 = lane_off + (ee.y & 0xffffu), ad3 = lane_off + (ee.y >> 16);
+    rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %4, %10 offset1:1\n\tds_read2_b32 %5, %10 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %6, %11 offset1:1\n\tds_read2_b32 %7, %11 offset0:2 offset1:3\n\t"
+                 "s_waitcnt lgkmcnt(4)"
+                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
+                 : "v"(ad0 & ~3u), "v"(ad1 & ~3u), "v"(ad2 & ~3u), "v"(ad3 & ~3u)
+                 : "memory");
+    uint32_t x[2][4];
+    rg_funnel_pair(p0, q0, p1, q1, ad0 & 3u, x[0]);
+    // (the second pair's registers are written by the LDS until here: they pass through this statement and nothing else)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p2), "+v"(q2), "+v"(p3), "+v"(q3) : : "memory");
+    rg_funnel_pair(p2, q2, p3, q3, ad2 & 3u, x[1]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
+        if (j < 3) // (acc[7] would hold hypotheses 13 and 15 of the lane: there are only 13)
+            acc[2 * j + 1] = acc[2 * j + 1] + __builtin_amdgcn_perm(0u, x[0][j], 0x0c030c01u) + __builtin_amdgcn_perm(0u, x[1][j], 0x0c030c01u);
+    }
+}
+
+// grid (P, B): block (p, item) = NW waves, wave w owns coarse angle p * NW + w.  Lane = 13 x-adjacent hypotheses of one
+// lattice row: row = lane & 31, half = lane >> 5 (nx <= 26, ny <= 32: checked on the host).
+// The walk over the regions is a two-stage pipeline: while region i is gathered, the global loads of region i + 1 are in
+// flight (registers) together with the wave's first 128 entries of it; they go to LDS between the two barriers that end
+// the gather.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three blocks per CU: 80 VGPRs */) void correlate_region_kernel(RegionArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr int TASKS = 4 * YM_RG_ROWS * YM_RG_SEGS, PER = (TASKS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char region[YM_RG_LDS_BYTES]; // four class images + the zero patch
+    __shared__ int rlist[YM_RG_MAX_REGIONS];
+    __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][2]; // per wave and listed region: its first entry and the end
+    __shared__ uint2 elist[NW][64];                   // per wave: its first 256 entries of the region being gathered
+    __shared__ int rcount;
+    int p;
+    const int b = xcd_item_of_block_2d(p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const YmItemState &st = a.states[b];
+    const int nt = a.lat.nt, nx = a.lat.nx, ny = a.lat.ny, ng = a.ng;
+    const int k = p * NW + wave;
+    const bool kvalid = k < nt;
+    const int row = lane & 31, half = lane >> 5;
+    const bool job = row < ny && half * YM_RG_G < nx;
+    const int half_pitch = a.g.pitch / 2;
+    const int plane_bytes = half_pitch * a.g.win_w;
+    const uint8_t *__restrict__ planes = a.planes + (size_t)b * a.grid_stride;
+    const int32_t *__restrict__ starts = a.starts + (size_t)st.qslot * a.starts_stride;
+    const uint16_t *__restrict__ entries = a.entries + (size_t)st.qslot * a.entries_stride;
+    const uint32_t lds0 = (uint32_t)(size_t)region;
+    // idle lanes read what lane (row 0, same half) reads: the same address is a broadcast, any other address could share a
+    // bank with a working lane
+    const uint32_t lane_off = lds0 + (uint32_t)((job ? row : 0) * YM_RG_PITCH + (half * YM_RG_G < nx ? half * YM_RG_G : 0));
+    uint32_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0u;
+    // the 16-bit sums hold YM_RG_FLUSH patches: the wave counts what it has added and, when a set is full, writes it out as
+    // partial set number `flushed` and starts the next (score_kernel adds the sets)
+    int in_set = 0, flushed = 0;
+    auto flush = [&]() {
+        if (flushed < ng) store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)flushed * nt + k) * 64 + lane) * 16, acc);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0u;
+        flushed++;
+        in_set = 0;
+    };
+    YM_STAMP(a, 8);
+    const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
+    if (regular) {
+        const int k_lo = p * NW, k_hi = min(nt, k_lo + NW);
+        const int nreg = a.nrx * a.nry;
+        for (int i = tid; i < (YM_RG_LDS_BYTES - YM_RG_ZERO) / 4; i += NT) reinterpret_cast<uint32_t *>(region + YM_RG_ZERO)[i] = 0u;
+        // the regions in which a patch of this block's angles starts
+        if (wave == 0) {
+            int n = 0;
+            for (int R0 = 0; R0 < nreg; R0 += 64) {
+                const int R = R0 + lane;
+                const bool has = R < nreg && starts[(size_t)R * nt + k_lo] != starts[(size_t)R * nt + k_hi];
+                const unsigned long long mask = __ballot(has);
+                if (has) rlist[n + __popcll(mask & ((1ull << lane) - 1ull))] = R;
+                n += __popcll(mask);
+            }
+            if (lane == 0) rcount = n;
+        }
+        __syncthreads();
+        const int nlist = rcount;
+        if (kvalid)
+            for (int i = lane; i < nlist; i += 64) {
+                const int32_t *srow = starts + (size_t)rlist[i] * nt + k;
+                seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1];
+            }
+        __syncthreads();
+        // copy task t = (class, row, 16-byte block): thread tid takes t = tid, tid + NT, ... (the last ones take task TASKS - 1
+        // again).  Its source offset inside a region is fixed, so a load is one instruction: uniform region base + that
+        // offset.  Nothing is range-checked: rows past the window and blocks past a plane row are other bytes of the
+        // planes buffer (the host allocates YM_RG_PLANES_SLACK bytes past the last item), and no patch the window holds
+        // ever reads them.
+        uint4 v[PER];
+        uint32_t src_rel[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t t = min((uint32_t)(tid + q * NT), (uint32_t)(TASKS - 1));
+            const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS; // rowidx = class * ROWS + row
+            const uint32_t cls = rowidx / YM_RG_ROWS, r = rowidx - cls * YM_RG_ROWS;
+            src_rel[q] = (cls & 1u) * (uint32_t)plane_bytes + (2u * r + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
+        }
+        auto stage_load = [&](int R) {
+            const int RX = R % a.nrx, RY = R / a.nrx;
+            const uint8_t *src = planes + ((size_t)(2 * RY * YM_RG_H) * half_pitch + (size_t)RX * YM_RG_W); // (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < PER; q++) v[q] = *reinterpret_cast<const uint4 *>(src + src_rel[q]);
+        };
+        auto stage_store = [&]() {
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t t = min((uint32_t)(tid + q * NT), (uint32_t)(TASKS - 1));
+                const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS;
+                uint32_t *d = reinterpret_cast<uint32_t *>(region + rowidx * YM_RG_PITCH + 16u * seg); // class images are contiguous
+                d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+            }
+        };
+        // this wave's entries of a region: [t0, t2) (a multiple of four entries)
+        auto segment = [&](int ri, int &t0, int &t2) {
+            t0 = t2 = 0;
+            if (kvalid) {
+                t0 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][0]);
+                t2 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][1]);
+            }
+        };
+        // The first 256 entries of a wave's segment travel like the region itself: loaded into a register while the previous
+        // region is gathered, put into LDS between the barriers, read from there (a broadcast ds_read_b64 per four patches).
+        // No vector-memory wait inside the gather: that would also wait for the staging loads in flight.
+        const uint2 *__restrict__ entries4 = reinterpret_cast<const uint2 *>(entries); // four entries per element
+        uint2 ev = make_uint2(0u, 0u);
+        auto entries_load = [&](int t0, int t2) {
+            ev = make_uint2(0u, 0u);
+            if (t0 + 4 * lane < t2) ev = entries4[(t0 >> 2) + lane];
+        };
+        auto gather = [&](int lo, int hi) { // entries [lo, hi)
+            const int lds_hi = min(hi, lo + 256);
+            if (lo < lds_hi) {
+                const uint2 *el = elist[wave];
+                const int n4 = (lds_hi - lo) >> 2;
+                uint2 ee = el[0];
+                for (int c = 0; c < n4; c++) {
+                    const uint2 nx = el[min(c + 1, n4 - 1)];
+                    rg_gather4(acc, lane_off, ee);
+                    ee = nx;
+                    in_set += 4;
+                    if (in_set == YM_RG_FLUSH) flush();
+                }
+            }
+            for (int c = lds_hi; c < hi; c += 4) { // (a very long segment)
+                rg_gather4(acc, lane_off, entries4[c >> 2]);
+                in_set += 4;
+                if (in_set == YM_RG_FLUSH) flush();
+            }
+        };
+        int s0 = 0, s2 = 0;
+        if (nlist > 0) {
+            segment(0, s0, s2);
+            entries_load(s0, s2);
+            stage_load(rlist[0]);
+            stage_store();
+            elist[wave][lane] = ev;
+        }
+        __syncthreads();
+        for (int ri = 0; ri < nlist; ri++) {
+            // two-stage pipeline: the global loads of the next region are in flight (registers) while this one is gathered
+            const bool has_next = ri + 1 < nlist;
+            int n0 = 0, n2 = 0;
+            if (has_next) {
+                segment(ri + 1, n0, n2);
+                entries_load(n0, n2);
+                stage_load(rlist[ri + 1]);
+            }
+            gather(s0, s2);
+            __syncthreads(); // every wave is done with region ri
+            if (has_next) {
+                stage_store();
+                elist[wave][lane] = ev;
+            }
+            s0 = n0; s2 = n2;
+            __syncthreads();
+        }
+    } else if (kvalid && job) {
+        // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path over the window
+        const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+        const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+        const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+        const int32_t *cy = cx + a.dim_stride;
+        const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
+        const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+        const int nq = st.nq;
+        for (int g = 0; g < ng; g++) { // set g = the beams [g * FLUSH, (g + 1) * FLUSH)
+            for (int j = 0; j < YM_RG_G; j++) {
+                const int ix = half * YM_RG_G + j;
+                if (ix >= nx) break;
+                const int base = cy[row] * a.g.pitch + cx[ix];
+                unsigned sum = 0;
+                const int i1 = min(nq, (g + 1) * YM_RG_FLUSH);
+                for (int i = g * YM_RG_FLUSH; i < i1; i++) {
+                    const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, a.g.pitch));
+                    sum += idx < limit ? grid[idx] : 0u;
+                }
+                acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
+            }
+            flush();
+        }
+    }
+    YM_STAMP(a, 9);
+    if (!a.fuse_score) {
+        if (!kvalid) return;
+        while (flushed < ng) flush(); // the set being filled, then empty ones
+        return;
+    }
+    // ---- score (score_kernel's arithmetic, statement for statement): this wave holds the last set of its angle's sums in
+    // registers and wrote the earlier ones itself; response, penalty, block maxima; the per-(x, y) maximum over theta goes
+    // through LDS (the region buffer is free now) so that only one atomic per cell and block reaches memory
+    unsigned long long *pmax = reinterpret_cast<unsigned long long *>(region); // [ny * nx] fp64 bit patterns, >= 0
+    const int nxy = nx * ny;
+    double *dpen = reinterpret_cast<double *>(region) + ((nxy + 1) & ~1); // [ny * nx] distance penalty of every cell: once
+                                                                           // per block, not once per wave (an fp64 division)
+    __syncthreads(); // every wave has left the region walk
+    for (int i = tid; i < nxy; i += NT) {
+        pmax[i] = 0ull;
+        const int iy = i / nx, ix = i - iy * nx;
+        const double x = -a.lat.off_x + ix * a.lat.step_x, y = -a.lat.off_y + iy * a.lat.step_y;
+        dpen[i] = dist_penalty(a.g, x * x + y * y);
+    }
+    __syncthreads();
+    if (kvalid) {
+        unsigned tot[YM_RG_G];
+#pragma unroll
+        for (int j = 0; j < YM_RG_G; j++) tot[j] = (acc[2 * (j >> 2) + (j & 1)] >> (16 * ((j >> 1) & 1))) & 0xffffu;
+        for (int f = 0; f < min(flushed, ng); f++) { // the sets this lane wrote out earlier
+            const uint16_t *pp = a.partial + (size_t)b * a.partial_stride + (((size_t)f * nt + k) * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < YM_RG_G; j++) tot[j] += pp[j];
+        }
+        const double ct = st.center[2];
+        const int nq = st.nq;
+        const double angle = (ct - a.lat.angle_off) + k * a.lat.angle_res;
+        const int ncb = (nxy + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
+        double bmax0 = -1.0, bmax1 = -1.0; // block maxima this lane contributes to (its 13 cells span at most 2 blocks)
+        const int c0 = row * nx + half * YM_RG_G, cb0 = job ? c0 / YM_SCORE_THREADS : 0;
+#pragma unroll
+        for (int j = 0; j < YM_RG_G; j++) {
+            const int ix = half * YM_RG_G + j;
+            if (job && ix < nx) {
+                const int c = row * nx + ix;
+                const double r = hyp_response_dp(a.g, a.lat.penalize, tot[j], nq, dpen[c], angle, ct);
+                a.resp[(size_t)b * a.sums_stride + (size_t)k * nxy + c] = r;
+                if (c / YM_SCORE_THREADS == cb0) bmax0 = r > bmax0 ? r : bmax0;
+                else bmax1 = r > bmax1 ? r : bmax1;
+                if (r > 0.0) atomicMax(&pmax[c], (unsigned long long)__double_as_longlong(r));
+            }
+        }
+        // block maxima of this angle: blockmax[k * ncb + cb]
+        for (int cb = 0; cb < ncb; cb++) {
+            const double mine = !job ? -1.0 : cb == cb0 ? bmax0 : cb == cb0 + 1 ? bmax1 : -1.0;
+            const double m = wave_reduce(mine, OpMaxD());
+            if (lane == 0) a.blockmax[(size_t)b * a.n_blocks + (size_t)k * ncb + cb] = m;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nxy; i += NT)
+        if (pmax[i]) atomicMax(reinterpret_cast<unsigned long long *>(a.probs) + (size_t)b * a.probs_stride + i, pmax[i]);
+}
+
+} // namespace ym
