@@ -188,6 +188,12 @@ def test_angle_sliced_match_equals_the_whole_match(which):
         for i in range(3):
             m.slice_begin(query, base, True, True, cuts[i], cuts[i + 1], resp.data_ptr(), probs[i].data_ptr())
         probs[2].copy_(torch.maximum(torch.maximum(probs[0], probs[1]), probs[2]))
+    # between slice_begin and slice_finish the matcher's synchronous slot belongs to the sliced match: anything else that
+    # needs it is refused (YM_ERR_BUSY) instead of clobbering the kept plan
+    from yag_slam_amd._capi import YmError
+    with pytest.raises(YmError) as busy:
+        m.match_scan(query, base, True, True)
+    assert busy.value.code == -6
     got = m.slice_finish()
     assert got.response == ref.response and got.covariance == ref.covariance and got.meta == ref.meta
     assert (got.best_pose.x, got.best_pose.y, got.best_pose.euler[-1]) == (ref.best_pose.x, ref.best_pose.y, ref.best_pose.euler[-1])

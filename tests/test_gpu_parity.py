@@ -648,23 +648,40 @@ def test_stale_window_bytes_do_not_survive_a_smaller_batch():
         m.close()
 
 
-def test_query_reading_beyond_the_matcher_threshold_is_refused():
-    """Round-1 advisor finding: the device window is cut from Karto's grid, which is sized from the MATCHER's
-    range_threshold.  A query whose own threshold lets a longer reading through points outside it; the fast kernels
-    have no bounds test, so the call must fail loudly (YM_ERR_UNSUPPORTED), never read a neighbour's window."""
+def test_query_reading_beyond_the_matcher_threshold_is_answered_like_karto():
+    """The device window is cut from Karto's grid, which is sized from the MATCHER's range_threshold.  A query whose own
+    threshold lets a longer reading through (/root/reference/yag_slam/models.py:110-116: scans carry range_max * 0.9, the
+    matcher's default is 20) points outside that grid, where Karto's GetResponse tests the LINEAR index
+    (IsUpTo(index, data size)): an offset that leaves the grid sideways wraps into a neighbouring row.  Such a call takes
+    the whole of Karto's storage as its window and forms every index with Karto's row pitch: results, grids and sum volumes
+    against the oracle (which keeps Karto's full grid) -- single matches, a batch, coarse only and refined, a query far
+    enough out that most of its readings leave the grid; and the same readings gated by the scan's own threshold."""
+    from oracle import oracle as orc
     from yag_slam_amd.scan_matching import ScanMatcher
-    from yag_slam_amd._capi import YmError
     q, base = cfg2_scans()
-    m = ScanMatcher(dict(range_threshold=4.0))
-    far_q = _mk_native(PlainScan(q.ranges, q.min_angle, q.angle_increment, q.min_range, 20.0, (3.0, 3.0, 0.0)))
+    cfg = dict(range_threshold=4.0)
+    far = lambda pose: PlainScan(q.ranges, q.min_angle, q.angle_increment, q.min_range, 20.0, pose)
     assert np.nanmax(q.ranges) > 4.0
-    nb = [_mk_native(b) for b in base[:3]]
-    with pytest.raises(YmError) as e:
-        m.match_scan(far_q, nb, True, True)
-    assert e.value.code == -4
-    # the same readings gated by the scan's own threshold are fine and match the oracle
+    for pose in ((3.0, 3.0, 0.0), (3.02, 2.97, 0.4)):
+        for pen, fine in ((True, True), (False, False)):
+            compare(cfg, far(pose), base[:3], pen, fine)
+    # the sums of the coarse volume, and a batch (the direct kernel's per-cell path, score kernel, finish kernel)
+    m, o = ScanMatcher(cfg), orc.Oracle(cfg, "karto")
+    fq, nb = _mk_native(far((3.0, 3.0, 0.0))), [_mk_native(b) for b in base[:3]]
+    r = m.match_scan(fq, nb, True, True)
+    ro = o.match_scan(far((3.0, 3.0, 0.0)), base[:3], True, True)
+    assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]), o.sums(0))
+    assert np.array_equal(m.debug_sums(1, dims=r.meta["fine_dims"]), o.sums(1))
+    chains = [nb, nb[:2], nb[1:], nb[::-1], nb[:1], nb[2:], nb, nb[1:2]]
+    per, best = m.match_scan_batch(fq, chains, True, True)
+    for ch, p in zip([base[:3], base[:2], base[1:3], base[:3][::-1], base[:1], base[2:3], base[:3], base[1:2]], per):
+        po = o.match_scan(far((3.0, 3.0, 0.0)), ch, True, True)
+        assert abs(p.response - po["response"]) <= 1e-12
+        np.testing.assert_allclose([p.best_pose.x, p.best_pose.y, p.best_pose.euler[-1]], po["pose"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.array(p.covariance), po["cov"], rtol=1e-9, atol=1e-15)
+    # the same readings gated by the scan's own threshold take the ordinary window
     ok_q = PlainScan(q.ranges, q.min_angle, q.angle_increment, q.min_range, 4.0, (3.0, 3.0, 0.0))
-    compare(dict(range_threshold=4.0), ok_q, base[:3], True, True)
+    compare(cfg, ok_q, base[:3], True, True)
 
 
 def test_point_cache_is_invisible():
@@ -727,6 +744,36 @@ def test_point_cache_is_invisible():
         a, b = m.match_scan(gq, gb, True, True), ref.match_scan(gq, gb, True, True)
         assert a.response == b.response and a.covariance == b.covariance
         assert np.array_equal(m.debug_grid()[0], ref.debug_grid()[0])
+
+
+def test_a_failed_call_leaves_no_unwritten_cache_entries():
+    """Round-2 advisor finding: the point cache is updated on the host before the kernels that fill its entries are enqueued.
+    A call that fails in between (here: an order-dependent smear on a chain of more readings than the select kernels
+    take, refused after the cache was planned) must not leave those entries "current": the same scans in a chain that
+    works must give what a fresh matcher gives."""
+    from yag_slam_amd import synth
+    from yag_slam_amd._capi import YmError
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, _ = cfg2_scans(range_threshold=12.0)
+    scene = synth.Scene()
+    mk = lambda r, p: PlainScan(r, synth.MIN_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, 12.0, p)
+    poses = [(2.0 + 0.02 * i, 3.0 + 0.01 * (i % 5), 0.01 * (i % 7)) for i in range(92)]   # 92 x 1081 = 99 452 readings
+    chain = [_mk_native(mk(scene.scan_ranges(p, index=700 + i), p)) for i, p in enumerate(poses)]
+    nq = _mk_native(q)
+    cfg = dict(resolution=0.01, smear_deviation=0.1, range_threshold=12.0, search_size=0.3)
+    m = ScanMatcher(cfg)
+    with pytest.raises(YmError) as e:
+        m.match_scan(nq, chain, True, True)
+    assert e.value.code == -4
+    got = m.match_scan(nq, chain[:6], True, True)
+    ref = ScanMatcher(cfg).match_scan(nq, chain[:6], True, True)
+    assert got.response == ref.response and got.covariance == ref.covariance and got.meta == ref.meta
+    # and in a batch (the split prepare: points_kernel fills the entries)
+    with pytest.raises(YmError):
+        m.match_scan_batch(nq, [chain] * 8, True, True)
+    per, _ = m.match_scan_batch(nq, [chain[10:16]] * 8, True, True)
+    ref = ScanMatcher(cfg).match_scan(nq, chain[10:16], True, True)
+    assert per[3].response == ref.response and per[3].covariance == ref.covariance
 
 
 def test_order_dependent_smear_on_long_chains():

@@ -68,6 +68,18 @@ def test_transform_composes_like_an_odometry_prior():
     assert abs(prior.euler[-1] - 1.5) < 1e-12
     ident = last_odom - last_odom
     assert abs(ident.x) < 1e-12 and abs(ident.y) < 1e-12 and abs(ident.euler[-1]) < 1e-12
+    # tiny_tf's spelling: position + quaternion (what yag-slam's map files store).  A planar rotation round-trips; a
+    # rotation out of the plane or a quaternion with components missing is refused, never read as some yaw
+    t = Transform(1.0, 2.0, 0.0, 0.0, 0.0, math.sin(0.35), math.cos(0.35))
+    assert abs(t.yaw - 0.7) < 1e-12
+    t = Transform(1.0, 2.0, 0.0, qx=t.qx, qy=t.qy, qz=t.qz, qw=t.qw)
+    assert abs(t.yaw - 0.7) < 1e-12
+    with pytest.raises(ValueError):
+        Transform(0.0, 0.0, 0.0, 0.1, 0.0, 0.0, 0.99)
+    with pytest.raises(ValueError):
+        Transform(0.0, 0.0, 0.0, qx=0.0, qy=0.3, qz=0.0, qw=0.95)
+    with pytest.raises(TypeError):
+        Transform(0.0, 0.0, 0.0, qz=0.5)
 
 
 def test_scan_model_without_gpu():
@@ -87,6 +99,12 @@ def test_scan_model_without_gpu():
     assert s.num == 7
     lx, ly = s.points_local()
     assert len(lx) == len(px)
+    # scans from JSON logs (models.py:110-116 of the reference): beams reversed unless told otherwise, threshold 0.9 x range_max
+    d = {"ranges": [1.0, 2.0, 3.0, 40.0], "angle_min": -0.2, "angle_max": 0.1, "angle_increment": 0.1, "range_min": 0.05, "range_max": 30.0}
+    j = LocalizedRangeScan.from_json(d, 1.0, 2.0, 0.5)
+    assert list(j.ranges) == [40.0, 3.0, 2.0, 1.0] and j.range_threshold == 30.0 * 0.9 and j.min_angle == -0.2
+    assert (j.corrected_pose.x, j.corrected_pose.y, j.corrected_pose.euler[-1]) == (1.0, 2.0, 0.5)
+    assert list(LocalizedRangeScan.from_json(d, 0, 0, 0, invert=False).ranges) == [1.0, 2.0, 3.0, 40.0] and d["ranges"] == [1.0, 2.0, 3.0, 40.0]
 
 
 def test_shard_ranges_cover_all_chains():

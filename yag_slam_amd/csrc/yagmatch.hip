@@ -561,12 +561,12 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     }
     for (const CallScan &s : call.scans) P.max_n = std::max(P.max_n, s.n);
     const int max_n = P.max_n, max_base = P.max_base;
-    // Karto sizes its grid from the MATCHER's range threshold; a query reading beyond it points outside that grid,
-    // where GetResponse's linear-index test wraps around Karto's own row pitch.  The fast kernels do no bounds test
-    // (inside the grid none is needed), so such a call is refused instead of answered differently.
-    if (g.semantics == YM_SEM_KARTO && rq > m->cfg.range_threshold)
-        return set_err(YM_ERR_UNSUPPORTED, "query scan holds a valid reading of %g m, beyond the matcher's range_threshold %g", rq,
-                       m->cfg.range_threshold);
+    // Karto sizes its grid from the MATCHER's range threshold; a query reading beyond it (scans carry their own threshold:
+    // /root/reference/yag_slam/models.py:110-116) points outside that grid, where GetResponse's linear-index test wraps
+    // around Karto's own row pitch.  Such a call is answered exactly as Karto would: window = Karto's whole storage, every
+    // linear index formed with Karto's pitch, per-cell paths only (ym_k_common.hpp, cell_value).
+    const bool wrap = g.semantics == YM_SEM_KARTO && rq > m->cfg.range_threshold;
+    g.kpitch = wrap ? (g.storage_w + 7) / 8 * 8 : 0;
     if (max_n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", max_n, YM_MAX_BEAMS);
 
     const bool yag = P.yag = g.semantics == YM_SEM_YAGPY;
@@ -592,9 +592,10 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     const int centre = g.border + (g.roi_w - 1) / 2;
     const double reach = rq + coarse_off + (yag ? 3 : 1) * g.res; // yagpy's fine pass reaches 2 cells past the coarse box
     int wh = (int)std::ceil(reach / g.res) + 3;
-    wh = std::min(wh, centre);
+    wh = wrap ? centre : std::min(wh, centre);
     g.win_origin = centre - wh;
     g.win_w = std::min(2 * wh + 1 + (yag ? 1 : 0), g.storage_w - g.win_origin); // even yagpy grids have no centre cell
+    if (wrap) { g.win_origin = 0; g.win_w = g.storage_w; }
     P.tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
     P.tiles_y = (g.win_w + YM_TILE_H - 1) / YM_TILE_H;
     g.pitch = P.tiles_x * YM_TILE_W + 64;
@@ -651,7 +652,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     {
         const double spacing = call.scans[call.items[0].query].beam_spacing;
         const bool likely = spacing > 0 && spacing < 0.6 * g.res;
-        P.dedup = (P.sx == 2 && chunk == 64 && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
+        P.dedup = (!wrap && P.sx == 2 && chunk == 64 && (m->corr_dedup ? m->corr_dedup == 1 : likely)) ? 1 : 0;
     }
 
     // Batches on lattices of at most 26 x 32 (a lattice row = two lanes of 13 hypotheses) without merged offsets: the
@@ -669,7 +670,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : 8;
         if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
         P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
-        P.region26 = !yag && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
+        P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
                      lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         if (P.region26) {
             P.n_groups = P.rg_ng;
@@ -680,7 +681,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         }
     }
     // Other batches on lattices of at most 48 x 64: the general form (ym_k_gather.hpp).
-    P.region = !P.region26 && !yag && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
+    P.region = !wrap && !P.region26 && !yag && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
     if (P.region) {
         // lanes: a lane owns 16 x-adjacent hypotheses of one lattice row; a group of 32 lanes = up to 32 rows of one
         // segment (conflict-free LDS reads), or the rows past 32 of several segments; a wave = two groups
@@ -1407,7 +1408,7 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
     }
 }
 
-int launch_call(ym_matcher *m, Slot &slot) {
+int launch_call_body(ym_matcher *m, Slot &slot) {
     DEV_GUARD(m->device);
     CallPlan P;
     int rc;
@@ -1451,6 +1452,23 @@ int launch_call(ym_matcher *m, Slot &slot) {
     m->last_sums_stride[1] = slot.call.refine ? (P.yag ? P.yvol : P.sums_f) : 0;
     m->last_valid = true;
     return YM_OK;
+}
+
+// The point cache is updated by plan_cache BEFORE the kernels that fill its new or re-posed entries are enqueued.  If
+// anything after that fails (typically an allocation for a large batch), those entries would stay "current" without
+// ever having been written, and a later, smaller call would read garbage from them: every entry this call touched is
+// made stale again (a pose no scan can have), and the slot's descriptor shadow is dropped (it may name stale = 0).
+int launch_call(ym_matcher *m, Slot &slot) {
+    const uint64_t before = m->call_counter;
+    const int rc = launch_call_body(m, slot);
+    if (rc != YM_OK) {
+        if (m->call_counter != before)
+            for (ym_matcher::CacheEntry &ce : m->cache_entries)
+                if (ce.stale_in_call == m->call_counter) ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
+        slot.desc_shadow.clear();
+        slot.in_flight = false;
+    }
+    return rc;
 }
 
 void state_to_result(const ym_matcher *m, const Slot &slot, const YmItemState &s, int expansions, int64_t prior_hyp,
@@ -1507,6 +1525,8 @@ int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */)
         const int64_t prev_hyp = nxy * (int64_t)(kt_round_h(off * 2.0 / m->cfg.coarse_angle_resolution) + 1);
         off += 20.0 * YM_KT_PI / 180.0;
         Slot &s2 = m->slots[kAsyncSlots];
+        if (&s2 != &slot && s2.in_flight && s2.call.slice)
+            return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
         Call sub;
         sub.scans = base_call.scans;
         sub.penalize = base_call.penalize;
@@ -1779,6 +1799,8 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
     if (!out) return set_err(YM_ERR_INVALID, "null result");
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
     Slot &slot = m->slots[kAsyncSlots];
+    if (slot.in_flight && slot.call.slice)
+        return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
     Call call;
     int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
     if (rc) return rc;
@@ -1798,6 +1820,8 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
         if ((rc = check_desc(&base[i]))) return rc;
         total += (size_t)base[i].n;
     }
+    if (m->slots[kAsyncSlots].in_flight && m->slots[kAsyncSlots].call.slice)
+        return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
     DEV_GUARD(m->device);
     // the staging buffers may still feed an earlier async copy on this stream
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -2222,6 +2246,7 @@ ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, doub
     unsigned *d_cnt = nullptr;
     uint8_t *d_img = nullptr;
     ym_occupancy *og = nullptr;
+    bool said = false; // this call has set its own error message (the thread's last message may be an older one)
     bool ok = hipMalloc(reinterpret_cast<void **>(&d_scans), sizeof(YmScanRef) * n_scans) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&d_boxes), sizeof(double) * 4 * n_scans) == hipSuccess &&
               hipMemcpy(d_scans, hs.data(), sizeof(YmScanRef) * n_scans, hipMemcpyHostToDevice) == hipSuccess;
@@ -2231,7 +2256,7 @@ ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, doub
         a.scans = d_scans; a.n_scans = n_scans; a.max_n = max_n; a.range_threshold = range_threshold; a.boxes = d_boxes;
         hipLaunchKernelGGL(ym::occ_bbox_kernel, dim3(n_scans), dim3(256), 0, nullptr, a);
         std::vector<double> boxes((size_t)4 * n_scans);
-        ok = hipMemcpy(boxes.data(), d_boxes, sizeof(double) * boxes.size(), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(boxes.data(), d_boxes, sizeof(double) * boxes.size(), hipMemcpyDeviceToHost) == hipSuccess;
         if (ok) {
             // OccupancyGrid::ComputeDimensions: the scans' bounding boxes joined, width = Round(size * scale)
             double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
@@ -2243,6 +2268,7 @@ ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, doub
             const int width = (int)kt_round_h((x1 - x0) * scale), height = (int)kt_round_h((y1 - y0) * scale);
             if (width <= 0 || height <= 0 || (double)width * height > 2.0e9) {
                 set_err(YM_ERR_UNSUPPORTED, "occupancy grid of %d x %d cells", width, height);
+                said = true;
                 ok = false;
             } else {
                 const size_t n = (size_t)width * height;
@@ -2253,13 +2279,14 @@ ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, doub
                     a.scale = scale; a.off_x = x0; a.off_y = y0; a.width = width; a.height = height;
                     a.pass = d_cnt; a.hits = d_cnt + n; a.image = d_img;
                     hipLaunchKernelGGL(ym::occ_trace_kernel, dim3((max_n + 255) / 256, n_scans), dim3(256), 0, nullptr, a);
+                    ok = hipGetLastError() == hipSuccess;
                     hipLaunchKernelGGL(ym::occ_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, a);
                     og = new ym_occupancy();
                     og->device = device;
                     og->info.width = width; og->info.height = height;
                     og->info.offset_x = x0; og->info.offset_y = y0; og->info.resolution = resolution;
                     og->image.resize(n);
-                    ok = hipGetLastError() == hipSuccess && hipMemcpy(og->image.data(), d_img, n, hipMemcpyDeviceToHost) == hipSuccess;
+                    ok = ok && hipGetLastError() == hipSuccess && hipMemcpy(og->image.data(), d_img, n, hipMemcpyDeviceToHost) == hipSuccess;
                 }
             }
         }
@@ -2269,7 +2296,7 @@ ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, doub
     if (d_cnt) (void)hipFree(d_cnt);
     if (d_img) (void)hipFree(d_img);
     if (!ok) {
-        if (g_err.empty() || og) set_err(YM_ERR_HIP, "rendering the occupancy grid failed");
+        if (!said) set_err(YM_ERR_HIP, "rendering the occupancy grid failed: %s", hipGetErrorString(hipGetLastError()));
         delete og;
         return nullptr;
     }

@@ -150,6 +150,20 @@ __device__ __forceinline__ int lookup_offset(double2 p, double cosine, double si
     return gx + gy * pitch;
 }
 
+// ScanMatcher::GetResponse reads pByte[offset] after the test IsUpTo(gridPositionIndex + offset, data size) on the LINEAR
+// index: an offset that leaves the grid sideways wraps into a neighbouring row.  Inside the device window no offset of a
+// reading within the matcher's range threshold ever leaves it, so the fast kernels need no test and the per-cell paths test
+// against the window.  A query that holds a reading BEYOND that threshold (scans carry their own) is answered with the
+// window = Karto's whole storage and every linear index formed with Karto's row pitch (g.kpitch), exactly as Karto would:
+// lin_pitch() is the pitch of lookup offsets and hypothesis cells, cell_value() the read.
+__device__ __forceinline__ int lin_pitch(const YmGeom &g) { return g.kpitch ? g.kpitch : g.pitch; }
+__device__ __forceinline__ unsigned cell_value(const YmGeom &g, const uint8_t *grid, unsigned limit, unsigned idx) {
+    if (!g.kpitch) return idx < limit ? grid[idx] : 0u;
+    if (idx >= (unsigned)(g.kpitch * g.storage_w)) return 0u; // IsUpTo(index, data size)
+    const unsigned cy = idx / (unsigned)g.kpitch, cx = idx - cy * (unsigned)g.kpitch;
+    return cx < (unsigned)g.win_w ? grid[cy * (unsigned)g.pitch + cx] : 0u; // (the bytes between width and pitch are zero)
+}
+
 // hypothesis cells of one lattice axis: WorldToGrid(centre + (start + i*step)), window coordinates
 __device__ __forceinline__ int hyp_cell(double centre, double start, int i, double step, double off, const YmGeom &g) {
     const double v = start + i * step;

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
         for (int e = threadIdx.x; e < cw * a.chunk; e += YM_CORR_THREADS) {
             const int ci = e / a.chunk, c = e - ci * a.chunk;
             const int i = (group * cw + ci) * a.chunk + c;
-            int o = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) : 0;
+            int o = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, regular ? a.g.pitch : lin_pitch(a.g)) : 0;
             if (SX == 2 && regular) {
                 // window-linear index of hypothesis column 0 for this beam -> (plane, index in plane)
                 const int l = o + cx0;
@@ -306,11 +306,8 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
             const int ix = xg * G + j;
             unsigned sum = 0;
             if (ix < a.lat.nx) {
-                const int base = cyv * a.g.pitch + cx[ix];
-                for (int i = 0; i < n_here; i++) {
-                    const unsigned idx = (unsigned)(base + offs[i]);
-                    sum += idx < limit ? grid[idx] : 0u;
-                }
+                const int base = cyv * lin_pitch(a.g) + cx[ix];
+                for (int i = 0; i < n_here; i++) sum += cell_value(a.g, grid, limit, (unsigned)(base + offs[i]));
             }
             acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
         }

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
     int32_t *foff = a.foffsets + ((size_t)b * a.nt_stride + k) * a.max_n;
     const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
-    const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
+    const bool block3 = !a.g.kpitch && nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
                         s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
     if (block3) {
         // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its beam
@@ -422,12 +422,12 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     } else {
         // generic lattice: per beam, every (iy, ix) cell
         for (int i = tid; i < nq; i += NT) {
-            const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+            const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, lin_pitch(a.g));
             foff[i] = off;
             for (int c = 0; c < nxy; c++) {
                 const int iy = c / nx, ix = c - iy * nx;
-                const unsigned idx = (unsigned)(s_cy[iy] * a.g.pitch + s_cx[ix] + off);
-                if (idx < limit) atomicAdd(&s_sum[c], (unsigned)grid[idx]);
+                const unsigned v = cell_value(a.g, grid, limit, (unsigned)(s_cy[iy] * lin_pitch(a.g) + s_cx[ix] + off));
+                if (v) atomicAdd(&s_sum[c], v);
             }
         }
     }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         const double best_angle = kt_normalize_angle_difference(mean[2], ct);
         const int gx = world_to_grid(mean[0], off_x, a.g.scale) + a.g.border - a.g.win_origin;
         const int gy = world_to_grid(mean[1], off_y, a.g.scale) + a.g.border - a.g.win_origin;
-        const int base = gy * a.g.pitch + gx;
+        const int base = gy * lin_pitch(a.g) + gx;
         const int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
         __syncthreads(); // s_asum cleared above
         // GetResponse(angle k, cell of the mean pose) uses the fine pass's own lookup offsets, so when that cell is one
@@ -532,10 +532,10 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
                     const int w = w0 + u * NT + tid;
                     kk[u] = w < total ? w / nq_pad : -1; // wave-uniform
                     const int i = w - kk[u] * nq_pad;
-                    idx[u] = (kk[u] >= 0 && i < nq) ? (unsigned)(base + foff[(size_t)kk[u] * a.max_n + i]) : limit;
+                    idx[u] = (kk[u] >= 0 && i < nq) ? (unsigned)(base + foff[(size_t)kk[u] * a.max_n + i]) : 0xffffffffu; // (never a cell)
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = idx[u] < limit ? grid[idx[u]] : 0u;
+                for (int u = 0; u < 8; u++) v[u] = cell_value(a.g, grid, limit, idx[u]);
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const unsigned sum = wave_reduce(v[u], OpAddU());
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
         for (int h = tid; h < nh; h += NT) s_sum[h] = 0u;
         __syncthreads();
         const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
-        const bool block3 = nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
+        const bool block3 = !a.g.kpitch && nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
                             s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
         for (int k = wave; k < nt; k += NW) { // wave-uniform
             const double cosine = s_cs[k].x, sine = s_cs[k].y;
@@ -673,11 +673,11 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
             } else {
                 // generic lattice: per beam, every (iy, ix) cell
                 for (int i = lane; i < nq; i += 64) {
-                    const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch);
+                    const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, lin_pitch(a.g));
                     for (int c = 0; c < nxy; c++) {
                         const int iy = c / nx, ix = c - iy * nx;
-                        const unsigned idx = (unsigned)(s_cy[iy] * a.g.pitch + s_cx[ix] + off);
-                        if (idx < limit) atomicAdd(&s_sum[k * nxy + c], (unsigned)grid[idx]);
+                        const unsigned v = cell_value(a.g, grid, limit, (unsigned)(s_cy[iy] * lin_pitch(a.g) + s_cx[ix] + off));
+                        if (v) atomicAdd(&s_sum[k * nxy + c], v);
                     }
                 }
             }
@@ -719,14 +719,12 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
         if (hit_x >= 0 && hit_y >= 0) {
             for (int k = tid; k < nt; k += NT) s_asum[k] = s_sum[k * nxy + hit_y * nx + hit_x];
         } else {
-            const int base = gy * a.g.pitch + gx;
+            const int base = gy * lin_pitch(a.g) + gx;
             for (int k = wave; k < nt; k += NW) {
                 const double cosine = s_cs[k].x, sine = s_cs[k].y;
                 unsigned v = 0;
-                for (int i = lane; i < nq; i += 64) {
-                    const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch));
-                    v += idx < limit ? grid[idx] : 0u;
-                }
+                for (int i = lane; i < nq; i += 64)
+                    v += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, lin_pitch(a.g))));
                 v = wave_reduce(v, OpAddU());
                 if (lane == 0) s_asum[k] = v;
             }

@@ -646,12 +646,10 @@ __global__ __launch_bounds__(1024) void gather_percell_kernel(GatherArgs a) {
                 for (int j = 0; j < YM_GA_G; j++) {
                     const int ix = seg * YM_GA_G + j;
                     if (ix >= nx) break;
-                    const int base = cy[row] * a.g.pitch + cx[ix];
+                    const int base = cy[row] * lin_pitch(a.g) + cx[ix];
                     unsigned sum = 0;
-                    for (int i = i0; i < i1; i++) {
-                        const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, a.g.pitch));
-                        sum += idx < limit ? grid[idx] : 0u;
-                    }
+                    for (int i = i0; i < i1; i++)
+                        sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
                     // hypothesis j of dword j >> 2: even ones in E (low / high half), odd ones -- and the even high one -- in S
                     // exactly as the sum of (dword >> 8) would hold them
                     if ((j & 1) == 0) E[n][p2][j >> 2] += sum << (8 * (j & 2));

@@ -214,7 +214,7 @@ __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmI
     __syncthreads();
     {
         const int stx = kt_round_int(a.lat.step_x * a.g.scale), sty = kt_round_int(a.lat.step_y * a.g.scale);
-        int ok = 1;
+        int ok = a.g.kpitch == 0; // (Karto's linear-index test over the whole storage: the per-cell paths)
         for (int i = tid; i < a.lat.nx; i += NT) ok &= (cx[i] == cx[0] + i * stx);
         for (int i = tid; i < a.lat.ny; i += NT) ok &= (cy[i] == cy[0] + i * sty);
         ok = __syncthreads_and(ok);

@@ -34,6 +34,13 @@ namespace ym {
 // bytes the host keeps past the last item's planes: a staged region may start up to (ROWS - 1) * 2 + 1 rows and 96 bytes
 // past the last cell of the second plane (never gathered, but read)
 #define YM_RG_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(half_pitch) + 256)
+// (what the staging loop of correlate_region_kernel reads of the last item: class 3, task row ROWS - 1 of a region that
+//  starts at most H - 1 class rows before the window's last one, i.e. plane row 2 * (H - 1 + ROWS - 1) + 1 past it, and
+//  16 * SEGS bytes along it)
+static_assert(2 * YM_RG_ROWS + 2 * YM_RG_H + 2 >= 2 * (YM_RG_H - 1 + YM_RG_ROWS - 1) + 1 + 1, "YM_RG_PLANES_SLACK does not cover the rows a staged region reads");
+static_assert(256 >= 16 * YM_RG_SEGS, "YM_RG_PLANES_SLACK does not cover the bytes a staged row reads");
+static_assert(16 * YM_RG_SEGS >= YM_RG_W + 2 * YM_RG_G + 3 && YM_RG_PITCH >= 16 * YM_RG_SEGS && (YM_RG_PITCH / 4) % 2 == 1,
+              "a staged row must hold the region, the patch margin and the misalignment, at an odd number of dwords per row");
 #define YM_RG_MAX_BINS 8192
 #define YM_RG_MAX_REGIONS 96                   // regions with work a block of correlate_region_kernel can list
 #define YM_RG_MAX_ENTRIES 28672
@@ -436,13 +443,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             for (int j = 0; j < YM_RG_G; j++) {
                 const int ix = half * YM_RG_G + j;
                 if (ix >= nx) break;
-                const int base = cy[row] * a.g.pitch + cx[ix];
+                const int base = cy[row] * lin_pitch(a.g) + cx[ix];
                 unsigned sum = 0;
                 const int i1 = min(nq, (g + 1) * YM_RG_FLUSH);
-                for (int i = g * YM_RG_FLUSH; i < i1; i++) {
-                    const unsigned idx = (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, a.g.pitch));
-                    sum += idx < limit ? grid[idx] : 0u;
-                }
+                for (int i = g * YM_RG_FLUSH; i < i1; i++)
+                    sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
                 acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
             }
             flush();

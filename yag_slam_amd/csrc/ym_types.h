@@ -34,6 +34,8 @@ struct YmGeom {
     int32_t win_w;       // window width = height in cells
     int32_t pitch;       // bytes per window row (multiple of 64, >= win_w + 64)
     int32_t semantics;
+    int32_t kpitch;      // 0, or Karto's own row pitch (storage width rounded up to 8): the call answers through GetResponse's
+    int32_t pad;         // linear-index test over Karto's WHOLE storage (a query reading beyond the matcher's range threshold)
     // penalties (Karto CorrelateScan)
     double dist_var, ang_var, min_dist_pen, min_ang_pen;
 };

@@ -149,6 +149,17 @@ class LocalizedRangeScan:
     def points_for_pose2d(self, x, y, t):
         return point_readings(self.ranges, x, y, t, self.min_angle, self.angle_increment, self.range_threshold)
 
+    @classmethod
+    def from_json(cls, d, x, y, t, invert=True):
+        """A scan from a ROS LaserScan message dumped as a dict (ranges, angle_min / _max / _increment, range_min / _max) at
+        pose (x, y, t), the way /root/reference/yag_slam/models.py:110-116 reads its logs: beams reversed unless
+        invert=False, the scan's own range threshold = 90 % of the sensor's maximum range."""
+        beams = list(d["ranges"])
+        if invert:
+            beams.reverse()
+        sensor = (d["angle_min"], d["angle_max"], d["angle_increment"], d["range_min"], d["range_max"], d["range_max"] * 0.9)
+        return cls(beams, *sensor, x, y, t)
+
     def copy(self):
         """A detached scan with the same readings at the corrected pose (graph_slam.py:233 matches a moved copy);
         it gets its own device twin on first use."""

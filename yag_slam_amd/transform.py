@@ -23,9 +23,15 @@ class Transform(object):
         self.x = float(x)
         self.y = float(y)
         self.z = float(z)
-        if len(rest) == 4 or "qw" in kw:
-            qz = float(rest[2] if len(rest) == 4 else kw.get("qz", 0.0))
-            qw = float(rest[3] if len(rest) == 4 else kw.get("qw", 1.0))
+        quat_keys = [k for k in ("qx", "qy", "qz", "qw") if k in kw]
+        if len(rest) == 4 or quat_keys:
+            if len(rest) not in (0, 4) or (quat_keys and (len(rest) == 4 or "qw" not in kw)):
+                raise TypeError("a quaternion needs all of qx, qy, qz, qw (got %s)" % (quat_keys or len(rest)))
+            qx, qy, qz, qw = (float(v) for v in (rest if len(rest) == 4 else
+                                                 (kw.get("qx", 0.0), kw.get("qy", 0.0), kw.get("qz", 0.0), kw["qw"])))
+            if abs(qx) > 1e-9 or abs(qy) > 1e-9:
+                # (a map file written for a 3-D pose: its yaw alone would be a wrong pose, silently)
+                raise ValueError("not a planar rotation: qx = %r, qy = %r" % (qx, qy))
             self._yaw = 2.0 * math.atan2(qz, qw)
         elif len(rest) <= 1:
             self._yaw = float(rest[0] if rest else kw.get("yaw", 0.0))
