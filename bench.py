@@ -17,7 +17,17 @@ per step.  `value` = lattice points scored by all ranks / wall time of K steps.
 
 `config.by_config` carries the other BASELINE configs measured in the same run: cfg1 (CPU oracle), cfg2 as ONE
 unbatched match_scan call, cfg3 (2000-scan sequential mapping), cfg4 (1 query vs 4096 distinct chains, the chains
-sharded over the ranks = strong scaling, RCCL arg-max), cfg5 (stress lattice).
+sharded over the ranks = strong scaling, RCCL arg-max), cfg5 (stress lattice) -- and what production would see of the
+metric workload: `cfg2x_batch_sweep` (1 query x N chains per enqueue, N = 8 ... 4096), `cfg2x_fresh_query` (a NEW query
+every enqueue: descriptor copy, query projection and the query's pair lists inside the timed loop) and `cfg2x_cold`
+(every chain re-posed before every enqueue: the point cache misses on every scan).  A leg that raised is listed under
+`leg_errors` and makes the exit code non-zero.
+
+`roofline`: `bound` = the resource of the dominant kernel with the highest measured utilisation, `frac` <= 1 against that
+resource's peak.  The kernel's duration is measured in this run (HIP events on the launch stream); the counters behind
+the utilisations (VALU / LDS / HBM, `rocprofv3 --pmc`) are replayed from the committed `profiles/*.json` of the same
+kernel and say so (`replayed_from`).  `algorithmic_frac` keeps SURVEY.md 8(d)'s figure (one grid byte per beam and
+hypothesis against the HBM peak): above 1 means the bytes are served from LDS, not that a roof was broken.
 """
 import argparse
 import json
@@ -78,8 +88,7 @@ def self_launch(args):
             print(ln, file=sys.stderr)
     if line is not None:
         print(line)
-    if line is not None:
-        return 0  # the metric line exists; a by_config leg that failed says so in its own entry (and on stderr)
+        return p.returncode  # non-zero when a leg failed: the line then lists it under "leg_errors"
     return p.returncode if p.returncode != 0 else 1
 
 
@@ -522,26 +531,127 @@ def main():
         issue = profile_json("issue_correlate.json")
         region = LB >= 8 and args.corr_region != 1
         kernel = "ym::correlate_region_kernel<8>" if region else "ym::correlate_kernel<2, 16, 4>"
-        if traffic and traffic.get("kernel") != kernel:
+        if traffic and (traffic.get("kernel") != kernel or int(traffic.get("batch", 0)) != LB):
             traffic = None
-        if issue and issue.get("kernel") != kernel:
+        if issue and (issue.get("kernel") != kernel or int(issue.get("batch", 0)) != LB):
             issue = None
         step_alg = hyp_step * nq  # coarse + fine lattice points x one byte per valid beam
+        # utilisation of every resource the counters cover, over THIS run's kernel duration (2.4 GHz, 256 CUs)
+        clocks = corr_s * 2.4e9 * 256
+        res = {}
+        if issue:
+            res["valu_issue"] = {"achieved": issue["valu"]["per_launch"] / clocks, "peak": issue["valu"]["peak_per_cu_clk"],
+                                 "unit": "wave-instructions per CU and clock", "peak_source": issue["valu"]["peak_source"]}
+            res["lds"] = {"achieved": issue["lds"]["cycles_per_launch"] / clocks, "peak": 1.0, "unit": "LDS busy cycles per CU and clock"}
+        if traffic:
+            res["hbm"] = {"achieved": traffic["hbm_bytes_per_launch"] / corr_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        for r_ in res.values():
+            r_["frac"] = r_["achieved"] / r_["peak"]
+        bound = max(res, key=lambda k_: res[k_]["frac"]) if res else "hbm"
+        top = res.get(bound, {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
         line["roofline"] = {
-            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic and int(traffic.get("batch", 0)) == LB else None,
-            "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": corr_s * 1e6,
-            "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
-            # the whole step against the same roof: every kernel of the call, launch gaps and host work included
-            "frac_step": step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            # what actually binds the kernel (the patches are gathered from LDS, the grid bands live in L2): VALU issue and
-            # LDS busy cycles from the committed counter pass
-            "issue_rate": issue,
+            "bound": bound, "kernel": kernel, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "hbm_frac": res["hbm"]["frac"] if "hbm" in res else None,
+            "resources": res,
+            "replayed_from": ("counters of profiles/issue_correlate.json + profiles/traffic_correlate.json (%s); only kernel_us is "
+                              "measured in this run" % (issue or traffic or {}).get("source", "-")) if res else None,
+            "kernel_us": corr_s * 1e6, "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
+            # one grid byte per valid beam and hypothesis, against the HBM peak.  Not a roofline fraction:
+            # the bytes are gathered from LDS, where a staged byte is read ~19 times
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBS,
+            # the whole step against the same figure: every kernel of the call, launch gaps and host work included
+            "algorithmic_frac_step": step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }
+        line["config"]["point_cache"] = dict(zip(("hits", "misses"), m.cache_stats()))
+
+        # ---- what production would see of this workload (same run, after the timed region of the metric)
+        def timed_enqueues(bs, n):
+            """n back-to-back enqueues cycling over the batch objects `bs` on matcher m; seconds per enqueue, GPU ms per call"""
+            for i in range(min(4, n)):
+                bs[i % len(bs)].run_async(True, True, slot=i % 8)
+            for sl in range(min(4, n)):
+                bs[0].wait(sl, per_chain=False)
+            torch.cuda.synchronize()
+            m.profile(True)
+            t1 = time.perf_counter()
+            for i in range(n):
+                if i >= 8:
+                    bs[0].wait(i % 8, per_chain=False)
+                bs[i % len(bs)].run_async(True, True, slot=i % 8)
+            for sl in range(min(8, n)):
+                bs[0].wait(sl, per_chain=False)
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - t1) / n
+            cms, cn = m.profile_read(2)
+            m.profile_read(0)
+            m.profile_read(1)
+            m.profile(False)
+            return sec, cms / max(cn, 1)
+
+        def leg_sweep():
+            out = {"what": "1 query x N distinct chains per enqueue (resident, warm point cache), enqueues back to back"}
+            for n in (8, 64, 512, 4096):
+                if n > args.batch:
+                    continue
+                sec, gpu_ms = timed_enqueues([m.make_batch(query, chains[:n])], 64 if n <= 512 else 12)
+                out[str(n)] = {"hypotheses_per_s": hyp_per_match * n / sec, "us_per_enqueue": sec * 1e6, "gpu_us_per_enqueue": gpu_ms * 1e3,
+                               "us_per_match": sec * 1e6 / n}
+            return out
+
+        def leg_fresh_query():
+            # a loop-closure query is NEW every call: two queries (the same readings at two priors) alternate, so every
+            # enqueue copies its descriptor, projects its query and sorts the query's (beam, angle) pairs again
+            q2 = synth.resident_scan(q_ranges, (q_prior[0] + 0.013, q_prior[1] - 0.007, q_prior[2] + 0.004))
+            q2.native(local_rank)
+            n = min(LB, args.batch)
+            sec, gpu_ms = timed_enqueues([m.make_batch(query, chains[:n]), m.make_batch(q2, chains[:n])], 16)
+            return {"chains_per_enqueue": n, "hypotheses_per_s": hyp_per_match * n / sec, "us_per_enqueue": sec * 1e6,
+                    "gpu_us_per_enqueue": gpu_ms * 1e3, "what": "two queries alternate: no enqueue repeats its predecessor's descriptor"}
+
+        def leg_cold():
+            # every chain re-posed before every enqueue: the point cache misses on every base scan (points_kernel projects
+            # them again), the descriptor is new.  512 chains: the pose writes are Python + ctypes calls, ~0.5 us each
+            n = min(512, args.batch)
+            b1 = m.make_batch(query, chains[:n])
+            flat = [s_ for ch in chains[:n] for s_ in ch]
+            poses = [(s_.corrected_pose.x, s_.corrected_pose.y, s_.corrected_pose.euler[-1]) for s_ in flat]
+            hs = [s_.native(local_rank) for s_ in flat]
+            setp = m._lib.ym_scan_set_pose
+            import ctypes as C_
+            m.profile(True)
+            reps, host = 12, 0.0
+            t1 = time.perf_counter()
+            for i in range(reps):
+                d = 1e-4 * (1 + i % 2)
+                th = time.perf_counter()
+                for h_, p_ in zip(hs, poses):
+                    setp(h_, C_.c_double(p_[0] + d), C_.c_double(p_[1]), C_.c_double(p_[2]))
+                host += time.perf_counter() - th
+                if i >= 8:
+                    b1.wait(i % 8, per_chain=False)
+                b1.run_async(True, True, slot=i % 8)
+            for sl in range(8):
+                b1.wait(sl, per_chain=False)
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - t1) / reps
+            cms, cn = m.profile_read(2)
+            m.profile(False)
+            for h_, p_ in zip(hs, poses):  # the chains go back to where the other legs expect them
+                setp(h_, C_.c_double(p_[0]), C_.c_double(p_[1]), C_.c_double(p_[2]))
+            return {"chains_per_enqueue": n, "gpu_us_per_enqueue": cms / max(cn, 1) * 1e3, "hypotheses_per_s_gpu": hyp_per_match * n / (cms / max(cn, 1) * 1e-3),
+                    "wall_us_per_enqueue": sec * 1e6, "host_pose_writes_us_per_enqueue": host / reps * 1e6,
+                    "what": "every base scan re-posed before every enqueue (point cache misses on all of them)"}
+
+        if rank == 0:
+            sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold)]
+        else:
+            sweep_legs = []
         del batches
         for lm in lanes[1:]:
             lm.close()
+    else:
+        sweep_legs = []
 
     if dist is not None:
         dist.barrier()
@@ -552,6 +662,7 @@ def main():
         if rank == 0 and not emitted[0]:
             emitted[0] = True
             line["config"]["by_config"] = by_config
+            line["leg_errors"] = sorted(k_ for k_, v_ in by_config.items() if isinstance(v_, dict) and "error" in v_)
             if line["value"] is None:  # a development run of single legs: not a metric line
                 line["metric"] = "partial run (--only %s)" % args.only
             os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -574,6 +685,8 @@ def main():
         if rank == 0 and out is not None:
             by_config[name] = out
 
+    for name_, fn_ in sweep_legs:
+        guarded(name_, fn_)
     if "single" in legs and rank == 0:
         guarded("cfg2_single_match", lambda: leg_single(m, query, chains[0], m.match_scan(query, chains[0], True, True).meta["hypotheses"]))
     if "cfg3" in legs and rank == 0:
@@ -608,6 +721,8 @@ def main():
     emit()
     if dist is not None:
         dist.destroy_process_group()
+    if any(isinstance(v_, dict) and "error" in v_ for v_ in by_config.values()):
+        sys.exit(3)  # the line is out; a leg failed
 
 
 if __name__ == "__main__":

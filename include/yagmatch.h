@@ -252,6 +252,9 @@ int ym_debug_stamps(ym_matcher *m, int enable, uint64_t *out, int32_t count);
 int ym_profile_enable(ym_matcher *m, int on);
 /* which: 0 = correlate (coarse), 1 = raster, 2 = whole call; returns accumulated ms and launch count */
 int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launches, int reset);
+/* point cache of the matcher (what Karto's LocalizedRangeScan keeps in m_PointReadings until the pose is set again):
+ * scans found current / scans (re)projected since the matcher was created */
+int ym_cache_stats(const ym_matcher *m, int64_t *hits, int64_t *misses);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 # bench line.  The counter passes are scripts/profile_pmc.sh (counters are never combined with other tracing).
 #   scripts/profile_round.sh r02p
 # kernel trace of the default bench command; of one cfg2 match; of the stress match.
-tag=${1:-r02p}
+tag=${1:-r03p}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o ${tag} -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.log

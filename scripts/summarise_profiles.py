@@ -47,12 +47,25 @@ def main():
         if os.path.exists(f) and os.path.getsize(f) > 0:
             shutil.copy(f, os.path.join(prof, "%s_%s" % (short, src.replace("bench.json", "bench_line.json"))))
     fetch, l2, tcp, sq = kernel_means(tag, "fetch"), kernel_means(tag, "l2"), kernel_means(tag, "tcp"), kernel_means(tag, "sq")
+    sq2 = kernel_means(tag, "sq2")
     stats = {}
     f = os.path.join(REPO, "gpurun_out", "%s_stats" % tag, "%s_kernel_stats.csv" % tag)
     if os.path.exists(f):
         for r in csv.DictReader(open(f)):
             stats[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
     rows = []
+    W2 = ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_WAVES")
+    if sq2:
+        with open(os.path.join(prof, "%s_pmc_waves_batch%d.csv" % (short, batch)), "w") as o:
+            o.write("# rocprofv3 --pmc %s (one pass, nothing else traced): python3 bench.py --only cfg2x --steps 2 --warmup 1  (launch batch %d)\n" % (" ".join(W2), batch))
+            o.write("# means per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles of wave time (MI355X_MICROARCH.md): "
+                    "waiting (s_waitcnt, barrier) + issue stalls + issuing ~ wave cycles\n")
+            o.write("kernel," + ",".join(W2) + ",wait_any_share,wait_inst_share,active_share\n")
+            for k in sorted(sq2):
+                d = sq2[k]
+                wc = max(d.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+                o.write("%s,%s,%.3f,%.3f,%.3f\n" % (k, ",".join("%.0f" % d.get(c, 0.0) for c in W2), d.get("SQ_WAIT_ANY", 0.0) / wc,
+                                                   d.get("SQ_WAIT_INST_ANY", 0.0) / wc, d.get("SQ_ACTIVE_INST_ANY", 0.0) / wc))
     for k in sorted(set(fetch) | set(l2) | set(tcp) | set(sq)):
         rows.append((k, fetch.get(k, {}).get("FETCH_SIZE", 0.0), l2.get(k, {}).get("TCC_HIT_sum", 0.0), l2.get(k, {}).get("TCC_MISS_sum", 0.0),
                      tcp.get(k, {}).get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0), tcp.get(k, {}).get("TCP_TOTAL_ACCESSES_sum", 0.0),
@@ -79,9 +92,13 @@ def main():
         if dur and "region" in k and iv:
             clk = dur * 1e-9 * CLOCK_HZ
             json.dump({"kernel": k, "batch": batch, "kernel_us_under_rocprof": dur * 1e-3,
-                       "valu": {"counter": "SQ_INSTS_VALU", "per_launch": iv, "per_cu_clk": iv / (CU * clk), "peak_per_cu_clk": 1.0,
-                                "frac": iv / (CU * clk),
-                                "peak_source": "four 16-lane SIMDs per CU: one wave64 VALU instruction per clock per CU"},
+                       "valu": {"counter": "SQ_INSTS_VALU", "per_launch": iv, "per_cu_clk": iv / (CU * clk), "peak_per_cu_clk": 0.96,
+                                "frac": iv / (CU * clk) / 0.96,
+                                "peak_source": "MEASURED for this kernel's instruction mix (v_add / v_alignbyte / v_and / v_perm / v_add3 / "
+                                               "v_add): 0.961 wave-instructions per CU and clock at 8 waves per SIMD, "
+                                               "scripts/exp/valu_issue.hip, profiles/r03_issue_rates.md (1.0 for v_perm-class, "
+                                               "2.0 for v_and-class instructions alone)"},
+                       "waves": sq2.get(k),
                        "lds": {"counter": "SQ_LDS_IDX_ACTIVE", "cycles_per_launch": la, "bank_conflict_cycles": lc,
                                "frac": la / (CU * clk), "peak_source": "LDS busy cycles / (256 CUs x kernel clocks)"},
                        "source": os.path.relpath(pmc_csv, REPO)},

@@ -2456,4 +2456,11 @@ int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launche
     return YM_OK;
 }
 
+int ym_cache_stats(const ym_matcher *m, int64_t *hits, int64_t *misses) {
+    if (!m) return set_err(YM_ERR_INVALID, "null matcher");
+    if (hits) *hits = m->cache_hits;
+    if (misses) *misses = m->cache_misses;
+    return YM_OK;
+}
+
 }  // extern "C"

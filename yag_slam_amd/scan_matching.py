@@ -313,6 +313,12 @@ class ScanMatcher(object):
         _capi.check(self._lib.ym_debug_stamps(self._m, int(bool(enable)), buf, 32))
         return list(buf)
 
+    def cache_stats(self):
+        """(hits, misses) of the matcher's point cache since it was created"""
+        h, ms = C.c_int64(0), C.c_int64(0)
+        _capi.check(self._lib.ym_cache_stats(self._m, C.byref(h), C.byref(ms)))
+        return int(h.value), int(ms.value)
+
     def profile(self, on=True):
         _capi.check(self._lib.ym_profile_enable(self._m, int(bool(on))))
 
