@@ -222,7 +222,7 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
         for s in ch:
             s.native(loop_m.device)
     sh = ymdist.ShardedLoopMatcher.from_local_shard(loop_m, query, chains, lo, args.cfg4_chains, rank, world)
-    reps = 6
+    reps = 16  # (the first enqueue's host work is not hidden behind a predecessor: enough repetitions to amortise it)
     records = torch.zeros((reps, ymdist.RECORD), dtype=torch.float64, device="cuda")
     gathered = torch.zeros((reps, world * ymdist.RECORD), dtype=torch.float64, device="cuda")
 

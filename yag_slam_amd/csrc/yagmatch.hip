@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <atomic>
 #include <string>
 #include <unordered_map>
@@ -120,6 +121,7 @@ struct CallScan {
     double pose[3];
     double max_valid; // largest reading that survives range gating (bounds the query's reach)
     double lbox[4];   // sensor-frame bounding box of the points (bounds where a base scan can stamp)
+    double wbox[4];   // the same box at the scan's pose, in the world (xmin, ymin, xmax, ymax; empty: xmin > xmax)
     double beam_spacing = 0; // median valid reading x angular resolution: how far apart neighbouring end points are
     uint64_t id = 0;  // resident scan identity (0: ranges uploaded for this call only, never cached)
     int cache_hint = -1;            // entry of the matcher's point cache this scan used last time (ym_batch remembers it)
@@ -240,6 +242,7 @@ struct ym_scan {
     double max_valid_karto, max_valid_yagpy;
     double beam_spacing; // median valid reading x angular resolution
     double lbox[4]; // sensor-frame bounding box (xmin, ymin, xmax, ymax) of every reading that can become a point
+    double wbox[4]; // the box at the current pose, in the world: kept with the pose so that a call need not rotate 40 000 boxes
 };
 
 struct ym_map {
@@ -1063,24 +1066,20 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     // extended to the rectangles that may still hold old non-zero bytes in any of this call's items.
     int want[4] = {tiles_x, tiles_y, -1, -1};
     for (const CallItem &it : call.items) {
-        const CallScan &q = call.scans[it.query];
-        const double offx = q.pose[0] - (0.5 * (g.roi_w - 1) * g.res), offy = q.pose[1] - (0.5 * (g.roi_w - 1) * g.res);
+        double wx0 = 1e300, wy0 = 1e300, wx1 = -1e300, wy1 = -1e300; // the chain's boxes joined (kept with the scans' poses)
         for (int j = 0; j < it.base_count; j++) {
             const CallScan &bs = call.scans[it.base_begin + j];
-            if (bs.lbox[0] > bs.lbox[2]) continue; // no usable reading
-            const double c = std::cos(bs.pose[2]), sn = std::sin(bs.pose[2]);
-            double wx0 = 1e300, wy0 = 1e300, wx1 = -1e300, wy1 = -1e300;
-            for (int k = 0; k < 4; k++) {
-                const double lx = bs.lbox[(k & 1) ? 2 : 0], ly = bs.lbox[(k & 2) ? 3 : 1];
-                const double x = bs.pose[0] + c * lx - sn * ly, y = bs.pose[1] + sn * lx + c * ly;
-                wx0 = std::min(wx0, x); wx1 = std::max(wx1, x); wy0 = std::min(wy0, y); wy1 = std::max(wy1, y);
-            }
-            const double pad = g.half_kernel + 3; // smear reach + rounding slack, in cells
-            const double cx0 = (wx0 - offx) / g.res + g.border - g.win_origin - pad, cx1 = (wx1 - offx) / g.res + g.border - g.win_origin + pad;
-            const double cy0 = (wy0 - offy) / g.res + g.border - g.win_origin - pad, cy1 = (wy1 - offy) / g.res + g.border - g.win_origin + pad;
-            want[0] = std::min(want[0], (int)std::floor(cx0 / YM_TILE_W) - 1); want[2] = std::max(want[2], (int)std::floor(cx1 / YM_TILE_W) + 1);
-            want[1] = std::min(want[1], (int)std::floor(cy0 / YM_TILE_H) - 1); want[3] = std::max(want[3], (int)std::floor(cy1 / YM_TILE_H) + 1);
+            wx0 = std::min(wx0, bs.wbox[0]); wy0 = std::min(wy0, bs.wbox[1]);
+            wx1 = std::max(wx1, bs.wbox[2]); wy1 = std::max(wy1, bs.wbox[3]);
         }
+        if (wx0 > wx1) continue; // no usable reading
+        const CallScan &q = call.scans[it.query];
+        const double offx = q.pose[0] - (0.5 * (g.roi_w - 1) * g.res), offy = q.pose[1] - (0.5 * (g.roi_w - 1) * g.res);
+        const double pad = g.half_kernel + 3; // smear reach + rounding slack, in cells
+        const double cx0 = (wx0 - offx) / g.res + g.border - g.win_origin - pad, cx1 = (wx1 - offx) / g.res + g.border - g.win_origin + pad;
+        const double cy0 = (wy0 - offy) / g.res + g.border - g.win_origin - pad, cy1 = (wy1 - offy) / g.res + g.border - g.win_origin + pad;
+        want[0] = std::min(want[0], (int)std::floor(cx0 / YM_TILE_W) - 1); want[2] = std::max(want[2], (int)std::floor(cx1 / YM_TILE_W) + 1);
+        want[1] = std::min(want[1], (int)std::floor(cy0 / YM_TILE_H) - 1); want[3] = std::max(want[3], (int)std::floor(cy1 / YM_TILE_H) + 1);
     }
     want[0] = std::max(want[0], 0); want[1] = std::max(want[1], 0);
     want[2] = std::min(want[2], tiles_x - 1); want[3] = std::min(want[3], tiles_y - 1);
@@ -1412,14 +1411,23 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     DEV_GUARD(m->device);
     CallPlan P;
     int rc;
+    static const bool debug_host = getenv("YM_DEBUG_HOST") != nullptr; // development aid: host time of a call's phases
+    timespec t_[8];
+    auto mark = [&](int i) { if (debug_host) clock_gettime(CLOCK_MONOTONIC, &t_[i]); };
+    mark(0);
     if ((rc = plan_sizes(m, slot, P))) return rc;
+    mark(1);
     if ((rc = plan_cache(m, slot, P))) return rc;
+    mark(2);
     if ((rc = plan_jobs(m, slot, P))) return rc;
+    mark(3);
     if ((rc = plan_descriptor(m, slot, P))) return rc;
+    mark(4);
     hipStream_t st = m->stream;
     hipEvent_t ev_call = nullptr;
     if ((rc = prof_begin(m, 2, &ev_call))) return rc;
     if ((rc = plan_raster(m, slot, P))) return rc;
+    mark(5);
 
     enqueue_prepare(m, P);
     if ((rc = enqueue_select(m, P))) return rc;
@@ -1441,6 +1449,12 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     HIP_TRY(hipEventRecord(slot.done, st));
     slot.in_flight = true;
     slot.n_items = P.B;
+    mark(6);
+    if (debug_host) {
+        auto us = [&](int a, int b) { return (t_[b].tv_sec - t_[a].tv_sec) * 1e6 + (t_[b].tv_nsec - t_[a].tv_nsec) * 1e-3; };
+        fprintf(stderr, "[ym] host us: sizes %.0f cache %.0f jobs %.0f descriptor %.0f raster-plan %.0f enqueue %.0f (B %d, %d scans)\n", us(0, 1), us(1, 2),
+                us(2, 3), us(3, 4), us(4, 5), us(5, 6), P.B, P.nscans);
+    }
 
     m->last_geom = P.g;
     m->last_lat[0] = P.lc;
@@ -1575,7 +1589,7 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->range_threshold = s->range_threshold;
     o->pose[0] = s->pose[0]; o->pose[1] = s->pose[1]; o->pose[2] = s->pose[2];
     o->max_valid = semantics == YM_SEM_YAGPY ? s->max_valid_yagpy : s->max_valid_karto;
-    for (int i = 0; i < 4; i++) o->lbox[i] = s->lbox[i];
+    for (int i = 0; i < 4; i++) { o->lbox[i] = s->lbox[i]; o->wbox[i] = s->wbox[i]; }
     o->id = s->id;
     o->beam_spacing = s->beam_spacing;
     o->cache_hint = o->qcache_hint = -1;
@@ -1592,6 +1606,20 @@ void local_bbox(const double *r, int n, double min_angle, double inc, double rt,
         const double a = min_angle + i * inc, x = v * std::cos(a), y = v * std::sin(a);
         box[0] = std::min(box[0], x); box[1] = std::min(box[1], y);
         box[2] = std::max(box[2], x); box[3] = std::max(box[3], y);
+    }
+}
+
+// the sensor-frame box at a pose: world bounding box of its four corners (an empty box stays empty)
+void world_bbox(const double lbox[4], const double pose[3], double wbox[4]) {
+    wbox[0] = wbox[1] = 1e300;
+    wbox[2] = wbox[3] = -1e300;
+    if (lbox[0] > lbox[2]) return;
+    const double c = std::cos(pose[2]), sn = std::sin(pose[2]);
+    for (int k = 0; k < 4; k++) {
+        const double lx = lbox[(k & 1) ? 2 : 0], ly = lbox[(k & 2) ? 3 : 1];
+        const double x = pose[0] + c * lx - sn * ly, y = pose[1] + sn * lx + c * ly;
+        wbox[0] = std::min(wbox[0], x); wbox[2] = std::max(wbox[2], x);
+        wbox[1] = std::min(wbox[1], y); wbox[3] = std::max(wbox[3], y);
     }
 }
 
@@ -1755,6 +1783,7 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     s->d_ranges = nullptr;
     max_valid_ranges(d->ranges, d->n, d->min_range, d->range_threshold, &s->max_valid_karto, &s->max_valid_yagpy);
     local_bbox(d->ranges, d->n, d->min_angle, d->angle_increment, d->range_threshold, s->lbox);
+    world_bbox(s->lbox, s->pose, s->wbox);
     s->beam_spacing = median_beam_spacing(d->ranges, d->n, d->min_range, d->range_threshold, d->angle_increment);
     DevGuard guard(device);
     if (!guard.ok ||
@@ -1775,6 +1804,7 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
 int ym_scan_set_pose(ym_scan *s, double x, double y, double heading) {
     if (!s) return set_err(YM_ERR_INVALID, "null scan");
     s->pose[0] = x; s->pose[1] = y; s->pose[2] = heading;
+    world_bbox(s->lbox, s->pose, s->wbox);
     return YM_OK;
 }
 
@@ -1844,6 +1874,7 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
         max_valid_ranges(d.ranges, d.n, d.min_range, d.range_threshold, &k, &y);
         c.max_valid = m->cfg.semantics == YM_SEM_YAGPY ? y : k;
         local_bbox(d.ranges, d.n, d.min_angle, d.angle_increment, d.range_threshold, c.lbox);
+        world_bbox(c.lbox, c.pose, c.wbox);
         c.beam_spacing = median_beam_spacing(d.ranges, d.n, d.min_range, d.range_threshold, d.angle_increment);
         at += (size_t)d.n;
     }
