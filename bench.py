@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=1, help="matchers (stream + workspace each) the enqueues of a step alternate over")
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-production-legs", action="store_true",
+                    help="skip cfg2x_batch_sweep / _fresh_query / _cold (profiling runs: only launches of the metric's batch size)")
     ap.add_argument("--cfg4-chains", type=int, default=CFG4_CHAINS)
     ap.add_argument("--cfg3-scans", type=int, default=CFG3_SCANS)
     ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
@@ -643,7 +645,7 @@ def main():
                     "wall_us_per_enqueue": sec * 1e6, "host_pose_writes_us_per_enqueue": host / reps * 1e6,
                     "what": "every base scan re-posed before every enqueue (point cache misses on all of them)"}
 
-        if rank == 0:
+        if rank == 0 and not args.no_production_legs:
             sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold)]
         else:
             sweep_legs = []

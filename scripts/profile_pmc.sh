@@ -8,6 +8,6 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for spec in "fetch:FETCH_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum" "tcp:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" "sq:SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "sq2:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES"; do
   name=${spec%%:*}; ctr=${spec#*:}
   rm -rf $out/${tag}_$name
-  rocprofv3 --pmc $ctr --kernel-exclude-regex "rocclr|at::native" --output-format csv -d $out/${tag}_$name -o ${tag} -- python3 bench.py --only cfg2x --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_$name.log
+  rocprofv3 --pmc $ctr --kernel-exclude-regex "rocclr|at::native" --output-format csv -d $out/${tag}_$name -o ${tag} -- python3 bench.py --only cfg2x --no-production-legs --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_$name.log
   ls -la $out/${tag}_$name
 done

@@ -57,7 +57,7 @@ def main():
     W2 = ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_WAVES")
     if sq2:
         with open(os.path.join(prof, "%s_pmc_waves_batch%d.csv" % (short, batch)), "w") as o:
-            o.write("# rocprofv3 --pmc %s (one pass, nothing else traced): python3 bench.py --only cfg2x --steps 2 --warmup 1  (launch batch %d)\n" % (" ".join(W2), batch))
+            o.write("# rocprofv3 --pmc %s (one pass, nothing else traced): python3 bench.py --only cfg2x --no-production-legs --steps 2 --warmup 1  (launch batch %d)\n" % (" ".join(W2), batch))
             o.write("# means per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles of wave time (MI355X_MICROARCH.md): "
                     "waiting (s_waitcnt, barrier) + issue stalls + issuing ~ wave cycles\n")
             o.write("kernel," + ",".join(W2) + ",wait_any_share,wait_inst_share,active_share\n")
@@ -75,7 +75,7 @@ def main():
     with open(pmc_csv, "w") as o:
         o.write("# rocprofv3 --pmc FETCH_SIZE | --pmc TCC_HIT_sum TCC_MISS_sum | --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum | "
                 "--pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT (four separate passes, nothing else traced): "
-                "python3 bench.py --only cfg2x --steps 2 --warmup 1  (launch batch %d)\n" % batch)
+                "python3 bench.py --only cfg2x --no-production-legs --steps 2 --warmup 1  (launch batch %d)\n" % batch)
         o.write("# means per launch.  FETCH_SIZE in KiB as reported; gfx950 counts half of a 16-B/lane stream (MI355X_MICROARCH.md): bytes ~= 2*1024*FETCH_SIZE\n")
         o.write("kernel,FETCH_SIZE_KiB,TCC_HIT_sum,TCC_MISS_sum,l2_hit_rate,TCP_TOTAL_CACHE_ACCESSES_sum,TCP_TOTAL_ACCESSES_sum,"
                 "SQ_INSTS_VALU,SQ_INSTS_LDS,SQ_LDS_IDX_ACTIVE,SQ_LDS_BANK_CONFLICT\n")
