@@ -1,4 +1,4 @@
-// ym_k_gather.hpp -- K4g: the coarse correlate of BATCHES, gathered from LDS region by region (round 3 form).
+// ym_k_gather.hpp -- K4g: the coarse correlate of BATCHES on any lattice up to 48 x 64, gathered from LDS region by region.
 // Part of ym_kernels.hpp (include that, not this file).
 //
 // The hypotheses of one beam are every other cell of every other row of the window, i.e. a DENSE nx x ny block of bytes
@@ -10,18 +10,20 @@
 //                         space the patch starts in, the angle, the patch's byte alignment and its multiplicity; packed as
 //                         32-bit UNITS of two patches of equal alignment and multiplicity (the odd patch of a class is a
 //                         unit of its own, listed behind the pairs); a work list of regions.
-//   gather_kernel         one block per item walks the work list: the loads of region i + 1 (ONE class image + the region's
-//                         units + its row of the bin table) are in flight in registers while region i is gathered from
-//                         LDS.  A wave owns NA angles and keeps their sums in registers; a lane owns 16 x-adjacent
-//                         hypotheses of one lattice row and reads their 20 bytes as three ds_read_b64 (LDS row pitch = 8 x
-//                         odd: conflict-free at 256 B/clk); the raw dwords of a unit's two patches are added as packed
-//                         bytes (<= 200), byte-aligned by one v_alignbyte per dword and widened into 16-bit lanes (even
-//                         bytes: v_and + v_add; odd bytes: the sum of x >> 8, separated when the sums leave the
-//                         registers), times the multiplicity where there is one.  Units are decoded by vector
-//                         instructions on wave-uniform registers: the scalar ALU issues no faster than the vector ALU
-//                         (profiles/r03_issue_rates.md) and the loop keeps it for loop control.  The block then scores its
-//                         sums itself.
-// Every region is staged ONCE per item (round 2 staged every region three times, once per block of an item's angles).
+//   gather_kernel         a block of an item (eight waves, one coarse angle each; ceil(nt / 8) blocks per item) walks the work
+//                         list: the loads of region i + 1 (ONE class image + the region's units + its row of the bin
+//                         table) are in flight in registers while region i is gathered from LDS.  A wave keeps its angle's
+//                         sums in registers; a lane owns 16 x-adjacent hypotheses of one lattice row and reads their 20 bytes
+//                         as three ds_read_b64 (LDS row pitch = 8 x odd: conflict-free at 256 B/clk); the raw dwords of a
+//                         unit's two patches are added as packed bytes (<= 200), byte-aligned by one v_alignbyte per dword
+//                         and widened into 16-bit lanes (even bytes: v_and + v_add; odd bytes: the sum of x >> 8, separated
+//                         when the sums leave the registers), times the multiplicity where there is one.  Units are decoded
+//                         by vector instructions on wave-uniform registers: the scalar ALU issues no faster than the vector
+//                         ALU (profiles/r03_issue_rates.md) and the loop keeps it for loop control.  The block then scores
+//                         its sums itself.
+// On the default 26 x 26 lattice the round-2 form (ym_k_region.hpp: 13 hypotheses per lane, four dwords per patch) needs a
+// third fewer vector instructions and keeps that domain; this file serves every other batch lattice up to 48 x 64, merged
+// offsets and scans of any length.  What was measured on the way: profiles/r03_gather_sweep.md, r03_lds_dma_experiment.md.
 #pragma once
 
 namespace ym {
