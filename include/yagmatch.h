@@ -235,13 +235,16 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * always through the global-memory kernel; 11: threads per finish block (256 / 1024, 0 = by batch size);
  * 12: keep the coarse integer sums of batches of 8 or more items for ym_debug_sums (single matches always do);
  * 13: merging of consecutive beams with the same lookup offset in the correlate kernel (0 = by grid coarseness, 1 = always,
- * 2 = never); 14: coarse correlate of batches (0 = region-staged kernel where the lattice allows it, 1 = always the direct
- * kernel, 2 = the region kernel's per-cell path, 3 = its "entry list does not fit" path); 15: waves per region-correlate
- * block; 16: raster blocks per item on batches (0 = sized by the previous call's longest tile list; the rest of a list is
- * walked by a second, small launch); 17: 2 = the region-staged correlate leaves the scoring of its sums to the score kernel
- * (0: it scores them itself unless option 12 asks for the integer sums); 18: room in the raster's per-tile hit lists on
- * batches, in entries per tile (0 = 32; -1 = no lists: every raster block scans the item's chunk boxes, as it does for an item
- * whose lists do not fit). */
+ * 2 = never); 14: coarse correlate of batches (0 = the region correlate on lattices up to 26 x 32, the gather correlate on
+ * others up to 48 x 64, else the direct kernel; 1 = always the direct kernel, 2 = the LDS correlates' per-cell path, 3 = their
+ * "lists do not fit" path, 4 = the gather correlate also where the region correlate would run); 15: waves per
+ * region-correlate block / angles per wave of the gather correlate; 16: raster blocks per item on batches (0 = sized by the
+ * previous call's longest tile list; the rest of a list is walked by a second, small launch); 17: blocks per item of the gather
+ * correlate (each takes a share of the angles); 18: room in the raster's per-tile hit lists on batches, in entries per tile
+ * (0 = 32; -1 = no lists: every raster block scans the item's chunk boxes, as it does for an item whose lists do not fit);
+ * 19: units per LDS buffer of the gather correlate (small values cut regions into chunks); 20: LDS bytes a gather block may
+ * use (small values make the regions small); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
+ * (0: it scores them itself unless option 12 asks for the integer sums). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.
