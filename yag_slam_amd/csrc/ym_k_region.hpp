@@ -261,9 +261,18 @@ __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
+        // odd bytes: the running sum of (dword >> 8) = sum(4j + 1) + 2^8 sum(4j + 2) + 2^16 sum(4j + 3), separated by rg_odd()
+        // when the sums leave the registers (v_lshrrev issues at twice the rate of the v_perm that would pick the two odd
+        // bytes: profiles/r03_issue_rates.md; 652 patches of at most 100 keep the sum below 2^32)
         if (j < 3) // (acc[7] would hold hypotheses 13 and 15 of the lane: there are only 13)
-            acc[2 * j + 1] = acc[2 * j + 1] + __builtin_amdgcn_perm(0u, x[0][j], 0x0c030c01u) + __builtin_amdgcn_perm(0u, x[1][j], 0x0c030c01u);
+            acc[2 * j + 1] = acc[2 * j + 1] + (x[0][j] >> 8) + (x[1][j] >> 8);
     }
+}
+
+// acc[2j + 1] as rg_gather4 keeps it -> hypotheses 4j + 1 (low 16 bits) and 4j + 3
+__device__ __forceinline__ void rg_odd(uint32_t (&acc)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[2 * j + 1] -= (acc[2 * j] >> 16) << 8;
 }
 
 // grid (P, B): block (p, item) = NW waves, wave w owns coarse angle p * NW + w.  Lane = 13 x-adjacent hypotheses of one
@@ -305,7 +314,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     // partial set number `flushed` and starts the next (score_kernel adds the sets)
     int in_set = 0, flushed = 0;
     auto flush = [&]() {
-        if (flushed < ng) store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)flushed * nt + k) * 64 + lane) * 16, acc);
+        if (flushed < ng) {
+            rg_odd(acc);
+            store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)flushed * nt + k) * 64 + lane) * 16, acc);
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[j] = 0u;
         flushed++;
@@ -449,6 +461,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 for (int i = g * YM_RG_FLUSH; i < i1; i++)
                     sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
                 acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
+                if ((j & 3) == 2) acc[2 * (j >> 2) + 1] += sum << 8; // (what the sum of dword >> 8 holds of byte 2)
             }
             flush();
         }
@@ -476,6 +489,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     __syncthreads();
     if (kvalid) {
         unsigned tot[YM_RG_G];
+        rg_odd(acc);
 #pragma unroll
         for (int j = 0; j < YM_RG_G; j++) tot[j] = (acc[2 * (j >> 2) + (j & 1)] >> (16 * ((j >> 1) & 1))) & 0xffffu;
         for (int f = 0; f < min(flushed, ng); f++) { // the sets this lane wrote out earlier
