@@ -194,23 +194,33 @@ def leg_single(m, query, chain, hyp_per_match):
 
 def leg_cfg3(m, ranges, n):
     """BASELINE configs[2]: n scans through the call pattern of GraphSlam.process_scan (running chain of 10, grid
-    rebuilt at every step), every scan resident; wall time includes the Python driver."""
+    rebuilt at every step), every scan resident.  Two drivers on the same trajectory: the loop inside the library
+    (SequentialMapper.process_scans -> ym_map_sequence; `scan_matches_per_s`) and the per-scan Python calls a robot's node
+    makes (SequentialMapper.process_scan; `per_scan_calls`); both wall times include their driver."""
     from yag_slam_amd import synth
     from yag_slam_amd.mapping import SequentialMapper
-    truth, scans = synth.trajectory_scans(n, ranges=ranges)
-    for s in scans:
-        s.native(m.device)
-    mapper = SequentialMapper(m)
-    hyp = 0
-    t0 = time.perf_counter()
-    for s in scans:
-        res = mapper.process_scan(s)
-        if res is not None:
-            hyp += res.meta["hypotheses"]
-    dt = time.perf_counter() - t0
-    err = np.array([[s.corrected_pose.x - t[0], s.corrected_pose.y - t[1]] for s, t in zip(scans, truth)])
-    return {"scans": n, "seconds": dt, "scan_matches_per_s": (n - 1) / dt, "hypotheses_per_s": hyp / dt,
-            "hypotheses": hyp, "max_position_error_m": float(np.hypot(err[:, 0], err[:, 1]).max())}
+    out = {}
+    for driver in ("library_loop", "per_scan_calls"):
+        truth, scans = synth.trajectory_scans(n, ranges=ranges)
+        for s in scans:
+            s.native(m.device)
+        mapper = SequentialMapper(m)
+        t0 = time.perf_counter()
+        if driver == "library_loop":
+            results = mapper.process_scans(scans)
+        else:
+            results = [mapper.process_scan(s) for s in scans]
+        dt = time.perf_counter() - t0
+        hyp = sum(r.meta["hypotheses"] for r in results if r is not None)
+        err = np.array([[s.corrected_pose.x - t[0], s.corrected_pose.y - t[1]] for s, t in zip(scans, truth)])
+        out[driver] = {"scans": n, "seconds": dt, "scan_matches_per_s": (n - 1) / dt, "hypotheses_per_s": hyp / dt,
+                       "hypotheses": hyp, "max_position_error_m": float(np.hypot(err[:, 0], err[:, 1]).max()),
+                       "final_pose": [scans[-1].corrected_pose.x, scans[-1].corrected_pose.y, scans[-1].corrected_pose.euler[-1]]}
+    res = dict(out["library_loop"])
+    res["driver"] = "ym_map_sequence (SequentialMapper.process_scans)"
+    res["per_scan_calls"] = {k: out["per_scan_calls"][k] for k in ("seconds", "scan_matches_per_s", "hypotheses_per_s")}
+    res["drivers_agree"] = out["library_loop"]["final_pose"] == out["per_scan_calls"]["final_pose"]
+    return res
 
 
 def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):

@@ -124,6 +124,21 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
 int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base,
                    int penalize, int refine, ym_result *out);
 
+/* The matcher calls of GraphSlam.process_scan for a whole trajectory, in one call
+ * (/root/reference/yag_slam/graph_slam.py:306-339; the host loop a robot log is replayed with):
+ *   for i = max(start, 1) .. n-1:
+ *       prior_i     = corrected_{i-1} (+) (odom_i (-) odom_{i-1})                                graph_slam.py:320-324
+ *       results[i]  = match(scans[i] at prior_i, scans[max(0, i - buffer_len) .. i-1], penalize, refine)
+ *       corrected_i = results[i].pose                                                             graph_slam.py:326-337
+ * with tiny_tf's planar Transform arithmetic ((+) composes, a (-) b = inverse(b) (+) a), operation for operation what
+ * yag_slam_amd/transform.py does, so the poses are bit-identical to the per-scan calls.  scans[0 .. start) are the
+ * running chain so far and keep their poses; every later scan's pose is set to its prior and then to its result (as
+ * ym_scan_set_pose would).  odom = n poses (x, y, heading).  results = n entries, those of scans that are not matched
+ * are zeroed.  Stops at the first scan whose match reports YM_ERR_RANGE in its result (its pose stays at the prior);
+ * *n_done = index of the first scan NOT completed (n when all are). */
+int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, int n, int start, int buffer_len,
+                    int penalize, int refine, ym_result *results, int32_t *n_done);
+
 /* Pipelined form: enqueue on the matcher's stream, collect later.  `slot` in [0, ym_async_slots). */
 int ym_async_slots(const ym_matcher *m);
 int ym_match_scans_async(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base,
@@ -243,7 +258,8 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * correlate (each takes a share of the angles); 18: room in the raster's per-tile hit lists on batches, in entries per tile
  * (0 = 32; -1 = no lists: every raster block scans the item's chunk boxes, as it does for an item whose lists do not fit);
  * 19: units per LDS buffer of the gather correlate (small values cut regions into chunks); 20: LDS bytes a gather block may
- * use (small values make the regions small); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
+ * use (small values make the regions small); 22: 0 = synchronous matches do not pre-project their query at the result pose;
+ * 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
  * (0: it scores them itself unless option 12 asks for the integer sums). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 

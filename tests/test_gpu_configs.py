@@ -67,6 +67,73 @@ def test_cfg3_sequential_mapping_lockstep_with_oracle_then_2000_scans():
     assert min(r.response for r in mapper.results) > 0.3
 
 
+def test_process_scans_in_the_library_equals_the_per_scan_loop():
+    """`SequentialMapper.process_scans` (ym_map_sequence: priors, matches and pose updates in one library call) against
+    `process_scan` scan by scan on the same trajectory: identical bits in every pose, response and covariance; also when
+    the sequence continues a running chain, and in pieces."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n = 120
+    _, ref_scans = synth.trajectory_scans(n + 1)
+    _, lib_scans = synth.trajectory_scans(n + 1)
+    ref = SequentialMapper(ScanMatcher())
+    ref_out = [ref.process_scan(s) for s in ref_scans[:n]]
+    lib = SequentialMapper(ScanMatcher())
+    lib_out = lib.process_scans(lib_scans[:1]) + lib.process_scans(lib_scans[1:4])     # chain shorter than the buffer
+    lib_out += [lib.process_scan(lib_scans[4])]                                        # mixed with the per-scan call
+    lib_out += lib.process_scans(lib_scans[5:70]) + lib.process_scans(lib_scans[70:n])
+    assert lib_out[0] is None and ref_out[0] is None and len(lib_out) == n
+    for i in range(1, n):
+        a, b = ref_out[i], lib_out[i]
+        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta, i
+        pa, pb = ref_scans[i].corrected_pose, lib_scans[i].corrected_pose
+        assert (pa.x, pa.y, pa.euler[-1]) == (pb.x, pb.y, pb.euler[-1]), i
+        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (pb.x, pb.y, pb.euler[-1]), i
+        assert ref_scans[i].num == lib_scans[i].num == i
+    assert [s.num for s in lib.running_scans] == [s.num for s in ref.running_scans]
+    assert len(lib.results) == len(ref.results) == n - 1
+    # the device twins hold the corrected poses: one more per-scan match on both mappers agrees
+    ra, rb = ref.process_scan(ref_scans[n]), lib.process_scan(lib_scans[n])
+    assert ra.response == rb.response and ra.covariance == rb.covariance
+
+
+def test_pre_projection_of_the_query_at_its_result_pose_changes_nothing_but_the_cache_hits():
+    """Synchronous matches project their query at the pose they found into its own point-cache slot (prefill_kernel) so
+    that the next match, which uses it as a base scan, finds it: same results with the feature off (debug option 22),
+    one cache miss fewer per step with it on; a pose set behind the matcher's back is not served from the slot."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    n = 60
+    outs, stats = [], []
+    for on in (1, 0):
+        _, scans = synth.trajectory_scans(n)
+        m = ScanMatcher()
+        m.debug_option(22, on)
+        mp = SequentialMapper(m)
+        res = [mp.process_scan(s) for s in scans[:n // 2]] + mp.process_scans(scans[n // 2:])
+        outs.append([(r.response, r.covariance, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1]) for r in res[1:]])
+        stats.append(m.cache_stats())
+    assert outs[0] == outs[1]
+    (hit_on, miss_on), (hit_off, miss_off) = stats
+    assert miss_off - miss_on >= n // 2 and hit_on > hit_off  # (the rest: the arena growing while the map is young)
+    # a scan moved after its match: the slot filled at the result pose must not be used
+    _, scans = synth.trajectory_scans(12)
+    _, twin = synth.trajectory_scans(12)
+    a, b = ScanMatcher(), ScanMatcher()
+    b.debug_option(22, 0)
+    ma, mb = SequentialMapper(a), SequentialMapper(b)
+    for k in range(11):
+        ra, rb = ma.process_scan(scans[k]), mb.process_scan(twin[k])
+    for sc in (scans[10], twin[10]):
+        p = sc.corrected_pose
+        sc.corrected_pose = Transform(p.x + 0.013, p.y - 0.007, 0.0, p.euler[-1] + 0.004)
+    ra, rb = ma.process_scan(scans[11]), mb.process_scan(twin[11])
+    assert ra.response == rb.response and ra.covariance == rb.covariance
+
+
 def test_cfg4_loop_batch_4096_distinct_chains_against_oracle():
     """configs[3] on one GPU: the cfg2 query against 4096 distinct 10-scan chains at seeded poses (chain 0 = the query's own
     neighbourhood; every chain sees the same room, so it need not be the arg-best), loop config, penalty off, coarse only -- one match_scan_batch call.  A seeded sample of 96 chains

@@ -168,6 +168,35 @@ def test_sequential_mapper_call_pattern():
     assert len(mp.running_scans) == 10 and mp.running_scans[-1].num == 13
 
 
+def test_sequential_mapper_process_scans_falls_back_to_the_per_scan_loop():
+    # a matcher plugin without map_sequence (the reference's own, the oracle): process_scans = process_scan in a loop
+    from collections import namedtuple
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.transform import Transform
+    R = namedtuple("R", "best_pose response covariance meta")
+
+    class Stub:
+        def match_scan(self, q, base, pen, fine):
+            return R(Transform(q.corrected_pose.x + 0.01, q.corrected_pose.y, 0, q.corrected_pose.euler[-1]), 1.0, None, {"n": len(base)})
+
+    def scans():
+        out = []
+        for i in range(14):
+            s = LocalizedRangeScan([1.0] * 5, -1, 1, 0.5, 0, 10, 5, 0, 0, 0)
+            s.odom_pose = Transform(0.1 * i, 0.02 * i, 0, 0.01 * i)
+            out.append(s)
+        return out
+    a, b = SequentialMapper(Stub()), SequentialMapper(Stub())
+    sa, sb = scans(), scans()
+    ra = [a.process_scan(s) for s in sa]
+    rb = b.process_scans(sb[:3]) + b.process_scans(sb[3:])
+    assert rb[0] is None and [r.meta["n"] for r in rb[1:]] == [r.meta["n"] for r in ra[1:]]
+    assert all((x.corrected_pose.x, x.corrected_pose.y, x.corrected_pose.euler[-1]) ==
+               (y.corrected_pose.x, y.corrected_pose.y, y.corrected_pose.euler[-1]) for x, y in zip(sa, sb))
+    assert [s.num for s in b.running_scans] == list(range(4, 14)) and len(b.results) == 13
+
+
 def _light_scan(num, pose):
     from yag_slam_amd.transform import Transform
 

@@ -149,6 +149,10 @@ struct Call {
     int k_begin = 0, k_end = -1;
     double *ext_resp = nullptr, *ext_probs = nullptr;
     bool slice = false;
+    // single synchronous matches of a resident query: once the result is on its way to the host, the query is projected
+    // at the RESULT pose into its own slot of the point cache (prefill_kernel), in the shadow of the caller's turnaround:
+    // the next match that uses it as a base scan at that pose (GraphSlam.process_scan does) finds the slot filled
+    bool prefill = false;
 };
 
 // Everything one call's launches share: sizes, lattices, the device window, how the coarse correlate is cut up,
@@ -221,6 +225,11 @@ struct Slot {
     CallPlan plan;     // angle-sliced match: kept between ym_match_slice_begin and _finish
     void *dev_best_out = nullptr; // optional device buffer (8 doubles) for the cross-rank arg-max
     void *dev_best_user = nullptr; // the same pointer, kept until the slot is collected (rewritten after a response expansion)
+    int prefill_entry = -1;        // point-cache entry prefill_kernel fills for this call's query (its pose is set by finish_call)
+    uint64_t prefill_key = 0;
+    unsigned char *prefill_cache = nullptr;
+    uint32_t poll_serial = 0;      // != 0: final_kernel writes this number into the word after the result states when they are complete
+    uint32_t serial_counter = 0;
 };
 
 struct ProfEvents {
@@ -301,6 +310,8 @@ struct ym_matcher {
     DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
     DevBuf<int32_t> rg_starts;
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
+    bool prefill = true;     // synchronous single matches project their query at the result pose afterwards (Call::prefill)
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     // gather correlate: per query slot of a call the (beam, angle) units sorted by region, the bin table, the work
@@ -595,6 +606,9 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     const int centre = g.border + (g.roi_w - 1) / 2;
     const double reach = rq + coarse_off + (yag ? 3 : 1) * g.res; // yagpy's fine pass reaches 2 cells past the coarse box
     int wh = (int)std::ceil(reach / g.res) + 3;
+    // (in steps of 64 cells: the window -- and with it the "this tile is zero" knowledge about its memory -- then stays
+    //  the same from match to match while the queries' longest readings differ by less)
+    wh = (wh + 63) / 64 * 64;
     wh = wrap ? centre : std::min(wh, centre);
     g.win_origin = centre - wh;
     g.win_w = std::min(2 * wh + 1 + (yag ? 1 : 0), g.storage_w - g.win_origin); // even yagpy grids have no centre cell
@@ -826,6 +840,8 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
     Call &call = slot.call;
     const int n = (int)call.scans.size();
     for (CallScan &s : call.scans) { s.cache = s.qcache = nullptr; s.stale = s.qstale = 0; }
+    slot.prefill_entry = -1;
+    slot.prefill_cache = nullptr;
     if (m->cache_off) return YM_OK;
     const uint64_t this_call = ++m->call_counter;
     // roles of every scan in this call
@@ -916,6 +932,34 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
         }
         break;
     }
+    // the query's own slot as a base scan, filled after the call at the result pose (Call::prefill): until finish_call has
+    // seen that pose the entry holds one no scan can have
+    if (call.prefill && m->prefill && P.B == 1 && !P.yag && !call.slice) {
+        const CallScan &q = call.scans[call.items[0].query];
+        if (q.id != 0 && q.n > 0) {
+            const uint64_t key = q.id * 2;
+            int e = -1;
+            auto it = m->cache_index.find(key);
+            if (it != m->cache_index.end() && m->cache_entries[it->second].n == q.n) e = it->second;
+            if (e < 0) {
+                const size_t bytes = bytes_of(q, 0);
+                if (m->cache_used + bytes <= m->cache_arena.cap) {
+                    e = (int)m->cache_entries.size();
+                    m->cache_entries.push_back(ym_matcher::CacheEntry{key, m->cache_used, q.n, {0, 0, 0}, this_call});
+                    m->cache_index.emplace(key, e);
+                    m->cache_used += bytes;
+                }
+            }
+            if (e >= 0) {
+                ym_matcher::CacheEntry &ce = m->cache_entries[e];
+                ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
+                ce.stale_in_call = this_call;
+                slot.prefill_entry = e;
+                slot.prefill_key = key;
+                slot.prefill_cache = m->cache_arena.p + ce.off;
+            }
+        }
+    }
     return YM_OK;
 }
 
@@ -986,7 +1030,7 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
     const size_t items_bytes = align_up(sizeof(YmItem) * P.B, 16);
     P.desc_bytes = P.scans_bytes + items_bytes + sizeof(int32_t) * (2 * (size_t)P.n_jobs + P.qrep.size());
     if ((rc = slot.desc.ensure(P.desc_bytes))) return rc;
-    if ((rc = slot.result.ensure(sizeof(YmItemState) * P.B))) return rc;
+    if ((rc = slot.result.ensure(align_up(sizeof(YmItemState) * P.B, 64) + 64))) return rc; // (+ the completion word of single matches)
     YmScanRef *hs = P.hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
     YmItem *hi = P.hi = reinterpret_cast<YmItem *>(slot.desc.p + P.scans_bytes);
     for (int i = 0; i < P.nscans; i++) {
@@ -1396,6 +1440,8 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.probs_stride = (size_t)lc.nx * lc.ny; a.grid = m->grid.p; a.grid_stride = P.grid_stride;
     a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
     a.fsums_stride = P.sums_f; a.stamps = P.stamps;
+    a.host_flag = nullptr; a.serial = 0; a.pad1 = 0;
+    slot.poll_serial = 0;
     if ((P.B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
         const size_t lds = YM_FINISH_LDS_BYTES(call.refine ? (size_t)lf.nx * lf.ny * lf.nt : 0);
         const bool small_blocks = m->finish_threads ? m->finish_threads == 256 : P.B >= 512;
@@ -1403,17 +1449,23 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
         else hipLaunchKernelGGL(ym::finish_kernel<1024>, dim3(P.B), dim3(1024), lds, st, a);
     } else {
         hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
+        if (P.B == 1 && m->poll_completion) { // the caller polls a word final_kernel writes after the result (no stream event to wait for)
+            if (++slot.serial_counter == 0) slot.serial_counter = 1;
+            slot.poll_serial = a.serial = slot.serial_counter;
+            a.host_flag = reinterpret_cast<uint32_t *>(slot.result.dp + align_up(sizeof(YmItemState) * P.B, 64));
+        }
         hipLaunchKernelGGL(ym::final_kernel, dim3(P.B), dim3(YM_FINISH_THREADS), 0, st, a);
     }
 }
 
 int launch_call_body(ym_matcher *m, Slot &slot) {
-    DEV_GUARD(m->device);
-    CallPlan P;
-    int rc;
     static const bool debug_host = getenv("YM_DEBUG_HOST") != nullptr; // development aid: host time of a call's phases
     timespec t_[8];
     auto mark = [&](int i) { if (debug_host) clock_gettime(CLOCK_MONOTONIC, &t_[i]); };
+    mark(7);
+    DEV_GUARD(m->device);
+    CallPlan P;
+    int rc;
     mark(0);
     if ((rc = plan_sizes(m, slot, P))) return rc;
     mark(1);
@@ -1429,31 +1481,57 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     if ((rc = plan_raster(m, slot, P))) return rc;
     mark(5);
 
+    timespec e_[8];
+    auto emark = [&](int i) { if (debug_host) clock_gettime(CLOCK_MONOTONIC, &e_[i]); };
+    emark(0);
     enqueue_prepare(m, P);
+    emark(1);
     if ((rc = enqueue_select(m, P))) return rc;
     if ((rc = enqueue_raster(m, P))) return rc;
+    emark(2);
     if (P.yag) {
         enqueue_yagpy_passes(m, slot, P);
+        emark(3); emark(4); emark(5);
     } else {
         if ((rc = enqueue_correlate(m, P))) return rc;
+        emark(3);
         enqueue_score(m, slot, P);
+        emark(4);
         if (!slot.call.slice) enqueue_finish(m, slot, P);
         else slot.plan = P; // ym_match_slice_finish picks up here
+        emark(5);
     }
     if (slot.dev_best_out)
         hipLaunchKernelGGL(ym::argbest_kernel, dim3(1), dim3(256), 0, st, m->states.p, P.B, (long long)slot.chain_id_base,
                            reinterpret_cast<double *>(slot.dev_best_out));
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, ev_call))) return rc;
+    auto enqueue_prefill = [&]() {
+        ym::PrefillArgs pa;
+        std::memset(&pa, 0, sizeof pa);
+        pa.sr = P.hs[slot.call.items[0].query];
+        pa.sr.cache = slot.prefill_cache;
+        pa.state = m->states.p;
+        pa.max_n = pa.sr.n;
+        pa.stamps = P.stamps;
+        hipLaunchKernelGGL(ym::prefill_kernel<1024>, dim3(1), dim3(1024), YM_PREP_LDS_BYTES(pa.sr.n), st, pa);
+    };
+    // The caller must not wait for the prefill.  When it polls the completion word the event is only a fallback and goes
+    // last (an event between two kernels costs the second one ~2 us); otherwise the event is recorded before the prefill.
+    if (slot.prefill_cache && slot.poll_serial) enqueue_prefill();
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(slot.done, st));
     slot.in_flight = true;
     slot.n_items = P.B;
+    if (slot.prefill_cache && !slot.poll_serial) enqueue_prefill();
+    HIP_TRY(hipGetLastError());
     mark(6);
     if (debug_host) {
         auto us = [&](int a, int b) { return (t_[b].tv_sec - t_[a].tv_sec) * 1e6 + (t_[b].tv_nsec - t_[a].tv_nsec) * 1e-3; };
-        fprintf(stderr, "[ym] host us: sizes %.0f cache %.0f jobs %.0f descriptor %.0f raster-plan %.0f enqueue %.0f (B %d, %d scans)\n", us(0, 1), us(1, 2),
+        fprintf(stderr, "[ym] host us: guard %.1f sizes %.0f cache %.0f jobs %.0f descriptor %.0f raster-plan %.0f enqueue %.0f (B %d, %d scans)\n", us(7, 0), us(0, 1), us(1, 2),
                 us(2, 3), us(3, 4), us(4, 5), us(5, 6), P.B, P.nscans);
+        auto eus = [&](int a, int b) { return (e_[b].tv_sec - e_[a].tv_sec) * 1e6 + (e_[b].tv_nsec - e_[a].tv_nsec) * 1e-3; };
+        fprintf(stderr, "[ym] enqueue us: prepare %.1f raster %.1f correlate %.1f score %.1f finish %.1f\n", eus(0, 1), eus(1, 2), eus(2, 3), eus(3, 4), eus(4, 5));
     }
 
     m->last_geom = P.g;
@@ -1517,10 +1595,37 @@ void state_to_result(const ym_matcher *m, const Slot &slot, const YmItemState &s
 // wait for a slot; handle Karto's response expansion (re-run with a wider coarse angle range)
 int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */) {
     if (!slot.in_flight) return set_err(YM_ERR_BUSY, "slot has no call in flight");
-    HIP_TRY(hipEventSynchronize(slot.done));
+    bool seen = false;
+    if (slot.poll_serial) {
+        // single match: spin on the word final_kernel writes behind the result states (a stream event is signalled
+        // several microseconds after the kernel has ended); after 2 ms fall back to the event (a faulted kernel never writes)
+        const volatile uint32_t *flag = reinterpret_cast<const volatile uint32_t *>(slot.result.p + align_up(sizeof(YmItemState) * slot.n_items, 64));
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            for (int spin = 0; spin < 2048 && !seen; spin++) {
+                seen = *flag == slot.poll_serial;
+                if (!seen) __builtin_ia32_pause();
+            }
+            if (seen) break;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 2.0) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        slot.poll_serial = 0;
+    }
+    if (!seen) HIP_TRY(hipEventSynchronize(slot.done));
     slot.in_flight = false;
     const int B = slot.n_items;
     const YmItemState *hs = reinterpret_cast<const YmItemState *>(slot.result.p);
+    if (slot.prefill_entry >= 0) {
+        // prefill_kernel projects the query at the pose of THIS state (a response expansion re-runs the call and may end
+        // elsewhere: then the entry simply does not match the scan's next pose)
+        const int e = slot.prefill_entry;
+        if ((size_t)e < m->cache_entries.size() && m->cache_entries[e].id == slot.prefill_key && hs[0].status == 0 && hs[0].nq > 0)
+            for (int i = 0; i < 3; i++) m->cache_entries[e].pose[i] = hs[0].mean[i];
+        slot.prefill_entry = -1;
+    }
     std::vector<int> redo;
     std::vector<int64_t> prior(B, 0);
     for (int i = 0; i < B; i++) {
@@ -1834,6 +1939,7 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
     Call call;
     int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
     if (rc) return rc;
+    call.prefill = true;
     slot.call = call;
     if ((rc = launch_call(m, slot))) return rc;
     return finish_call(m, slot, out);
@@ -1888,6 +1994,66 @@ int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base,
     slot.call = call;
     if ((rc = launch_call(m, slot))) return rc;
     return finish_call(m, slot, out);
+}
+
+// tiny_tf's planar Transform arithmetic as yag_slam_amd/transform.py spells it (same operations in the same order: the
+// priors must be the bits the per-scan Python path produces)
+static void tf_compose(const double a[3], const double b[3], double out[3]) { // a + b
+    const double c = std::cos(a[2]), s = std::sin(a[2]);
+    const double x = a[0] + c * b[0] - s * b[1], y = a[1] + s * b[0] + c * b[1];
+    out[0] = x; out[1] = y; out[2] = a[2] + b[2];
+}
+static void tf_inverse(const double a[3], double out[3]) {
+    const double c = std::cos(a[2]), s = std::sin(a[2]);
+    const double x = -(c * a[0] + s * a[1]), y = -(-s * a[0] + c * a[1]);
+    out[0] = x; out[1] = y; out[2] = -a[2];
+}
+
+int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, int n, int start, int buffer_len,
+                    int penalize, int refine, ym_result *results, int32_t *n_done) {
+    if (!m || !scans || !odom || !results || !n_done) return set_err(YM_ERR_INVALID, "null argument");
+    if (n < 0 || start < 0 || buffer_len < 1) return set_err(YM_ERR_INVALID, "bad trajectory length, start or chain length");
+    *n_done = 0;
+    for (int i = 0; i < n; i++)
+        if (!scans[i]) return set_err(YM_ERR_INVALID, "null scan %d", i);
+    const int begin = std::min(n, std::max(start, 1));
+    for (int i = 0; i < begin; i++) std::memset(&results[i], 0, sizeof results[i]);
+    *n_done = begin;
+    static const bool debug_host = getenv("YM_DEBUG_HOST") != nullptr; // development aid: where a step's host time goes
+    timespec t0, t1, t2;
+    double us_launch = 0, us_wait = 0, us_build = 0;
+    int n_timed = 0;
+    for (int i = begin; i < n; i++) {
+        double inv[3], diff[3], prior[3];
+        tf_inverse(odom + 3 * (size_t)(i - 1), inv);              // query.odom_pose - last.odom_pose
+        tf_compose(inv, odom + 3 * (size_t)i, diff);
+        tf_compose(scans[i - 1]->pose, diff, prior);                // last.corrected_pose + that
+        int rc = ym_scan_set_pose(scans[i], prior[0], prior[1], prior[2]);
+        if (rc) return rc;
+        const int first = std::max(0, i - buffer_len);
+        if (debug_host) clock_gettime(CLOCK_MONOTONIC, &t0);
+        Slot &slot = m->slots[kAsyncSlots];
+        if (slot.in_flight && slot.call.slice)
+            return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
+        if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call))) return rc;
+        slot.call.prefill = true;
+        if (debug_host) { clock_gettime(CLOCK_MONOTONIC, &t1); us_build += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3; }
+        if ((rc = launch_call(m, slot))) return rc;
+        if (debug_host) clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((rc = finish_call(m, slot, &results[i]))) return rc;
+        if (debug_host) {
+            clock_gettime(CLOCK_MONOTONIC, &t2);
+            us_launch += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+            us_wait += (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3;
+            n_timed++;
+        }
+        if (results[i].status != 0) return YM_OK;
+        if ((rc = ym_scan_set_pose(scans[i], results[i].pose[0], results[i].pose[1], results[i].pose[2]))) return rc;
+        *n_done = i + 1;
+    }
+    if (debug_host && n_timed)
+        fprintf(stderr, "[ym] map_sequence: %d steps, build call %.1f us, build + plan + enqueue %.1f us, wait + result %.1f us per step\n", n_timed, us_build / n_timed, us_launch / n_timed, us_wait / n_timed);
+    return YM_OK;
 }
 
 int ym_async_slots(const ym_matcher *m) { return m ? kAsyncSlots : YM_ERR_INVALID; }
@@ -2434,6 +2600,8 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 13) m->corr_dedup = value;
     else if (option == 14) m->corr_region = value;
     else if (option == 15) m->corr_region_na = m->corr_region_nw = value;
+    else if (option == 22) m->prefill = value != 0;
+    else if (option == 23) m->poll_completion = value != 0;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;

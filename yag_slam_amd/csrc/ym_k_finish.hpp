@@ -166,6 +166,8 @@ struct FinishArgs {
     uint32_t *fsums;          // [B][nt_f*ny_f*nx_f] fine sums (kept for parity tests)
     size_t fsums_stride;
     unsigned long long *stamps;
+    uint32_t *host_flag;      // single matches: pinned host word that receives `serial` once host_out[0] is complete (the
+    uint32_t serial, pad1;    // caller polls it instead of waiting for a stream event), or null
 };
 
 // sum N doubles across the block in one round (2 barriers); result in every thread
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
             st.response = 0.0;
             st.coarse_response = 1.0; // nothing to retry with a wider angle
             if (a.host_out) a.host_out[b] = st;
+            if (a.host_flag) { __threadfence_system(); *reinterpret_cast<volatile uint32_t *>(a.host_flag) = a.serial; }
         }
         return;
     }
@@ -570,6 +573,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         st.coarse_response = coarse_response;
         st.status = status;
         if (a.host_out) a.host_out[b] = st;
+        if (a.host_flag) { __threadfence_system(); *reinterpret_cast<volatile uint32_t *>(a.host_flag) = a.serial; }
     }
     YM_STAMP(a, 19);
 }

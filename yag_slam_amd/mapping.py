@@ -36,6 +36,29 @@ class SequentialMapper(object):
         return res
 
 
+    def process_scans(self, scans):
+        """`process_scan` for every scan of a trajectory with the loop itself inside the library (`ym_map_sequence`: no
+        Python between two matches).  Same poses, results and running chain as calling `process_scan` scan by scan;
+        returns the list of results (None for the very first scan of a map)."""
+        scans = list(scans)
+        out = []
+        if scans and not self.running_scans:
+            out.append(self.process_scan(scans.pop(0)))
+        if not scans:
+            return out
+        native = getattr(self.seq_matcher, "map_sequence", None)
+        if native is None:
+            return out + [self.process_scan(s) for s in scans]
+        start = len(self.running_scans)
+        seq = self.running_scans + scans
+        for k in range(start, len(seq)):
+            seq[k].num = seq[k - 1].num + 1
+        res = native(seq, start, self.scan_buffer_len, True, True)
+        self.running_scans = seq[-self.scan_buffer_len:]
+        self.results.extend(res)
+        return out + res
+
+
 def _dist2(a, b):
     """squared planar distance between two scans' corrected poses (helpers.py:383-386)"""
     pa, pb = a.corrected_pose, b.corrected_pose

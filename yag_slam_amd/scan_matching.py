@@ -139,6 +139,35 @@ class ScanMatcher(object):
             raise _capi.YmError(res.status, "Mapper FATAL ERROR - unable to find best position / index out of range")
         return _result(res)
 
+    def map_sequence(self, scans, start, buffer_len, penalty=True, do_fine=True):
+        """The matcher calls of `GraphSlam.process_scan` (/root/reference/yag_slam/graph_slam.py:320-337) for
+        scans[start:], scans[:start] being the running chain so far: odometry prior from `odom_pose`, match against the
+        last `buffer_len` scans, `corrected_pose` = the match's pose -- one library call (`ym_match_scans` in a host
+        loop without Python).  Every scan must be resident (our LocalizedRangeScan).  Returns the results of
+        scans[start:]; raises like `match_scan` at the first scan Karto would abort on (the scans before it are done)."""
+        n = len(scans)
+        handles = (C.c_void_p * max(1, n))(*[self._require_native(s) for s in scans])
+        odom = np.empty((max(1, n), 3), dtype=np.float64)
+        for i, s in enumerate(scans):
+            p = s.odom_pose
+            odom[i, 0], odom[i, 1], odom[i, 2] = p.x, p.y, p.euler[-1]
+        per = (_capi.YmResult * max(1, n))()
+        done = C.c_int32(0)
+        _capi.check(self._lib.ym_map_sequence(self._m, handles, odom.ctypes.data_as(C.POINTER(C.c_double)), n, int(start),
+                                              int(buffer_len), int(bool(penalty)), int(bool(do_fine)), per, C.byref(done)))
+        first = max(int(start), 1)
+        res = _results(per)[first:done.value] if done.value > first else []
+        for s, r in zip(scans[first:done.value], res):
+            s._corrected_pose = r.best_pose  # (the device twin already has it)
+        if done.value < n:
+            bad = scans[done.value]
+            pose = (C.c_double * 3)()
+            _capi.check(self._lib.ym_scan_get_pose(bad._native, pose))
+            bad._corrected_pose = Transform(pose[0], pose[1], 0.0, pose[2])  # the prior, where the per-scan path leaves it
+            raise _capi.YmError(per[done.value].status, "Mapper FATAL ERROR - unable to find best position / index out of "
+                                "range (scan %d of the sequence)" % done.value)
+        return res
+
     def match_scan_batch(self, query, chains, penalty=False, do_fine=False):
         """One query against many candidate chains (the loop of graph_slam.py:217-236 in one call).
         Returns (per_chain_results, best_index)."""
