@@ -135,9 +135,16 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
  * running chain so far and keep their poses; every later scan's pose is set to its prior and then to its result (as
  * ym_scan_set_pose would).  odom = n poses (x, y, heading).  results = n entries, those of scans that are not matched
  * are zeroed.  Stops at the first scan whose match reports YM_ERR_RANGE in its result (its pose stays at the prior);
- * *n_done = index of the first scan NOT completed (n when all are). */
+ * *n_done = index of the first scan NOT completed (n when all are).
+ * device_chain != 0: no host round trip between steps either.  The steps are enqueued back to back, 128 at a time; the
+ * kernel that ends step i leaves scan i's pose and scan i+1's prior in device memory, where step i+1's kernels read them,
+ * and the host -- planning ahead of the device -- sizes each step's raster from poses it dead-reckons with the odometry
+ * alone.  The priors are then composed with the DEVICE's cos / sin: poses and responses agree with the synchronous form
+ * to rounding (~1e-12), not bit for bit.  A step whose cells leave the predicted rectangle, that Karto would abort, or
+ * that needs a response expansion is detected on the device, the rest of its segment is skipped, and the step is repeated
+ * synchronously.  Karto semantics, resident scans, buffer_len < 16; anything else runs synchronously. */
 int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, int n, int start, int buffer_len,
-                    int penalize, int refine, ym_result *results, int32_t *n_done);
+                    int penalize, int refine, int device_chain, ym_result *results, int32_t *n_done);
 
 /* Pipelined form: enqueue on the matcher's stream, collect later.  `slot` in [0, ym_async_slots). */
 int ym_async_slots(const ym_matcher *m);

@@ -15,6 +15,29 @@ t = time.perf_counter()
 mp.process_scans(scans[:N - 3 - 40])
 dt = time.perf_counter() - t
 print("library loop: %.1f us per step" % (dt * 1e6 / (N - 44)))
+_, scans2 = synth.trajectory_scans(N)
+for s in scans2:
+    s.native(0)
+mp2 = SequentialMapper(ScanMatcher())
+t = time.perf_counter()
+mp2.process_scans(scans2, device_chain=True)
+dt = time.perf_counter() - t
+print("device chain: %.1f us per step" % (dt * 1e6 / (N - 1)))
+_, scans3 = synth.trajectory_scans(N)
+for s in scans3:
+    s.native(0)
+m3 = ScanMatcher()
+mp3 = SequentialMapper(m3)
+mp3.process_scans(scans3[:200], device_chain=True)
+m3.debug_stamps(True)
+mp3.process_scans(scans3[200:300], device_chain=True)
+st = m3.debug_stamps(False)
+t0 = st[0]
+nm = ["prep:start","prep:points","prep:trig","","rast:start","rast:scan","rast:rowpass","rast:end",
+         "corr:start","corr:end","score:start","score:end","fine:start","fine:coarse","fine:cells","fine:end",
+         "final:start","final:fties","prep:qend","final:end"]
+print("chained step:", " ".join("%s %.2f" % (n_, (v - t0) / 100.0) for n_, v in zip(nm, st) if n_ and v), "idle before %.2f" % (st[28] / 100.0))
+print("agreement with the library loop at scan %d:" % (N - 44), scans[N - 44].corrected_pose, scans2[N - 44].corrected_pose)
 names = ["prep:start","prep:points","prep:trig","","rast:start","rast:scan","rast:rowpass","rast:end",
          "corr:start","corr:end","score:start","score:end","fine:start","fine:coarse","fine:cells","fine:end",
          "final:start","final:fties","prep:qend","final:end","pf:start","pf:points","pf:chain","pf:stored","pf:nxt","pf:ex","pf:hops"]

@@ -98,6 +98,41 @@ def test_process_scans_in_the_library_equals_the_per_scan_loop():
     assert ra.response == rb.response and ra.covariance == rb.covariance
 
 
+def test_device_chained_sequence_agrees_with_the_per_scan_loop():
+    """`process_scans(device_chain=True)`: the steps enqueued back to back, each step's pose handed to the next on the
+    device (the priors composed with the device's cos / sin).  Against `process_scan` scan by scan: poses and responses to
+    rounding, the same lattice sizes and hypothesis counts, the same running chain; a per-scan match afterwards sees the
+    poses the sequence left on the device twins."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n = 400
+    _, ref_scans = synth.trajectory_scans(n + 1)
+    _, dev_scans = synth.trajectory_scans(n + 1)
+    ref = SequentialMapper(ScanMatcher())
+    ref_out = [ref.process_scan(s) for s in ref_scans[:n]]
+    dev = SequentialMapper(ScanMatcher())
+    dev_out = dev.process_scans(dev_scans[:3], device_chain=True)          # (a chain shorter than the buffer)
+    dev_out += dev.process_scans(dev_scans[3:150], device_chain=True)      # more than one segment of 128
+    dev_out += [dev.process_scan(dev_scans[150])]
+    dev_out += dev.process_scans(dev_scans[151:n], device_chain=True)
+    assert len(dev_out) == n and dev_out[0] is None
+    worst = 0.0
+    for i in range(1, n):
+        a, b = ref_out[i], dev_out[i]
+        assert abs(a.response - b.response) <= 1e-9, (i, a.response, b.response)
+        pa, pb = ref_scans[i].corrected_pose, dev_scans[i].corrected_pose
+        d = max(abs(pa.x - pb.x), abs(pa.y - pb.y), abs(pa.euler[-1] - pb.euler[-1]))
+        assert d <= 1e-9, (i, d)
+        worst = max(worst, d)
+        np.testing.assert_allclose(np.array(a.covariance), np.array(b.covariance), rtol=1e-6, atol=1e-12)
+        assert a.meta["hypotheses"] == b.meta["hypotheses"] and a.meta["coarse_dims"] == b.meta["coarse_dims"]
+        assert (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1]) == (pb.x, pb.y, pb.euler[-1])
+    assert [s.num for s in dev.running_scans] == [s.num for s in ref.running_scans]
+    ra, rb = ref.process_scan(ref_scans[n]), dev.process_scan(dev_scans[n])
+    assert abs(ra.response - rb.response) <= 1e-9
+
+
 def test_pre_projection_of_the_query_at_its_result_pose_changes_nothing_but_the_cache_hits():
     """Synchronous matches project their query at the pose they found into its own point-cache slot (prefill_kernel) so
     that the next match, which uses it as a base scan, finds it: same results with the feature off (debug option 22),

@@ -746,6 +746,54 @@ def test_point_cache_is_invisible():
         assert np.array_equal(m.debug_grid()[0], ref.debug_grid()[0])
 
 
+def test_chain_structure_from_scan_creation_equals_the_per_pose_computation():
+    """The trigger chain of the valid-point filter is computed once per scan in the sensor frame (structure_kernel, with a
+    guard band around the distance threshold) and used at every pose; debug option 24 = 0 recomputes it from the projected
+    points at every pose, as Karto does.  Same cells, grids and results -- near the origin, rotated, 9 km out, single
+    matches and batches, both semantics, and for a scan with a reading pair placed ON the threshold (whose structure is
+    not trusted)."""
+    import math
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    from tests.util import load_case
+    q, base = cfg2_scans()
+    # a pair of neighbouring readings exactly 0.1 m apart (law of cosines), inside a run of close readings
+    r = np.array(base[3].ranges, dtype=np.float64)
+    inc = base[3].angle_increment
+    k = 500
+    r[k - 3:k + 4] = 1.0
+    r[k + 1] = math.cos(inc) + math.sqrt(0.01 - math.sin(inc) ** 2)
+    base[3] = PlainScan(r, base[3].min_angle, inc, base[3].min_range, base[3].range_threshold,
+                        (base[3].corrected_pose.x, base[3].corrected_pose.y, base[3].corrected_pose.euler[-1]))
+
+    def same(a, b):
+        return (a.response == b.response and a.covariance == b.covariance and a.meta == b.meta and
+                (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1]))
+
+    for sem in ("karto", "yagpy"):
+        cfg = None if sem == "karto" else load_case("small_dirty_rot")["cfg"]
+        m, ref = ScanMatcher(cfg, semantics=sem), ScanMatcher(cfg, semantics=sem)
+        ref.debug_option(24, 0)
+        for shift in ((0.0, 0.0, 0.0), (0.4, -0.3, 2.5), (9000.0, -8500.0, -1.1)):
+            def moved(s):
+                c = s.corrected_pose
+                p = Transform(shift[0], shift[1], 0.0, shift[2]) + Transform(c.x, c.y, 0.0, c.euler[-1])
+                return _mk_native(PlainScan(s.ranges, s.min_angle, s.angle_increment, s.min_range, s.range_threshold,
+                                            (p.x, p.y, p.euler[-1])))
+            nq, nb = moved(q), [moved(b) for b in base]
+            a, b = m.match_scan(nq, nb, True, True), ref.match_scan(nq, nb, True, True)
+            assert same(a, b), (sem, shift)
+            assert np.array_equal(m.debug_cells(0)[0], ref.debug_cells(0)[0])
+            assert np.array_equal(m.debug_grid(0)[0], ref.debug_grid(0)[0])
+            chains = [nb, nb[:4], nb[3:], nb[::-1]] * 3
+            pa, pb = m.match_scan_batch(nq, chains, True, True)[0], ref.match_scan_batch(nq, chains, True, True)[0]
+            assert all(same(x, y) for x, y in zip(pa, pb)), (sem, shift)
+            for item in (0, 1, 6, 11):
+                assert np.array_equal(m.debug_cells(item)[0], ref.debug_cells(item)[0])
+        m.close()
+        ref.close()
+
+
 def test_a_failed_call_leaves_no_unwritten_cache_entries():
     """Round-2 advisor finding: the point cache is updated on the host before the kernels that fill its entries are enqueued.
     A call that fails in between (here: an order-dependent smear on a chain of more readings than the select kernels

@@ -178,7 +178,7 @@ def lib():
     L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]
     L.ym_cache_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ym_coarse_dims.argtypes = [vp, ip]
-    L.ym_map_sequence.argtypes = [vp, C.POINTER(vp), dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YmResult), ip]
+    L.ym_map_sequence.argtypes = [vp, C.POINTER(vp), dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YmResult), ip]
     L.ym_match_slice_begin.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.ym_match_slice_finish.argtypes = [vp, C.POINTER(YmResult)]
     L.ym_occupancy_create.restype = vp

@@ -130,6 +130,8 @@ struct CallScan {
     int qcache_hint = -1;           // the same three for the scan as the QUERY of a batch
     unsigned char *qcache = nullptr;
     int qstale = 0;
+    const int32_t *gov = nullptr;     // the scan's pose-independent chain structure, when it may be used at this pose
+    const double *pose_dev = nullptr; // device-chained sequence: where the device finds the pose the host only predicts
 };
 
 struct CallItem {
@@ -153,6 +155,12 @@ struct Call {
     // at the RESULT pose into its own slot of the point cache (prefill_kernel), in the shadow of the caller's turnaround:
     // the next match that uses it as a base scan at that pose (GraphSlam.process_scan does) finds the slot filled
     bool prefill = false;
+    // a step of a device-chained sequence (ym_map_sequence): the poses of the scans whose matches are still in flight come
+    // from the device (CallScan::pose_dev; the host's are dead-reckoned predictions that only size the raster), the
+    // result state lands in chain_out, and final_kernel leaves this step's pose and the next step's prior on the device
+    int chain_step = 0;               // 0: an ordinary call
+    double chain_next_diff[3] = {0, 0, 0};
+    YmItemState *chain_out = nullptr; // DEVICE view of the pinned state this step's result goes to
 };
 
 // Everything one call's launches share: sizes, lattices, the device window, how the coarse correlate is cut up,
@@ -197,6 +205,8 @@ struct CallPlan {
     const YmItem *d_items = nullptr;
     // raster coverage
     int launch[4] = {0, 0, -1, -1}, ltx = 0, lty = 0, tile_cap = 1;
+    int chain_step = 0;
+    int cell_box[4] = {INT32_MIN, INT32_MIN, INT32_MAX, INT32_MAX}; // chained steps: window cells whose smear stays inside the launched tiles
     bool use_tile_list = false;
     bool use_tile_hits = false;
     int hit_cap = 0;
@@ -245,6 +255,8 @@ struct ym_scan {
     uint64_t id; // unique per created scan: the key of the matchers' point caches
     int device;
     double *d_ranges;
+    int32_t *d_gov[2] = {nullptr, nullptr}; // trigger-chain structure per semantics (structure_kernel), inside d_ranges' allocation;
+    bool gov_ok[2] = {false, false};        // ... and whether it holds at every pose (no distance test near the threshold)
     int n;
     double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
     double pose[3];
@@ -310,6 +322,7 @@ struct ym_matcher {
     DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
     DevBuf<int32_t> rg_starts;
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
     bool prefill = true;     // synchronous single matches project their query at the result pose afterwards (Call::prefill)
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
@@ -329,6 +342,9 @@ struct ym_matcher {
     DevBuf<double> probs;
     DevBuf<double> yaxes;      // yagpy: xvals, yvals, tvals per item
     DevBuf<double2> yrot;      // yagpy: points rotated per angle
+    DevBuf<double> seq_pose;   // device-chained sequences: [0..2] the last step's pose, [3..5] the next step's odometry prior
+    DevBuf<int32_t> seq_fault; // ... and the first step the host has to repeat (0: none)
+    PinnedBuf seq_results;     // ... and the result state of every step of a segment
     DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
     bool stamps_on = false;
     int corr_u = 0;      // development: force the number of beams in flight per lane (16, 32, 48)
@@ -584,6 +600,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if (max_n > YM_MAX_BEAMS) return set_err(YM_ERR_UNSUPPORTED, "scan has %d readings; limit is %d", max_n, YM_MAX_BEAMS);
 
     const bool yag = P.yag = g.semantics == YM_SEM_YAGPY;
+    P.chain_step = call.chain_step;
     const double coarse_off = yag ? 0.5 * m->cfg.search_size : 0.5 * (g.side - 1) * g.res;
     const double coarse_step = 2 * g.res;
     YmLattice &lc = P.lc, &lf = P.lf;
@@ -1047,6 +1064,8 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
         hs[i].min_range = s.min_range;
         hs[i].range_threshold = s.range_threshold;
         hs[i].pose[0] = s.pose[0]; hs[i].pose[1] = s.pose[1]; hs[i].pose[2] = s.pose[2];
+        hs[i].pose_dev = s.pose_dev;
+        hs[i].gov = (m->use_scan_structure && std::fabs(s.pose[0]) < YM_CHAIN_POSE_LIMIT && std::fabs(s.pose[1]) < YM_CHAIN_POSE_LIMIT) ? s.gov : nullptr;
     }
     for (int i = 0; i < P.B; i++) {
         hi[i].query = call.items[i].query;
@@ -1125,6 +1144,7 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
         want[0] = std::min(want[0], (int)std::floor(cx0 / YM_TILE_W) - 1); want[2] = std::max(want[2], (int)std::floor(cx1 / YM_TILE_W) + 1);
         want[1] = std::min(want[1], (int)std::floor(cy0 / YM_TILE_H) - 1); want[3] = std::max(want[3], (int)std::floor(cy1 / YM_TILE_H) + 1);
     }
+    if (call.chain_step) { want[0] -= 1; want[1] -= 2; want[2] += 1; want[3] += 2; } // (predicted poses: 64 cells more each way)
     want[0] = std::max(want[0], 0); want[1] = std::max(want[1], 0);
     want[2] = std::min(want[2], tiles_x - 1); want[3] = std::min(want[3], tiles_y - 1);
     if (want[2] < want[0] || want[3] < want[1]) { want[0] = tiles_x; want[1] = tiles_y; want[2] = want[3] = -1; } // nothing can be stamped
@@ -1141,6 +1161,16 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     if (m->full_raster) { launch[0] = launch[1] = 0; launch[2] = tiles_x - 1; launch[3] = tiles_y - 1; }
     P.ltx = std::max(0, launch[2] - launch[0] + 1);
     P.lty = std::max(0, launch[3] - launch[1] + 1);
+    if (call.chain_step) {
+        // what prepare_kernel checks every kept cell against: a cell whose smear would reach a tile this call does not launch
+        // (the window's own edge is no limit) is a fault of the step
+        const int h = g.half_kernel;
+        P.cell_box[0] = launch[0] <= 0 ? INT32_MIN : launch[0] * YM_TILE_W + h;
+        P.cell_box[1] = launch[1] <= 0 ? INT32_MIN : launch[1] * YM_TILE_H + h;
+        P.cell_box[2] = launch[2] >= tiles_x - 1 ? INT32_MAX : (launch[2] + 1) * YM_TILE_W - 1 - h;
+        P.cell_box[3] = launch[3] >= tiles_y - 1 ? INT32_MAX : (launch[3] + 1) * YM_TILE_H - 1 - h;
+        if (P.ltx <= 0 || P.lty <= 0) { P.cell_box[0] = P.cell_box[1] = INT32_MAX; P.cell_box[2] = P.cell_box[3] = INT32_MIN; } // nothing launched
+    }
     P.tile_cap = std::max(1, P.ltx * P.lty);
     // a work list pays for its extra launch from a handful of items on (raster 210 -> 159 us on 256 items)
     P.use_tile_list = B >= 8 && P.ltx * P.lty > 0 && tiles_x * tiles_y < 32768;
@@ -1179,6 +1209,9 @@ void enqueue_prepare(ym_matcher *m, const CallPlan &P) {
         for (int i = 0; i < P.nscans; i++) a.inl.scans[i] = P.hs[i];
     }
     a.qnp = m->qnp.p; a.jobs = P.d_jobs; a.job_slot = P.d_job_slot;
+    a.fault = nullptr; a.step = 0; a.pad1 = 0;
+    for (int k = 0; k < 4; k++) a.cell_box[k] = P.cell_box[k];
+    if (P.chain_step) { a.fault = m->seq_fault.p; a.step = P.chain_step; }
     const size_t lds = YM_PREP_LDS_BYTES(P.max_n);
     if (P.split_prepare) {
         if (P.n_jobs > 0) hipLaunchKernelGGL(ym::points_kernel, dim3(P.n_jobs), dim3(YM_POINTS_THREADS), lds, m->stream, a);
@@ -1441,6 +1474,13 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
     a.fsums_stride = P.sums_f; a.stamps = P.stamps;
     a.host_flag = nullptr; a.serial = 0; a.pad1 = 0;
+    a.seq_pose = nullptr; a.fault = nullptr; a.next_diff[0] = a.next_diff[1] = a.next_diff[2] = 0.0; a.step = 0; a.expansion = 0;
+    if (call.chain_step) {
+        a.host_out = call.chain_out;
+        a.seq_pose = m->seq_pose.p; a.fault = m->seq_fault.p; a.step = call.chain_step;
+        for (int k = 0; k < 3; k++) a.next_diff[k] = call.chain_next_diff[k];
+        a.expansion = (m->cfg.semantics == YM_SEM_KARTO && m->cfg.use_response_expansion) ? 1 : 0;
+    }
     slot.poll_serial = 0;
     if ((P.B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
         const size_t lds = YM_FINISH_LDS_BYTES(call.refine ? (size_t)lf.nx * lf.ny * lf.nt : 0);
@@ -1449,7 +1489,7 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
         else hipLaunchKernelGGL(ym::finish_kernel<1024>, dim3(P.B), dim3(1024), lds, st, a);
     } else {
         hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
-        if (P.B == 1 && m->poll_completion) { // the caller polls a word final_kernel writes after the result (no stream event to wait for)
+        if (P.B == 1 && m->poll_completion && !call.chain_step) { // the caller polls a word final_kernel writes after the result (no stream event to wait for)
             if (++slot.serial_counter == 0) slot.serial_counter = 1;
             slot.poll_serial = a.serial = slot.serial_counter;
             a.host_flag = reinterpret_cast<uint32_t *>(slot.result.dp + align_up(sizeof(YmItemState) * P.B, 64));
@@ -1698,6 +1738,8 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->id = s->id;
     o->beam_spacing = s->beam_spacing;
     o->cache_hint = o->qcache_hint = -1;
+    const int sem = semantics == YM_SEM_YAGPY ? 1 : 0;
+    o->gov = s->gov_ok[sem] ? s->d_gov[sem] : nullptr;
     return YM_OK;
 }
 
@@ -1823,6 +1865,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
         ym_destroy(m);
         return nullptr;
     }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prefill_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
     if (m->stamps.ensure(32) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipMemset(m->stamps.p, 0, 32 * sizeof(unsigned long long));
     return m;
@@ -1891,8 +1935,10 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     world_bbox(s->lbox, s->pose, s->wbox);
     s->beam_spacing = median_beam_spacing(d->ranges, d->n, d->min_range, d->range_threshold, d->angle_increment);
     DevGuard guard(device);
-    if (!guard.ok ||
-        hipMalloc(reinterpret_cast<void **>(&s->d_ranges), sizeof(double) * std::max(1, d->n)) != hipSuccess) {
+    // one allocation: ranges[n], the chain structure per semantics [2][n][2] ints, its info words [4]
+    const size_t n1 = (size_t)std::max(1, d->n);
+    const size_t ranges_bytes = align_up(sizeof(double) * n1, 16), gov_bytes = align_up(sizeof(int32_t) * 2 * n1, 16);
+    if (!guard.ok || hipMalloc(reinterpret_cast<void **>(&s->d_ranges), ranges_bytes + 2 * gov_bytes + 16) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot allocate device ranges");
         delete s;
         return nullptr;
@@ -1902,6 +1948,27 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
         (void)hipFree(s->d_ranges);
         delete s;
         return nullptr;
+    }
+    if (d->n > 0 && d->n <= YM_MAX_BEAMS) {
+        unsigned char *base = reinterpret_cast<unsigned char *>(s->d_ranges);
+        s->d_gov[0] = reinterpret_cast<int32_t *>(base + ranges_bytes);
+        s->d_gov[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + gov_bytes);
+        int32_t *d_info = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes);
+        static std::atomic<int> lds_raised{0};
+        if (!lds_raised.exchange(1))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
+        ym::StructureArgs sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sr.ranges = s->d_ranges; sa.sr.n = s->n; sa.sr.min_angle = s->min_angle; sa.sr.angle_inc = s->angle_inc;
+        sa.sr.min_range = s->min_range; sa.sr.range_threshold = s->range_threshold;
+        sa.gov[0] = s->d_gov[0]; sa.gov[1] = s->d_gov[1]; sa.info = d_info;
+        hipLaunchKernelGGL(ym::structure_kernel<512>, dim3(2), dim3(512), YM_PREP_LDS_BYTES(s->n), 0, sa);
+        int32_t info[4] = {0, 1, 0, 1};
+        if (hipGetLastError() == hipSuccess && hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost) == hipSuccess) {
+            s->gov_ok[0] = info[1] == 0;
+            s->gov_ok[1] = info[3] == 0;
+        } // (a failure only means the matchers compute the chain per pose)
     }
     return s;
 }
@@ -2009,8 +2076,110 @@ static void tf_inverse(const double a[3], double out[3]) {
     out[0] = x; out[1] = y; out[2] = -a[2];
 }
 
+// One synchronous step of ym_map_sequence: prior from the previous scan's pose, match, pose := result.
+static int sequence_step_sync(ym_matcher *m, ym_scan *const *scans, const double *odom, int i, int buffer_len, int penalize,
+                              int refine, ym_result *result) {
+    double inv[3], diff[3], prior[3];
+    tf_inverse(odom + 3 * (size_t)(i - 1), inv);              // query.odom_pose - last.odom_pose
+    tf_compose(inv, odom + 3 * (size_t)i, diff);
+    tf_compose(scans[i - 1]->pose, diff, prior);                // last.corrected_pose + that
+    int rc = ym_scan_set_pose(scans[i], prior[0], prior[1], prior[2]);
+    if (rc) return rc;
+    const int first = std::max(0, i - buffer_len);
+    Slot &slot = m->slots[kAsyncSlots];
+    if (slot.in_flight && slot.call.slice)
+        return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
+    slot.call = Call();
+    if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call))) return rc;
+    slot.call.prefill = true;
+    if ((rc = launch_call(m, slot))) return rc;
+    if ((rc = finish_call(m, slot, result))) return rc;
+    if (result->status != 0) return YM_OK;
+    return ym_scan_set_pose(scans[i], result->pose[0], result->pose[1], result->pose[2]);
+}
+
+// Steps [lo, hi) of ym_map_sequence enqueued back to back, no host round trip between them: step i's final_kernel leaves
+// scan i's pose and scan i + 1's odometry prior on the device (seq_pose), the kernels of step i + 1 read them from there
+// (YmScanRef::pose_dev), and the host -- which plans step i + 1 before step i has run -- sizes the raster from poses it
+// dead-reckons with the odometry alone.  A step whose cells leave that prediction, that Karto would abort, or that needs
+// a response expansion makes the device skip the rest (seq_fault); the caller repeats it synchronously.
+// Returns the number of steps completed in *done (results and poses of [lo, lo + *done) are final).
+static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const double *odom, int lo, int hi, int buffer_len,
+                                    int penalize, int refine, ym_result *results, int *done) {
+    *done = 0;
+    DEV_GUARD(m->device);
+    int rc;
+    const int n_seg = hi - lo;
+    if ((rc = m->seq_pose.ensure(6))) return rc;
+    if ((rc = m->seq_fault.ensure(1))) return rc;
+    if ((rc = m->seq_results.ensure(sizeof(YmItemState) * (size_t)n_seg))) return rc;
+    HIP_TRY(hipMemsetAsync(m->seq_fault.p, 0, sizeof(int32_t), m->stream));
+    Slot &slot = m->slots[kAsyncSlots];
+    if (slot.in_flight) return set_err(YM_ERR_BUSY, "the matcher's synchronous slot holds a call in flight");
+    std::vector<std::array<double, 3>> predicted((size_t)n_seg);
+    int enqueued = 0;
+    for (int i = lo; i < hi; i++, enqueued++) {
+        double inv[3], diff[3], prior[3], next_diff[3] = {0, 0, 0};
+        tf_inverse(odom + 3 * (size_t)(i - 1), inv);
+        tf_compose(inv, odom + 3 * (size_t)i, diff);
+        tf_compose(scans[i - 1]->pose, diff, prior); // (scan i - 1: its true pose for i == lo, else what the odometry predicts)
+        if ((rc = ym_scan_set_pose(scans[i], prior[0], prior[1], prior[2]))) break;
+        predicted[(size_t)(i - lo)] = {prior[0], prior[1], prior[2]};
+        if (i + 1 < hi) {
+            tf_inverse(odom + 3 * (size_t)i, inv);
+            tf_compose(inv, odom + 3 * (size_t)(i + 1), next_diff);
+        }
+        const int first = std::max(0, i - buffer_len);
+        slot.call = Call();
+        if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call))) break;
+        Call &call = slot.call;
+        call.chain_step = i; // (>= 1)
+        for (int k = 0; k < 3; k++) call.chain_next_diff[k] = next_diff[k];
+        call.chain_out = reinterpret_cast<YmItemState *>(m->seq_results.dp) + (i - lo);
+        if (i > lo) {
+            call.scans[0].pose_dev = m->seq_pose.p + 3;             // the query's prior
+            call.scans[(size_t)(i - first)].pose_dev = m->seq_pose.p; // base scan i - 1 (the last of the chain): its result
+        }
+        if ((rc = launch_call(m, slot))) break;
+        slot.in_flight = false; // (collected below, from seq_results)
+        if (slot.prefill_cache || m->cache_off || !slot.call.scans[(size_t)(i - first)].cache) {
+            // (cannot happen: chained steps never prefill, and the caller made room in the point cache) -- be safe:
+            enqueued++;
+            rc = set_err(YM_ERR_UNSUPPORTED, "device-chained sequence without a point-cache slot");
+            break;
+        }
+    }
+    int32_t fault = 0;
+    hipError_t herr = hipMemcpyAsync(&fault, m->seq_fault.p, sizeof fault, hipMemcpyDeviceToHost, m->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(m->stream);
+    if (herr != hipSuccess) return set_err(YM_ERR_HIP, "%s", hipGetErrorString(herr));
+    const int good = std::min(enqueued, fault > 0 ? fault - lo : enqueued);
+    const YmItemState *hs = reinterpret_cast<const YmItemState *>(m->seq_results.p);
+    for (int k = 0; k < good; k++) {
+        const int i = lo + k;
+        state_to_result(m, slot, hs[k], 0, 0, &results[i]);
+        // the point-cache slot scan i got as a base scan was filled at this pose; the host knew it as the prediction
+        auto it = m->cache_index.find(scans[i]->id * 2);
+        if (it != m->cache_index.end()) {
+            ym_matcher::CacheEntry &ce = m->cache_entries[it->second];
+            if (ce.pose[0] == predicted[(size_t)k][0] && ce.pose[1] == predicted[(size_t)k][1] && ce.pose[2] == predicted[(size_t)k][2])
+                for (int q = 0; q < 3; q++) ce.pose[q] = results[i].pose[q];
+        }
+        (void)ym_scan_set_pose(scans[i], results[i].pose[0], results[i].pose[1], results[i].pose[2]);
+    }
+    for (int k = good; k < enqueued; k++) { // skipped steps: whatever their slots hold was not computed
+        auto it = m->cache_index.find(scans[lo + k]->id * 2);
+        if (it != m->cache_index.end()) {
+            ym_matcher::CacheEntry &ce = m->cache_entries[it->second];
+            ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
+        }
+    }
+    *done = good;
+    return rc;
+}
+
 int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, int n, int start, int buffer_len,
-                    int penalize, int refine, ym_result *results, int32_t *n_done) {
+                    int penalize, int refine, int device_chain, ym_result *results, int32_t *n_done) {
     if (!m || !scans || !odom || !results || !n_done) return set_err(YM_ERR_INVALID, "null argument");
     if (n < 0 || start < 0 || buffer_len < 1) return set_err(YM_ERR_INVALID, "bad trajectory length, start or chain length");
     *n_done = 0;
@@ -2019,40 +2188,56 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
     const int begin = std::min(n, std::max(start, 1));
     for (int i = 0; i < begin; i++) std::memset(&results[i], 0, sizeof results[i]);
     *n_done = begin;
-    static const bool debug_host = getenv("YM_DEBUG_HOST") != nullptr; // development aid: where a step's host time goes
-    timespec t0, t1, t2;
-    double us_launch = 0, us_wait = 0, us_build = 0;
-    int n_timed = 0;
-    for (int i = begin; i < n; i++) {
-        double inv[3], diff[3], prior[3];
-        tf_inverse(odom + 3 * (size_t)(i - 1), inv);              // query.odom_pose - last.odom_pose
-        tf_compose(inv, odom + 3 * (size_t)i, diff);
-        tf_compose(scans[i - 1]->pose, diff, prior);                // last.corrected_pose + that
-        int rc = ym_scan_set_pose(scans[i], prior[0], prior[1], prior[2]);
-        if (rc) return rc;
-        const int first = std::max(0, i - buffer_len);
-        if (debug_host) clock_gettime(CLOCK_MONOTONIC, &t0);
-        Slot &slot = m->slots[kAsyncSlots];
-        if (slot.in_flight && slot.call.slice)
-            return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
-        if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call))) return rc;
-        slot.call.prefill = true;
-        if (debug_host) { clock_gettime(CLOCK_MONOTONIC, &t1); us_build += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3; }
-        if ((rc = launch_call(m, slot))) return rc;
-        if (debug_host) clock_gettime(CLOCK_MONOTONIC, &t1);
-        if ((rc = finish_call(m, slot, &results[i]))) return rc;
-        if (debug_host) {
-            clock_gettime(CLOCK_MONOTONIC, &t2);
-            us_launch += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
-            us_wait += (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3;
-            n_timed++;
+    static const bool debug_host = getenv("YM_DEBUG_HOST") != nullptr;
+    // chained segments need Karto semantics (one pass structure), every scan resident with a slot in the point cache, an
+    // inline descriptor (chain + query <= YM_INLINE_SCANS) and the two-kernel finish
+    const bool can_chain = device_chain && m->cfg.semantics == YM_SEM_KARTO && !m->cache_off && buffer_len + 1 <= YM_INLINE_SCANS &&
+                           m->finish_form != 2;
+    const int kSegment = 128;
+    int i = begin, n_sync = 0, n_segments = 0;
+    while (i < n) {
+        int rc;
+        bool chained = false;
+        if (can_chain && n - i >= 2) {
+            // room in the point cache for the slots this segment creates (a growing arena drops every entry: not while the
+            // host does not know the poses they were filled at)
+            const int hi = std::min(n, i + kSegment);
+            size_t need = 0;
+            for (int j = std::max(0, i - buffer_len); j < hi; j++)
+                if (m->cache_index.find(scans[j]->id * 2) == m->cache_index.end()) need += align_up(YM_CACHE_BYTES(scans[j]->n), 16);
+            if (m->cache_used + need > m->cache_arena.cap) {
+                // grow now, between segments, when the host knows every pose: all entries go and are recomputed
+                size_t all = 0;
+                for (int j = std::max(0, i - buffer_len); j < hi; j++) all += align_up(YM_CACHE_BYTES(scans[j]->n), 16);
+                const size_t want = std::min(m->cache_limit, std::max(2 * m->cache_arena.cap, 2 * all));
+                if (want >= all) {
+                    DEV_GUARD(m->device);
+                    HIP_TRY(hipStreamSynchronize(m->stream));
+                    m->cache_entries.clear();
+                    m->cache_index.clear();
+                    m->cache_used = 0;
+                    if (want > m->cache_arena.cap && (rc = m->cache_arena.ensure(want))) return rc;
+                    need = all;
+                }
+            }
+            if (scans[i]->id != 0 && m->cache_used + need <= m->cache_arena.cap) {
+                int done = 0;
+                rc = sequence_segment_chained(m, scans, odom, i, hi, buffer_len, penalize, refine, results, &done);
+                if (rc) { *n_done = i + done; return rc; }
+                i += done;
+                *n_done = i;
+                n_segments++;
+                chained = done == hi - (i - done);
+                if (chained) continue; // (else: scan i faulted -- repeat it the ordinary way)
+            }
         }
+        if (i >= n) break;
+        if ((rc = sequence_step_sync(m, scans, odom, i, buffer_len, penalize, refine, &results[i]))) return rc;
+        n_sync++;
         if (results[i].status != 0) return YM_OK;
-        if ((rc = ym_scan_set_pose(scans[i], results[i].pose[0], results[i].pose[1], results[i].pose[2]))) return rc;
-        *n_done = i + 1;
+        *n_done = ++i;
     }
-    if (debug_host && n_timed)
-        fprintf(stderr, "[ym] map_sequence: %d steps, build call %.1f us, build + plan + enqueue %.1f us, wait + result %.1f us per step\n", n_timed, us_build / n_timed, us_launch / n_timed, us_wait / n_timed);
+    if (debug_host) fprintf(stderr, "[ym] map_sequence: %d scans, %d chained segments, %d synchronous steps\n", n - begin, n_segments, n_sync);
     return YM_OK;
 }
 
@@ -2602,6 +2787,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 15) m->corr_region_na = m->corr_region_nw = value;
     else if (option == 22) m->prefill = value != 0;
     else if (option == 23) m->poll_completion = value != 0;
+    else if (option == 24) m->use_scan_structure = value != 0;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;

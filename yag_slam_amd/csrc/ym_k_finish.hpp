@@ -168,6 +168,13 @@ struct FinishArgs {
     unsigned long long *stamps;
     uint32_t *host_flag;      // single matches: pinned host word that receives `serial` once host_out[0] is complete (the
     uint32_t serial, pad1;    // caller polls it instead of waiting for a stream event), or null
+    // device-chained sequences (ym_map_sequence): the step's pose goes to seq_pose[0..2] and the next step's odometry prior
+    // = that pose (+) next_diff (tiny_tf's Transform composition) to seq_pose[3..5]; a step that Karto would abort or
+    // repeat with a wider angle range (response expansion) is a fault the host handles
+    double *seq_pose;         // null: not a chained step
+    int32_t *fault;
+    double next_diff[3];
+    int32_t step, expansion;  // expansion: the matcher's use_response_expansion
 };
 
 // sum N doubles across the block in one round (2 barriers); result in every thread
@@ -439,6 +446,15 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     YM_STAMP(a, 15);
 }
 
+// a chained step's pose and the next step's odometry prior (ym_map_sequence; yag_slam_amd/transform.py: a + b)
+__device__ __forceinline__ void chain_next_pose(const FinishArgs &a, const double pose[3]) {
+    const double c = cos(pose[2]), s = sin(pose[2]);
+    a.seq_pose[0] = pose[0]; a.seq_pose[1] = pose[1]; a.seq_pose[2] = pose[2];
+    a.seq_pose[3] = pose[0] + c * a.next_diff[0] - s * a.next_diff[1];
+    a.seq_pose[4] = pose[1] + s * a.next_diff[0] + c * a.next_diff[1];
+    a.seq_pose[5] = pose[2] + a.next_diff[2];
+}
+
 // ---- K6b final: grid (B), 256 threads: fine arg-max / mean, angular covariance, result.
 __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) {
     constexpr int NT = YM_FINISH_THREADS;
@@ -461,6 +477,7 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
             st.coarse_response = 1.0; // nothing to retry with a wider angle
             if (a.host_out) a.host_out[b] = st;
             if (a.host_flag) { __threadfence_system(); *reinterpret_cast<volatile uint32_t *>(a.host_flag) = a.serial; }
+            if (a.seq_pose) chain_next_pose(a, st.pose);
         }
         return;
     }
@@ -574,6 +591,10 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         st.status = status;
         if (a.host_out) a.host_out[b] = st;
         if (a.host_flag) { __threadfence_system(); *reinterpret_cast<volatile uint32_t *>(a.host_flag) = a.serial; }
+        if (a.seq_pose) {
+            if (status != 0 || (a.expansion && kt_double_equal(coarse_response, 0.0))) atomicCAS(a.fault, 0, a.step);
+            chain_next_pose(a, mean);
+        }
     }
     YM_STAMP(a, 19);
 }

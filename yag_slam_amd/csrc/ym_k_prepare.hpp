@@ -33,6 +33,12 @@ struct PrepareArgs {
     const int32_t *jobs;     // [n_jobs] scan index | (query ? 0x80000000 : 0)
     const int32_t *job_slot; // [n_jobs] query slot of a query job
     unsigned long long *stamps;
+    // device-chained sequences (ym_map_sequence): the host sized the raster's tile rectangle from PREDICTED poses; a kept
+    // cell outside cell_box (window cells whose smear stays inside the launched tiles) or an earlier step's fault makes
+    // *fault = step (first one wins) and the host repeats from there with the poses it then knows
+    int32_t *fault;          // null: not a chained step
+    int32_t step, pad1;
+    int32_t cell_box[4];     // x0, y0, x1, y1 (inclusive)
 };
 
 // LDS carve-up shared by the kernels that project a scan
@@ -104,21 +110,32 @@ __device__ __forceinline__ int project_points(const YmScanRef &sr, double px, do
 // its nodes.  Marked without one long serial walk: cut the points into segments of 64; (1) every point walks to the
 // first node past its own segment, (2) one thread hops from segment to segment with those exits (<= n/64 hops),
 // (3) one thread per entered segment marks the chain nodes inside it.
-template <int NT>
-__device__ __forceinline__ void mark_chain(const PrepLds &l, int np, bool yag, unsigned long long *stamps = nullptr) {
+// GUARD: also report (block-wide) whether any distance test came within YM_CHAIN_GUARD of the threshold.  The chain is a
+// function of those tests' outcomes alone; squared distances between the same two readings computed at two different
+// poses differ by rounding only (< 1e-12 m^2 for poses within 10 km: coordinates below 2^14 m carry errors below 4e-12 m,
+// distances are at most 0.2 m), so a scan without a near test has the SAME chain at every such pose.
+#define YM_CHAIN_GUARD 1e-9
+#define YM_CHAIN_POSE_LIMIT 1.0e4
+template <int NT, bool GUARD = false>
+__device__ __forceinline__ int mark_chain(const PrepLds &l, int np, bool yag, unsigned long long *stamps = nullptr) {
     const int tid = threadIdx.x;
     const double min_sq = yag ? 0.2 * 0.2 : 0.1 * 0.1;
+    int near = 0;
     for (int i = tid; i < np; i += NT) {
         const double fx = l.sx[i], fy = l.sy[i];
         int j = i + 1;
         for (; j < np; j++) {
             const double dx = fx - l.sx[j], dy = fy - l.sy[j];
-            if (dx * dx + dy * dy > min_sq) break;
+            const double d2 = dx * dx + dy * dy;
+            if (GUARD) near |= fabs(d2 - min_sq) <= YM_CHAIN_GUARD ? 1 : 0;
+            if (d2 > min_sq) break;
         }
         l.nxt[i] = j;
         l.chain[i] = 0;
     }
-    __syncthreads();
+    int unsafe = 0;
+    if (GUARD) unsafe = __syncthreads_or(near);
+    else __syncthreads();
     if (stamps && threadIdx.x == 0 && blockIdx.x == 0) stamps[24] = wall_clock64();
     constexpr int SEG = 64;
     const int nseg = (np + SEG - 1) / SEG;
@@ -143,6 +160,7 @@ __device__ __forceinline__ void mark_chain(const PrepLds &l, int np, bool yag, u
         }
     }
     __syncthreads();
+    return unsafe;
 }
 
 // per point: the chain node that decides it (karto: the last node at or before i; yagpy: before i, none for point 0)
@@ -159,9 +177,10 @@ template <int NT>
 __device__ __forceinline__ void store_cache(const YmScanRef &sr, const PrepLds &l, int np, bool yag) {
     double2 *cpts = reinterpret_cast<double2 *>(sr.cache + YM_CACHE_HEADER);
     int2 *cgov = reinterpret_cast<int2 *>(sr.cache + YM_CACHE_HEADER + (size_t)sr.n * 16);
+    const int2 *known = reinterpret_cast<const int2 *>(sr.gov);
     for (int i = threadIdx.x; i < np; i += NT) {
         cpts[i] = make_double2(l.sx[i], l.sy[i]);
-        cgov[i] = gov_walk(l, i, np, yag);
+        cgov[i] = known ? known[i] : gov_walk(l, i, np, yag);
     }
     if (threadIdx.x == 0) *reinterpret_cast<int *>(sr.cache) = np;
 }
@@ -225,6 +244,11 @@ __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmI
     }
 }
 
+__device__ __forceinline__ void chain_check_cell(const PrepareArgs &a, int2 c) {
+    if (a.fault && c.x != YM_CELL_NONE && (c.x < a.cell_box[0] || c.y < a.cell_box[1] || c.x > a.cell_box[2] || c.y > a.cell_box[3]))
+        atomicCAS(a.fault, 0, a.step);
+}
+
 // The query-dependent half of FindValidPoints + AddScan's cell lookup for one base scan of one item: point i is kept
 // iff its run's trigger pair (s, t) puts t on the far side of the line through the viewpoint and s; kept points
 // become window cells, 64 consecutive cells share a bounding box.  PT(i) / GOV(i) read point i and its (s, t) from
@@ -266,6 +290,7 @@ __device__ __forceinline__ void prepare_cells(const PrepareArgs &a, int b, int s
             }
         }
         if (i < a.max_n) cells[i] = c;
+        chain_check_cell(a, c);
         // bounding box of the chunk's rasterised cells: the raster kernel reads a chunk only when
         // this box touches its tile
         const bool has = c.x != YM_CELL_NONE;
@@ -341,6 +366,7 @@ __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, in
                     c = make_int2(gx + a.g.border - a.g.win_origin, gy + a.g.border - a.g.win_origin);
             }
             if (i < a.max_n) cells[i] = c;
+            chain_check_cell(a, c);
             const bool has = c.x != YM_CELL_NONE;
             const int x0 = half_wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = half_wave_reduce(has ? c.y : INT32_MAX, OpMinI());
             const int x1 = half_wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = half_wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
@@ -367,8 +393,14 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
         return;
     }
     const int si = is_query ? it.query : it.base_begin + slot;
-    const YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
-    const YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
+    YmScanRef sr = a.use_inline ? a.inl.scans[si] : a.scans[si];
+    YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
+    if (sr.pose_dev) { sr.pose[0] = sr.pose_dev[0]; sr.pose[1] = sr.pose_dev[1]; sr.pose[2] = sr.pose_dev[2]; }
+    if (qr.pose_dev) { qr.pose[0] = qr.pose_dev[0]; qr.pose[1] = qr.pose_dev[1]; qr.pose[2] = qr.pose_dev[2]; }
+    if (a.fault && *a.fault) { // a chained step after a fault: nothing to do (the host repeats it); leave an empty problem
+        if (!is_query) { clear_slot<NT>(a, b, slot); return; }
+        sr.n = 0;
+    }
     const bool yag = a.g.semantics == 1;
     if (!is_query && sr.cache && !sr.stale) {
         cells_from_cache<NT>(a, b, slot, sr, qr, yag);
@@ -392,12 +424,40 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
         YM_STAMP(a, 18);
         return;
     }
-    mark_chain<NT>(l, np, yag);
+    const int2 *known = reinterpret_cast<const int2 *>(sr.gov); // the chain structure, when it is known to hold at this pose
+    if (!known) mark_chain<NT>(l, np, yag);
     YM_STAMP_B1(a, 22);
     if (sr.cache) store_cache<NT>(sr, l, np, yag);
-    prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y,
-                      [&](int i) { return make_double2(l.sx[i], l.sy[i]); }, [&](int i) { return gov_walk(l, i, np, yag); });
+    if (known)
+        prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y,
+                          [&](int i) { return make_double2(l.sx[i], l.sy[i]); }, [&](int i) { return known[i]; });
+    else
+        prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y,
+                          [&](int i) { return make_double2(l.sx[i], l.sy[i]); }, [&](int i) { return gov_walk(l, i, np, yag); });
     YM_STAMP_B1(a, 23);
+}
+
+// ---- K0 structure: grid (2), once per scan (ym_scan_create).  Block 0: Karto's rules, block 1: the Python matcher's.
+// The trigger chain of the valid-point filter (which readings start a run, and where each run ends) depends on the
+// readings' mutual distances only; computed here at the identity pose with a guard band around the distance threshold
+// (mark_chain<GUARD>), it is what any pose within YM_CHAIN_POSE_LIMIT gives, bit for bit, unless a test was near the
+// threshold -- then info says so and the matcher recomputes the chain from the projected points at every pose, as before.
+struct StructureArgs {
+    YmScanRef sr;       // ranges + sensor parameters
+    int32_t *gov[2];    // [n][2] per semantics: for compacted point i the chain node that decides it and where its run ends
+    int32_t *info;      // [2][2]: number of point readings, 1 = a distance test was within the guard band
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
+    const bool yag = blockIdx.x == 1;
+    const PrepLds l = prep_lds(lds_raw, a.sr.n);
+    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt);
+    const int unsafe = mark_chain<NT, true>(l, np, yag);
+    int2 *gov = reinterpret_cast<int2 *>(a.gov[blockIdx.x]);
+    for (int i = threadIdx.x; i < np; i += NT) gov[i] = gov_walk(l, i, np, yag);
+    if (threadIdx.x == 0) { a.info[2 * blockIdx.x] = np; a.info[2 * blockIdx.x + 1] = unsafe; }
 }
 
 // ---- K1p prefill: one block, after a single match.  Projects the match's query at the pose the match FOUND (the item's
@@ -420,7 +480,7 @@ __global__ __launch_bounds__(NT) void prefill_kernel(PrefillArgs a) {
     const PrepLds l = prep_lds(lds_raw, a.max_n);
     const int np = project_points<NT>(a.sr, st.mean[0], st.mean[1], st.mean[2], false, l.sx, l.sy, s_cnt);
     YM_STAMP(a, 21);
-    mark_chain<NT>(l, np, false, a.stamps);
+    if (!a.sr.gov) mark_chain<NT>(l, np, false, a.stamps);
     YM_STAMP(a, 22);
     store_cache<NT>(a.sr, l, np, false);
     YM_STAMP(a, 23);
@@ -449,7 +509,7 @@ __global__ __launch_bounds__(YM_POINTS_THREADS) void points_kernel(PrepareArgs a
         if (threadIdx.x == 0) *(sr.qcache ? reinterpret_cast<int *>(sr.qcache) : a.qnp + qs) = np;
         return;
     }
-    mark_chain<NT>(l, np, yag);
+    if (!sr.gov) mark_chain<NT>(l, np, yag);
     store_cache<NT>(sr, l, np, yag);
 }
 

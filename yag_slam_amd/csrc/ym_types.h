@@ -62,6 +62,10 @@ struct YmScanRef {
     unsigned char *qcache; // the same for the scan in the role of a QUERY of a batch: [int32 np][pad][double2 local[n]]
     int32_t qstale;
     int32_t pad;
+    const int32_t *gov;     // DEVICE: the scan's trigger-chain structure [n][2] computed once in the sensor frame (ym_scan_create),
+                            // valid at any pose (see structure_kernel); null: compute it from the projected points
+    const double *pose_dev; // DEVICE pointer to the pose (x, y, heading) when the host does not know it yet -- a scan of a
+                            // device-chained sequence whose match is still in flight (ym_map_sequence) --, else null
 };
 
 // A matcher caches, per resident base scan and pose, what LocalizedRangeScan::Update and the viewpoint-independent half

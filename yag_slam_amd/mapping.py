@@ -36,10 +36,11 @@ class SequentialMapper(object):
         return res
 
 
-    def process_scans(self, scans):
+    def process_scans(self, scans, device_chain=False):
         """`process_scan` for every scan of a trajectory with the loop itself inside the library (`ym_map_sequence`: no
         Python between two matches).  Same poses, results and running chain as calling `process_scan` scan by scan;
-        returns the list of results (None for the very first scan of a map)."""
+        returns the list of results (None for the very first scan of a map).  device_chain: the device also hands each
+        step's pose to the next without a host round trip (ScanMatcher.map_sequence); poses then agree to rounding."""
         scans = list(scans)
         out = []
         if scans and not self.running_scans:
@@ -53,7 +54,7 @@ class SequentialMapper(object):
         seq = self.running_scans + scans
         for k in range(start, len(seq)):
             seq[k].num = seq[k - 1].num + 1
-        res = native(seq, start, self.scan_buffer_len, True, True)
+        res = native(seq, start, self.scan_buffer_len, True, True, device_chain)
         self.running_scans = seq[-self.scan_buffer_len:]
         self.results.extend(res)
         return out + res

@@ -139,12 +139,15 @@ class ScanMatcher(object):
             raise _capi.YmError(res.status, "Mapper FATAL ERROR - unable to find best position / index out of range")
         return _result(res)
 
-    def map_sequence(self, scans, start, buffer_len, penalty=True, do_fine=True):
+    def map_sequence(self, scans, start, buffer_len, penalty=True, do_fine=True, device_chain=False):
         """The matcher calls of `GraphSlam.process_scan` (/root/reference/yag_slam/graph_slam.py:320-337) for
         scans[start:], scans[:start] being the running chain so far: odometry prior from `odom_pose`, match against the
         last `buffer_len` scans, `corrected_pose` = the match's pose -- one library call (`ym_match_scans` in a host
         loop without Python).  Every scan must be resident (our LocalizedRangeScan).  Returns the results of
-        scans[start:]; raises like `match_scan` at the first scan Karto would abort on (the scans before it are done)."""
+        scans[start:]; raises like `match_scan` at the first scan Karto would abort on (the scans before it are done).
+        device_chain: no host round trip between the steps either (the device hands each step's pose to the next;
+        include/yagmatch.h) -- the priors are then composed with the device's cos / sin, so poses agree with the
+        step-by-step form to rounding, not bit for bit."""
         n = len(scans)
         handles = (C.c_void_p * max(1, n))(*[self._require_native(s) for s in scans])
         odom = np.empty((max(1, n), 3), dtype=np.float64)
@@ -154,7 +157,8 @@ class ScanMatcher(object):
         per = (_capi.YmResult * max(1, n))()
         done = C.c_int32(0)
         _capi.check(self._lib.ym_map_sequence(self._m, handles, odom.ctypes.data_as(C.POINTER(C.c_double)), n, int(start),
-                                              int(buffer_len), int(bool(penalty)), int(bool(do_fine)), per, C.byref(done)))
+                                              int(buffer_len), int(bool(penalty)), int(bool(do_fine)), int(bool(device_chain)),
+                                              per, C.byref(done)))
         first = max(int(start), 1)
         res = _results(per)[first:done.value] if done.value > first else []
         for s, r in zip(scans[first:done.value], res):
