@@ -322,6 +322,7 @@ struct ym_matcher {
     DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
     DevBuf<int32_t> rg_starts;
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
     bool prefill = true;     // synchronous single matches project their query at the result pose afterwards (Call::prefill)
@@ -626,6 +627,8 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     // (in steps of 64 cells: the window -- and with it the "this tile is zero" knowledge about its memory -- then stays
     //  the same from match to match while the queries' longest readings differ by less)
     wh = (wh + 63) / 64 * 64;
+    if (m->last_wh >= wh && m->last_wh - wh <= 256) wh = m->last_wh; // (and not smaller again at once: a window up to 256 cells too wide stays)
+    m->last_wh = wh;
     wh = wrap ? centre : std::min(wh, centre);
     g.win_origin = centre - wh;
     g.win_w = std::min(2 * wh + 1 + (yag ? 1 : 0), g.storage_w - g.win_origin); // even yagpy grids have no centre cell
@@ -1560,7 +1563,7 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     // last (an event between two kernels costs the second one ~2 us); otherwise the event is recorded before the prefill.
     if (slot.prefill_cache && slot.poll_serial) enqueue_prefill();
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(slot.done, st));
+    if (!slot.call.chain_step) HIP_TRY(hipEventRecord(slot.done, st)); // (a chained segment is collected with one stream synchronisation)
     slot.in_flight = true;
     slot.n_items = P.B;
     if (slot.prefill_cache && !slot.poll_serial) enqueue_prefill();
