@@ -265,8 +265,9 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * correlate (each takes a share of the angles); 18: room in the raster's per-tile hit lists on batches, in entries per tile
  * (0 = 32; -1 = no lists: every raster block scans the item's chunk boxes, as it does for an item whose lists do not fit);
  * 19: units per LDS buffer of the gather correlate (small values cut regions into chunks); 20: LDS bytes a gather block may
- * use (small values make the regions small); 22: 0 = synchronous matches do not pre-project their query at the result pose;
- * 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
+ * use (small values make the regions small); 23: 0 = single matches wait for a stream event instead
+ * of polling the completion word; 24: 0 = the trigger chains of base scans are recomputed at every pose instead of taken
+ * from the scan's creation-time structure; 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
  * (0: it scores them itself unless option 12 asks for the integer sums). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 

@@ -40,7 +40,7 @@ print("chained step:", " ".join("%s %.2f" % (n_, (v - t0) / 100.0) for n_, v in 
 print("agreement with the library loop at scan %d:" % (N - 44), scans[N - 44].corrected_pose, scans2[N - 44].corrected_pose)
 names = ["prep:start","prep:points","prep:trig","","rast:start","rast:scan","rast:rowpass","rast:end",
          "corr:start","corr:end","score:start","score:end","fine:start","fine:coarse","fine:cells","fine:end",
-         "final:start","final:fties","prep:qend","final:end","pf:start","pf:points","pf:chain","pf:stored","pf:nxt","pf:ex","pf:hops"]
+         "final:start","final:fties","prep:qend","final:end"]
 m.debug_stamps(True)
 mp.process_scans(scans[N - 3 - 40:N - 3 - 20])
 st = m.debug_stamps(True)

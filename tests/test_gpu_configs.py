@@ -133,42 +133,6 @@ def test_device_chained_sequence_agrees_with_the_per_scan_loop():
     assert abs(ra.response - rb.response) <= 1e-9
 
 
-def test_pre_projection_of_the_query_at_its_result_pose_changes_nothing_but_the_cache_hits():
-    """Synchronous matches project their query at the pose they found into its own point-cache slot (prefill_kernel) so
-    that the next match, which uses it as a base scan, finds it: same results with the feature off (debug option 22),
-    one cache miss fewer per step with it on; a pose set behind the matcher's back is not served from the slot."""
-    from yag_slam_amd import synth
-    from yag_slam_amd.mapping import SequentialMapper
-    from yag_slam_amd.scan_matching import ScanMatcher
-    from yag_slam_amd.transform import Transform
-    n = 60
-    outs, stats = [], []
-    for on in (1, 0):
-        _, scans = synth.trajectory_scans(n)
-        m = ScanMatcher()
-        m.debug_option(22, on)
-        mp = SequentialMapper(m)
-        res = [mp.process_scan(s) for s in scans[:n // 2]] + mp.process_scans(scans[n // 2:])
-        outs.append([(r.response, r.covariance, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1]) for r in res[1:]])
-        stats.append(m.cache_stats())
-    assert outs[0] == outs[1]
-    (hit_on, miss_on), (hit_off, miss_off) = stats
-    assert miss_off - miss_on >= n // 2 and hit_on > hit_off  # (the rest: the arena growing while the map is young)
-    # a scan moved after its match: the slot filled at the result pose must not be used
-    _, scans = synth.trajectory_scans(12)
-    _, twin = synth.trajectory_scans(12)
-    a, b = ScanMatcher(), ScanMatcher()
-    b.debug_option(22, 0)
-    ma, mb = SequentialMapper(a), SequentialMapper(b)
-    for k in range(11):
-        ra, rb = ma.process_scan(scans[k]), mb.process_scan(twin[k])
-    for sc in (scans[10], twin[10]):
-        p = sc.corrected_pose
-        sc.corrected_pose = Transform(p.x + 0.013, p.y - 0.007, 0.0, p.euler[-1] + 0.004)
-    ra, rb = ma.process_scan(scans[11]), mb.process_scan(twin[11])
-    assert ra.response == rb.response and ra.covariance == rb.covariance
-
-
 def test_cfg4_loop_batch_4096_distinct_chains_against_oracle():
     """configs[3] on one GPU: the cfg2 query against 4096 distinct 10-scan chains at seeded poses (chain 0 = the query's own
     neighbourhood; every chain sees the same room, so it need not be the arg-best), loop config, penalty off, coarse only -- one match_scan_batch call.  A seeded sample of 96 chains

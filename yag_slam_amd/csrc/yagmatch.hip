@@ -151,10 +151,6 @@ struct Call {
     int k_begin = 0, k_end = -1;
     double *ext_resp = nullptr, *ext_probs = nullptr;
     bool slice = false;
-    // single synchronous matches of a resident query: once the result is on its way to the host, the query is projected
-    // at the RESULT pose into its own slot of the point cache (prefill_kernel), in the shadow of the caller's turnaround:
-    // the next match that uses it as a base scan at that pose (GraphSlam.process_scan does) finds the slot filled
-    bool prefill = false;
     // a step of a device-chained sequence (ym_map_sequence): the poses of the scans whose matches are still in flight come
     // from the device (CallScan::pose_dev; the host's are dead-reckoned predictions that only size the raster), the
     // result state lands in chain_out, and final_kernel leaves this step's pose and the next step's prior on the device
@@ -235,9 +231,6 @@ struct Slot {
     CallPlan plan;     // angle-sliced match: kept between ym_match_slice_begin and _finish
     void *dev_best_out = nullptr; // optional device buffer (8 doubles) for the cross-rank arg-max
     void *dev_best_user = nullptr; // the same pointer, kept until the slot is collected (rewritten after a response expansion)
-    int prefill_entry = -1;        // point-cache entry prefill_kernel fills for this call's query (its pose is set by finish_call)
-    uint64_t prefill_key = 0;
-    unsigned char *prefill_cache = nullptr;
     uint32_t poll_serial = 0;      // != 0: final_kernel writes this number into the word after the result states when they are complete
     uint32_t serial_counter = 0;
 };
@@ -325,7 +318,6 @@ struct ym_matcher {
     int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
-    bool prefill = true;     // synchronous single matches project their query at the result pose afterwards (Call::prefill)
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     // gather correlate: per query slot of a call the (beam, angle) units sorted by region, the bin table, the work
@@ -860,8 +852,6 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
     Call &call = slot.call;
     const int n = (int)call.scans.size();
     for (CallScan &s : call.scans) { s.cache = s.qcache = nullptr; s.stale = s.qstale = 0; }
-    slot.prefill_entry = -1;
-    slot.prefill_cache = nullptr;
     if (m->cache_off) return YM_OK;
     const uint64_t this_call = ++m->call_counter;
     // roles of every scan in this call
@@ -951,34 +941,6 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
             else { s.cache = p; s.stale = stale; s.cache_hint = e; }
         }
         break;
-    }
-    // the query's own slot as a base scan, filled after the call at the result pose (Call::prefill): until finish_call has
-    // seen that pose the entry holds one no scan can have
-    if (call.prefill && m->prefill && P.B == 1 && !P.yag && !call.slice) {
-        const CallScan &q = call.scans[call.items[0].query];
-        if (q.id != 0 && q.n > 0) {
-            const uint64_t key = q.id * 2;
-            int e = -1;
-            auto it = m->cache_index.find(key);
-            if (it != m->cache_index.end() && m->cache_entries[it->second].n == q.n) e = it->second;
-            if (e < 0) {
-                const size_t bytes = bytes_of(q, 0);
-                if (m->cache_used + bytes <= m->cache_arena.cap) {
-                    e = (int)m->cache_entries.size();
-                    m->cache_entries.push_back(ym_matcher::CacheEntry{key, m->cache_used, q.n, {0, 0, 0}, this_call});
-                    m->cache_index.emplace(key, e);
-                    m->cache_used += bytes;
-                }
-            }
-            if (e >= 0) {
-                ym_matcher::CacheEntry &ce = m->cache_entries[e];
-                ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
-                ce.stale_in_call = this_call;
-                slot.prefill_entry = e;
-                slot.prefill_key = key;
-                slot.prefill_cache = m->cache_arena.p + ce.off;
-            }
-        }
     }
     return YM_OK;
 }
@@ -1549,24 +1511,10 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
                            reinterpret_cast<double *>(slot.dev_best_out));
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, ev_call))) return rc;
-    auto enqueue_prefill = [&]() {
-        ym::PrefillArgs pa;
-        std::memset(&pa, 0, sizeof pa);
-        pa.sr = P.hs[slot.call.items[0].query];
-        pa.sr.cache = slot.prefill_cache;
-        pa.state = m->states.p;
-        pa.max_n = pa.sr.n;
-        pa.stamps = P.stamps;
-        hipLaunchKernelGGL(ym::prefill_kernel<1024>, dim3(1), dim3(1024), YM_PREP_LDS_BYTES(pa.sr.n), st, pa);
-    };
-    // The caller must not wait for the prefill.  When it polls the completion word the event is only a fallback and goes
-    // last (an event between two kernels costs the second one ~2 us); otherwise the event is recorded before the prefill.
-    if (slot.prefill_cache && slot.poll_serial) enqueue_prefill();
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     if (!slot.call.chain_step) HIP_TRY(hipEventRecord(slot.done, st)); // (a chained segment is collected with one stream synchronisation)
     slot.in_flight = true;
     slot.n_items = P.B;
-    if (slot.prefill_cache && !slot.poll_serial) enqueue_prefill();
     HIP_TRY(hipGetLastError());
     mark(6);
     if (debug_host) {
@@ -1661,14 +1609,6 @@ int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */)
     slot.in_flight = false;
     const int B = slot.n_items;
     const YmItemState *hs = reinterpret_cast<const YmItemState *>(slot.result.p);
-    if (slot.prefill_entry >= 0) {
-        // prefill_kernel projects the query at the pose of THIS state (a response expansion re-runs the call and may end
-        // elsewhere: then the entry simply does not match the scan's next pose)
-        const int e = slot.prefill_entry;
-        if ((size_t)e < m->cache_entries.size() && m->cache_entries[e].id == slot.prefill_key && hs[0].status == 0 && hs[0].nq > 0)
-            for (int i = 0; i < 3; i++) m->cache_entries[e].pose[i] = hs[0].mean[i];
-        slot.prefill_entry = -1;
-    }
     std::vector<int> redo;
     std::vector<int64_t> prior(B, 0);
     for (int i = 0; i < B; i++) {
@@ -1868,8 +1808,6 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
         ym_destroy(m);
         return nullptr;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prefill_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
     if (m->stamps.ensure(32) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipMemset(m->stamps.p, 0, 32 * sizeof(unsigned long long));
     return m;
@@ -2009,7 +1947,6 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
     Call call;
     int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
     if (rc) return rc;
-    call.prefill = true;
     slot.call = call;
     if ((rc = launch_call(m, slot))) return rc;
     return finish_call(m, slot, out);
@@ -2094,7 +2031,6 @@ static int sequence_step_sync(ym_matcher *m, ym_scan *const *scans, const double
         return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
     slot.call = Call();
     if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call))) return rc;
-    slot.call.prefill = true;
     if ((rc = launch_call(m, slot))) return rc;
     if ((rc = finish_call(m, slot, result))) return rc;
     if (result->status != 0) return YM_OK;
@@ -2145,8 +2081,7 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
         }
         if ((rc = launch_call(m, slot))) break;
         slot.in_flight = false; // (collected below, from seq_results)
-        if (slot.prefill_cache || m->cache_off || !slot.call.scans[(size_t)(i - first)].cache) {
-            // (cannot happen: chained steps never prefill, and the caller made room in the point cache) -- be safe:
+        if (m->cache_off || !slot.call.scans[(size_t)(i - first)].cache) { // (the caller made room in the point cache) -- be safe:
             enqueued++;
             rc = set_err(YM_ERR_UNSUPPORTED, "device-chained sequence without a point-cache slot");
             break;
@@ -2788,7 +2723,6 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 13) m->corr_dedup = value;
     else if (option == 14) m->corr_region = value;
     else if (option == 15) m->corr_region_na = m->corr_region_nw = value;
-    else if (option == 22) m->prefill = value != 0;
     else if (option == 23) m->poll_completion = value != 0;
     else if (option == 24) m->use_scan_structure = value != 0;
     else if (option == 16) m->raster_gx = value;

@@ -117,7 +117,7 @@ __device__ __forceinline__ int project_points(const YmScanRef &sr, double px, do
 #define YM_CHAIN_GUARD 1e-9
 #define YM_CHAIN_POSE_LIMIT 1.0e4
 template <int NT, bool GUARD = false>
-__device__ __forceinline__ int mark_chain(const PrepLds &l, int np, bool yag, unsigned long long *stamps = nullptr) {
+__device__ __forceinline__ int mark_chain(const PrepLds &l, int np, bool yag) {
     const int tid = threadIdx.x;
     const double min_sq = yag ? 0.2 * 0.2 : 0.1 * 0.1;
     int near = 0;
@@ -136,7 +136,6 @@ __device__ __forceinline__ int mark_chain(const PrepLds &l, int np, bool yag, un
     int unsafe = 0;
     if (GUARD) unsafe = __syncthreads_or(near);
     else __syncthreads();
-    if (stamps && threadIdx.x == 0 && blockIdx.x == 0) stamps[24] = wall_clock64();
     constexpr int SEG = 64;
     const int nseg = (np + SEG - 1) / SEG;
     for (int i = tid; i < np; i += NT) {
@@ -147,11 +146,9 @@ __device__ __forceinline__ int mark_chain(const PrepLds &l, int np, bool yag, un
     }
     for (int i = tid; i < nseg; i += NT) l.ent[i] = -1;
     __syncthreads();
-    if (stamps && threadIdx.x == 0 && blockIdx.x == 0) stamps[25] = wall_clock64();
     if (tid == 0)
         for (int cur = 0; cur < np; cur = l.ex[cur]) l.ent[cur / SEG] = cur;
     __syncthreads();
-    if (stamps && threadIdx.x == 0 && blockIdx.x == 0) stamps[26] = wall_clock64();
     for (int sgi = tid; sgi < nseg; sgi += NT) {
         int c = l.ent[sgi];
         if (c >= 0) {
@@ -458,32 +455,6 @@ __global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
     int2 *gov = reinterpret_cast<int2 *>(a.gov[blockIdx.x]);
     for (int i = threadIdx.x; i < np; i += NT) gov[i] = gov_walk(l, i, np, yag);
     if (threadIdx.x == 0) { a.info[2 * blockIdx.x] = np; a.info[2 * blockIdx.x + 1] = unsafe; }
-}
-
-// ---- K1p prefill: one block, after a single match.  Projects the match's query at the pose the match FOUND (the item's
-// state, still on the device) into the scan's own slot of the point cache -- what prepare_kernel would do for it as a
-// stale base scan of the next match (LocalizedRangeScan::Update after SetCorrectedPose, then the query-independent half
-// of FindValidPoints) -- while the caller is still busy with the result.
-struct PrefillArgs {
-    YmScanRef sr;              // the query; cache = the slot to fill
-    const YmItemState *state;  // the single item's state
-    int32_t max_n, pad;
-    unsigned long long *stamps;
-};
-template <int NT>
-__global__ __launch_bounds__(NT) void prefill_kernel(PrefillArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
-    const YmItemState &st = *a.state;
-    YM_STAMP(a, 20);
-    if (st.status != 0 || st.nq == 0) return; // (the host leaves the slot's pose invalid)
-    const PrepLds l = prep_lds(lds_raw, a.max_n);
-    const int np = project_points<NT>(a.sr, st.mean[0], st.mean[1], st.mean[2], false, l.sx, l.sy, s_cnt);
-    YM_STAMP(a, 21);
-    if (!a.sr.gov) mark_chain<NT>(l, np, false, a.stamps);
-    YM_STAMP(a, 22);
-    store_cache<NT>(a.sr, l, np, false);
-    YM_STAMP(a, 23);
 }
 
 // ---- K1 for batches, first half: the heavy, query-independent work ONCE per distinct scan of the call.
