@@ -6,6 +6,7 @@ attribute bag yag-slam serialises (graph_slam.py:82-83).  All numerics run in li
 the MI355X; this file only marshals scans and results across the ctypes boundary.
 """
 import ctypes as C
+import struct
 from collections import namedtuple
 
 import numpy as np
@@ -40,15 +41,18 @@ def _desc_of(scan, keep):
     return d
 
 
+# one unpack of the whole ym_result instead of ~30 ctypes field reads (a few microseconds of a 60 us match)
+_RESULT_STRUCT = struct.Struct("<d3d9ddq3i3i4i")
+assert _RESULT_STRUCT.size == C.sizeof(_capi.YmResult)
+
+
 def _result(r):
-    cov = [[r.cov[3 * i + j] for j in range(3)] for i in range(3)]
+    v = _RESULT_STRUCT.unpack_from(r)
     meta = {
-        "coarse_response": r.coarse_response, "hypotheses": int(r.hypotheses),
-        "coarse_dims": tuple(r.coarse_dims[:]), "fine_dims": tuple(r.fine_dims[:]),
-        "n_query_points": int(r.n_query_points), "expansions": int(r.expansions), "status": int(r.status),
+        "coarse_response": v[13], "hypotheses": v[14], "coarse_dims": v[15:18], "fine_dims": v[18:21],
+        "n_query_points": v[21], "expansions": v[22], "status": v[23],
     }
-    return ScanMatcherResult(r.response, cov, Transform.from_position_euler(r.pose[0], r.pose[1], 0, 0, 0, r.pose[2]),
-                             meta)
+    return ScanMatcherResult(v[0], [list(v[4:7]), list(v[7:10]), list(v[10:13])], Transform(v[1], v[2], 0.0, v[3]), meta)
 
 
 # numpy view of an array of ym_result (include/yagmatch.h): converting a batch result field by field through ctypes
@@ -124,11 +128,15 @@ class ScanMatcher(object):
     # ---- the plugin call -------------------------------------------------------------------
     def match_scan(self, query, base_scans, penalty=True, do_fine=False):
         res = _capi.YmResult()
-        handles = [self._native(s) for s in [query] + list(base_scans)]
-        if all(h is not None for h in handles):
-            arr = (C.c_void_p * max(1, len(base_scans)))(*handles[1:])
-            _capi.check(self._lib.ym_match_scans(self._m, handles[0], arr, len(base_scans), int(bool(penalty)),
-                                                 int(bool(do_fine)), C.byref(res)))
+        dev = self.device
+        handles = [s._native if (type(s) is LocalizedRangeScan and s._native is not None and s._native_device == dev)
+                   else self._native(s) for s in (query, *base_scans)]
+        if None not in handles:
+            nb = len(handles) - 1
+            arr = (C.c_void_p * max(1, nb))(*handles[1:])
+            rc = self._lib.ym_match_scans(self._m, handles[0], arr, nb, 1 if penalty else 0, 1 if do_fine else 0, C.byref(res))
+            if rc:
+                _capi.check(rc)
         else:
             keep = []
             q = _desc_of(query, keep)
