@@ -146,6 +146,10 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
 int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, int n, int start, int buffer_len,
                     int penalize, int refine, int device_chain, ym_result *results, int32_t *n_done);
 
+/* counters of ym_map_sequence since ym_create: device-chained segments enqueued, segments a fault cut short, steps run
+ * synchronously (all of them without device_chain) */
+int ym_sequence_stats(const ym_matcher *m, int64_t *segments, int64_t *faults, int64_t *sync_steps);
+
 /* Pipelined form: enqueue on the matcher's stream, collect later.  `slot` in [0, ym_async_slots). */
 int ym_async_slots(const ym_matcher *m);
 int ym_match_scans_async(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base,
@@ -267,7 +271,8 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * 19: units per LDS buffer of the gather correlate (small values cut regions into chunks); 20: LDS bytes a gather block may
  * use (small values make the regions small); 23: 0 = single matches wait for a stream event instead
  * of polling the completion word; 24: 0 = the trigger chains of base scans are recomputed at every pose instead of taken
- * from the scan's creation-time structure; 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
+ * from the scan's creation-time structure; 25: tiles added around the raster rectangle a device-chained step predicts
+ * (1; negative values make every chained step a fault); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
  * (0: it scores them itself unless option 12 asks for the integer sums). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 

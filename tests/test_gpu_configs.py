@@ -133,6 +133,60 @@ def test_device_chained_sequence_agrees_with_the_per_scan_loop():
     assert abs(ra.response - rb.response) <= 1e-9
 
 
+def test_device_chained_sequence_recovers_from_faults():
+    """What the host cannot know when it plans a chained step ahead of the device is caught on the device and the step is
+    repeated synchronously: (1) the chain's cells leaving the rectangle of raster tiles the host sized from dead-reckoned
+    poses -- provoked with a rectangle shrunk by debug option 25 (an odometry that turns and stretches every increment
+    stays inside the real one in this room) --; (2) a scan whose odometry jumps by metres, i.e. a match that needs Karto's
+    response expansion.  Results as from the per-scan loop, to rounding."""
+    import math
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    n = 300
+
+    def scans_with(odom_of):
+        _, scans = synth.trajectory_scans(n)
+        od = odom_of([s.odom_pose for s in scans])
+        for s, o in zip(scans, od):
+            s.odom_pose = o
+        return scans
+
+    def drifting(od):
+        out = [od[0]]
+        for a, b in zip(od, od[1:]):
+            d = b - a
+            out.append(out[-1] + Transform(1.06 * d.x, 1.06 * d.y, 0.0, d.euler[-1] + 0.012))
+        return out
+
+    def jumping(od):
+        out = list(od)
+        p = out[120]
+        out[120] = Transform(p.x + 100.0, p.y - 60.0, 0.0, p.euler[-1] + 0.9)   # (one bad odometry pose: two bad increments)
+        return out
+
+    for name, odom_of, want_fault in (("drift", drifting, False), ("shrunk", drifting, True), ("jump", jumping, True)):
+        ref_scans, dev_scans = scans_with(odom_of), scans_with(odom_of)
+        ref = SequentialMapper(ScanMatcher())
+        ref_out = ref.process_scans(ref_scans)
+        dm = ScanMatcher()
+        if name == "shrunk":
+            dm.debug_option(25, -3)
+        dev = SequentialMapper(dm)
+        dev_out = dev.process_scans(dev_scans, device_chain=True)
+        segments, faults, sync_steps = dm.sequence_stats()
+        assert segments >= 3 and (faults >= 1) == want_fault and sync_steps == faults, (name, segments, faults, sync_steps)
+        for i in range(1, n):
+            a, b = ref_out[i], dev_out[i]
+            assert abs(a.response - b.response) <= 1e-9, (name, i)
+            assert a.meta == b.meta or a.meta["hypotheses"] == b.meta["hypotheses"], (name, i)
+            pa, pb = ref_scans[i].corrected_pose, dev_scans[i].corrected_pose
+            assert max(abs(pa.x - pb.x), abs(pa.y - pb.y), abs(pa.euler[-1] - pb.euler[-1])) <= 1e-9, (name, i)
+        if name == "jump":
+            assert max(r.meta["expansions"] for r in dev_out[1:]) >= 1
+
+
 def test_cfg4_loop_batch_4096_distinct_chains_against_oracle():
     """configs[3] on one GPU: the cfg2 query against 4096 distinct 10-scan chains at seeded poses (chain 0 = the query's own
     neighbourhood; every chain sees the same room, so it need not be the arg-best), loop config, penalty off, coarse only -- one match_scan_batch call.  A seeded sample of 96 chains

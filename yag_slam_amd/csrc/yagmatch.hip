@@ -315,6 +315,8 @@ struct ym_matcher {
     DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
     DevBuf<int32_t> rg_starts;
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
+    int64_t seq_segments = 0, seq_faults = 0, seq_sync_steps = 0; // ym_map_sequence: chained segments, those cut short, synchronous steps
     int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
@@ -1109,7 +1111,10 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
         want[0] = std::min(want[0], (int)std::floor(cx0 / YM_TILE_W) - 1); want[2] = std::max(want[2], (int)std::floor(cx1 / YM_TILE_W) + 1);
         want[1] = std::min(want[1], (int)std::floor(cy0 / YM_TILE_H) - 1); want[3] = std::max(want[3], (int)std::floor(cy1 / YM_TILE_H) + 1);
     }
-    if (call.chain_step) { want[0] -= 1; want[1] -= 2; want[2] += 1; want[3] += 2; } // (predicted poses: 64 cells more each way)
+    if (call.chain_step) { // (predicted poses: 64 cells more each way; a negative margin, debug option 25, provokes faults)
+        const int mg = m->chain_margin;
+        want[0] -= mg; want[1] -= 2 * mg; want[2] += mg; want[3] += 2 * mg;
+    }
     want[0] = std::max(want[0], 0); want[1] = std::max(want[1], 0);
     want[2] = std::min(want[2], tiles_x - 1); want[3] = std::min(want[3], tiles_y - 1);
     if (want[2] < want[0] || want[3] < want[1]) { want[0] = tiles_x; want[1] = tiles_y; want[2] = want[3] = -1; } // nothing can be stamped
@@ -2131,7 +2136,9 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
     // inline descriptor (chain + query <= YM_INLINE_SCANS) and the two-kernel finish
     const bool can_chain = device_chain && m->cfg.semantics == YM_SEM_KARTO && !m->cache_off && buffer_len + 1 <= YM_INLINE_SCANS &&
                            m->finish_form != 2;
-    const int kSegment = 128;
+    // segment length: a fault (the odometry drifted away from the matches, a response expansion) costs the rest of its
+    // segment, so the length halves after one and doubles again after a segment that went through
+    int seg_len = 128;
     int i = begin, n_sync = 0, n_segments = 0;
     while (i < n) {
         int rc;
@@ -2139,7 +2146,7 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
         if (can_chain && n - i >= 2) {
             // room in the point cache for the slots this segment creates (a growing arena drops every entry: not while the
             // host does not know the poses they were filled at)
-            const int hi = std::min(n, i + kSegment);
+            const int hi = std::min(n, i + seg_len);
             size_t need = 0;
             for (int j = std::max(0, i - buffer_len); j < hi; j++)
                 if (m->cache_index.find(scans[j]->id * 2) == m->cache_index.end()) need += align_up(YM_CACHE_BYTES(scans[j]->n), 16);
@@ -2165,13 +2172,17 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
                 i += done;
                 *n_done = i;
                 n_segments++;
+                m->seq_segments++;
                 chained = done == hi - (i - done);
+                seg_len = chained ? std::min(128, seg_len * 2) : std::max(8, seg_len / 2);
                 if (chained) continue; // (else: scan i faulted -- repeat it the ordinary way)
+                m->seq_faults++;
             }
         }
         if (i >= n) break;
         if ((rc = sequence_step_sync(m, scans, odom, i, buffer_len, penalize, refine, &results[i]))) return rc;
         n_sync++;
+        m->seq_sync_steps++;
         if (results[i].status != 0) return YM_OK;
         *n_done = ++i;
     }
@@ -2725,6 +2736,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 15) m->corr_region_na = m->corr_region_nw = value;
     else if (option == 23) m->poll_completion = value != 0;
     else if (option == 24) m->use_scan_structure = value != 0;
+    else if (option == 25) m->chain_margin = value;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
@@ -2775,6 +2787,12 @@ int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launche
     if (ms_total) *ms_total = m->prof[which].ms;
     if (launches) *launches = m->prof[which].launches;
     if (reset) { m->prof[which].ms = 0; m->prof[which].launches = 0; }
+    return YM_OK;
+}
+
+int ym_sequence_stats(const ym_matcher *m, int64_t *segments, int64_t *faults, int64_t *sync_steps) {
+    if (!m || !segments || !faults || !sync_steps) return set_err(YM_ERR_INVALID, "null argument");
+    *segments = m->seq_segments; *faults = m->seq_faults; *sync_steps = m->seq_sync_steps;
     return YM_OK;
 }
 

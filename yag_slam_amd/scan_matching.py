@@ -180,6 +180,12 @@ class ScanMatcher(object):
                                 "range (scan %d of the sequence)" % done.value)
         return res
 
+    def sequence_stats(self):
+        """(device-chained segments, segments cut short by a fault, synchronous steps) of map_sequence so far"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _capi.check(self._lib.ym_sequence_stats(self._m, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
     def match_scan_batch(self, query, chains, penalty=False, do_fine=False):
         """One query against many candidate chains (the loop of graph_slam.py:217-236 in one call).
         Returns (per_chain_results, best_index)."""
