@@ -130,7 +130,10 @@ struct CallScan {
     int qcache_hint = -1;           // the same three for the scan as the QUERY of a batch
     unsigned char *qcache = nullptr;
     int qstale = 0;
-    const int32_t *gov = nullptr;     // the scan's pose-independent chain structure, when it may be used at this pose
+    const int32_t *gov = nullptr;     // the scan's pose-independent chain structure (trusted scans) ...
+    const int32_t *cidx = nullptr;    // ... its compaction ...
+    int cnp = 0;                      // ... and its number of point readings
+    bool direct = false;              // this call uses them (plan_cache): the scan needs no slot in the point cache
     const double *pose_dev = nullptr; // device-chained sequence: where the device finds the pose the host only predicts
 };
 
@@ -155,6 +158,7 @@ struct Call {
     // from the device (CallScan::pose_dev; the host's are dead-reckoned predictions that only size the raster), the
     // result state lands in chain_out, and final_kernel leaves this step's pose and the next step's prior on the device
     int chain_step = 0;               // 0: an ordinary call
+    double *chain_pose_out = nullptr; // DEVICE: this step's row of the segment's pose table
     double chain_next_diff[3] = {0, 0, 0};
     YmItemState *chain_out = nullptr; // DEVICE view of the pinned state this step's result goes to
 };
@@ -249,6 +253,8 @@ struct ym_scan {
     int device;
     double *d_ranges;
     int32_t *d_gov[2] = {nullptr, nullptr}; // trigger-chain structure per semantics (structure_kernel), inside d_ranges' allocation;
+    int32_t *d_cidx[2] = {nullptr, nullptr}; // ... the compaction (beam -> point reading) that goes with it,
+    int32_t cnp[2] = {0, 0};                 // ... the number of point readings,
     bool gov_ok[2] = {false, false};        // ... and whether it holds at every pose (no distance test near the threshold)
     int n;
     double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
@@ -337,7 +343,7 @@ struct ym_matcher {
     DevBuf<double> probs;
     DevBuf<double> yaxes;      // yagpy: xvals, yvals, tvals per item
     DevBuf<double2> yrot;      // yagpy: points rotated per angle
-    DevBuf<double> seq_pose;   // device-chained sequences: [0..2] the last step's pose, [3..5] the next step's odometry prior
+    DevBuf<double> seq_pose;   // device-chained sequences: [0..2] the next step's odometry prior, [4 + 3k ..] the pose step k of the segment found
     DevBuf<int32_t> seq_fault; // ... and the first step the host has to repeat (0: none)
     PinnedBuf seq_results;     // ... and the result state of every step of a segment
     DevBuf<unsigned long long> stamps; // phase time stamps (development aid)
@@ -853,7 +859,12 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
 int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
     Call &call = slot.call;
     const int n = (int)call.scans.size();
-    for (CallScan &s : call.scans) { s.cache = s.qcache = nullptr; s.stale = s.qstale = 0; }
+    for (CallScan &s : call.scans) {
+        s.cache = s.qcache = nullptr;
+        s.stale = s.qstale = 0;
+        // the scan's creation-time structure holds at this pose (ym_k_prepare.hpp, structure_kernel)
+        s.direct = m->use_scan_structure && s.gov && s.cidx && std::fabs(s.pose[0]) < YM_CHAIN_POSE_LIMIT && std::fabs(s.pose[1]) < YM_CHAIN_POSE_LIMIT;
+    }
     if (m->cache_off) return YM_OK;
     const uint64_t this_call = ++m->call_counter;
     // roles of every scan in this call
@@ -866,7 +877,9 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
     std::vector<Want> wants;
     for (int i = 0; i < n; i++) {
         if (call.scans[i].id == 0 || call.scans[i].n <= 0) continue;
-        if (role[i] & 1) wants.push_back(Want{i, 0});
+        // a few items: a scan with a trusted structure is projected by its own block faster than its cache slot is read
+        // (one round of loads instead of three), so it gets none
+        if ((role[i] & 1) && !(P.B < 8 && call.scans[i].direct)) wants.push_back(Want{i, 0});
         if (role[i] & 2) wants.push_back(Want{i, 1});
     }
     auto bytes_of = [](const CallScan &s, int kind) { return align_up(kind ? YM_QCACHE_BYTES(s.n) : YM_CACHE_BYTES(s.n), 16); };
@@ -1032,7 +1045,10 @@ int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
         hs[i].range_threshold = s.range_threshold;
         hs[i].pose[0] = s.pose[0]; hs[i].pose[1] = s.pose[1]; hs[i].pose[2] = s.pose[2];
         hs[i].pose_dev = s.pose_dev;
-        hs[i].gov = (m->use_scan_structure && std::fabs(s.pose[0]) < YM_CHAIN_POSE_LIMIT && std::fabs(s.pose[1]) < YM_CHAIN_POSE_LIMIT) ? s.gov : nullptr;
+        hs[i].gov = s.direct ? s.gov : nullptr;
+        hs[i].cidx = s.direct ? s.cidx : nullptr;
+        hs[i].cnp = s.direct ? s.cnp : 0;
+        hs[i].pad2 = 0;
     }
     for (int i = 0; i < P.B; i++) {
         hi[i].query = call.items[i].query;
@@ -1444,10 +1460,10 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.qlocal = m->qlocal.p; a.foffsets = m->foffsets.p; a.fsums = m->sums.p + m->sums_pass_offset[1];
     a.fsums_stride = P.sums_f; a.stamps = P.stamps;
     a.host_flag = nullptr; a.serial = 0; a.pad1 = 0;
-    a.seq_pose = nullptr; a.fault = nullptr; a.next_diff[0] = a.next_diff[1] = a.next_diff[2] = 0.0; a.step = 0; a.expansion = 0;
+    a.seq_pose = nullptr; a.seq_prior = nullptr; a.fault = nullptr; a.next_diff[0] = a.next_diff[1] = a.next_diff[2] = 0.0; a.step = 0; a.expansion = 0;
     if (call.chain_step) {
         a.host_out = call.chain_out;
-        a.seq_pose = m->seq_pose.p; a.fault = m->seq_fault.p; a.step = call.chain_step;
+        a.seq_pose = call.chain_pose_out; a.seq_prior = m->seq_pose.p; a.fault = m->seq_fault.p; a.step = call.chain_step;
         for (int k = 0; k < 3; k++) a.next_diff[k] = call.chain_next_diff[k];
         a.expansion = (m->cfg.semantics == YM_SEM_KARTO && m->cfg.use_response_expansion) ? 1 : 0;
     }
@@ -1688,6 +1704,8 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->cache_hint = o->qcache_hint = -1;
     const int sem = semantics == YM_SEM_YAGPY ? 1 : 0;
     o->gov = s->gov_ok[sem] ? s->d_gov[sem] : nullptr;
+    o->cidx = s->gov_ok[sem] ? s->d_cidx[sem] : nullptr;
+    o->cnp = s->cnp[sem];
     return YM_OK;
 }
 
@@ -1881,10 +1899,11 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     world_bbox(s->lbox, s->pose, s->wbox);
     s->beam_spacing = median_beam_spacing(d->ranges, d->n, d->min_range, d->range_threshold, d->angle_increment);
     DevGuard guard(device);
-    // one allocation: ranges[n], the chain structure per semantics [2][n][2] ints, its info words [4]
+    // one allocation: ranges[n], the chain structure per semantics ([2][n][2] + [2][n] ints), its info words [4]
     const size_t n1 = (size_t)std::max(1, d->n);
     const size_t ranges_bytes = align_up(sizeof(double) * n1, 16), gov_bytes = align_up(sizeof(int32_t) * 2 * n1, 16);
-    if (!guard.ok || hipMalloc(reinterpret_cast<void **>(&s->d_ranges), ranges_bytes + 2 * gov_bytes + 16) != hipSuccess) {
+    const size_t cidx_bytes = align_up(sizeof(int32_t) * n1, 16);
+    if (!guard.ok || hipMalloc(reinterpret_cast<void **>(&s->d_ranges), ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes + 16) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot allocate device ranges");
         delete s;
         return nullptr;
@@ -1899,7 +1918,9 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
         unsigned char *base = reinterpret_cast<unsigned char *>(s->d_ranges);
         s->d_gov[0] = reinterpret_cast<int32_t *>(base + ranges_bytes);
         s->d_gov[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + gov_bytes);
-        int32_t *d_info = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes);
+        s->d_cidx[0] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes);
+        s->d_cidx[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes + cidx_bytes);
+        int32_t *d_info = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes);
         static std::atomic<int> lds_raised{0};
         if (!lds_raised.exchange(1))
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1908,12 +1929,14 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
         std::memset(&sa, 0, sizeof sa);
         sa.sr.ranges = s->d_ranges; sa.sr.n = s->n; sa.sr.min_angle = s->min_angle; sa.sr.angle_inc = s->angle_inc;
         sa.sr.min_range = s->min_range; sa.sr.range_threshold = s->range_threshold;
-        sa.gov[0] = s->d_gov[0]; sa.gov[1] = s->d_gov[1]; sa.info = d_info;
+        sa.gov[0] = s->d_gov[0]; sa.gov[1] = s->d_gov[1]; sa.cidx[0] = s->d_cidx[0]; sa.cidx[1] = s->d_cidx[1]; sa.info = d_info;
         hipLaunchKernelGGL(ym::structure_kernel<512>, dim3(2), dim3(512), YM_PREP_LDS_BYTES(s->n), 0, sa);
         int32_t info[4] = {0, 1, 0, 1};
         if (hipGetLastError() == hipSuccess && hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost) == hipSuccess) {
             s->gov_ok[0] = info[1] == 0;
             s->gov_ok[1] = info[3] == 0;
+            s->cnp[0] = info[0];
+            s->cnp[1] = info[2];
         } // (a failure only means the matchers compute the chain per pose)
     }
     return s;
@@ -2054,13 +2077,12 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
     DEV_GUARD(m->device);
     int rc;
     const int n_seg = hi - lo;
-    if ((rc = m->seq_pose.ensure(6))) return rc;
+    if ((rc = m->seq_pose.ensure(4 + 3 * (size_t)n_seg))) return rc; // [0..2] the next step's prior, [4 + 3k ..] the pose of step lo + k
     if ((rc = m->seq_fault.ensure(1))) return rc;
     if ((rc = m->seq_results.ensure(sizeof(YmItemState) * (size_t)n_seg))) return rc;
     HIP_TRY(hipMemsetAsync(m->seq_fault.p, 0, sizeof(int32_t), m->stream));
     Slot &slot = m->slots[kAsyncSlots];
     if (slot.in_flight) return set_err(YM_ERR_BUSY, "the matcher's synchronous slot holds a call in flight");
-    std::vector<std::array<double, 3>> predicted((size_t)n_seg);
     int enqueued = 0;
     for (int i = lo; i < hi; i++, enqueued++) {
         double inv[3], diff[3], prior[3], next_diff[3] = {0, 0, 0};
@@ -2068,7 +2090,6 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
         tf_compose(inv, odom + 3 * (size_t)i, diff);
         tf_compose(scans[i - 1]->pose, diff, prior); // (scan i - 1: its true pose for i == lo, else what the odometry predicts)
         if ((rc = ym_scan_set_pose(scans[i], prior[0], prior[1], prior[2]))) break;
-        predicted[(size_t)(i - lo)] = {prior[0], prior[1], prior[2]};
         if (i + 1 < hi) {
             tf_inverse(odom + 3 * (size_t)i, inv);
             tf_compose(inv, odom + 3 * (size_t)(i + 1), next_diff);
@@ -2080,15 +2101,17 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
         call.chain_step = i; // (>= 1)
         for (int k = 0; k < 3; k++) call.chain_next_diff[k] = next_diff[k];
         call.chain_out = reinterpret_cast<YmItemState *>(m->seq_results.dp) + (i - lo);
-        if (i > lo) {
-            call.scans[0].pose_dev = m->seq_pose.p + 3;             // the query's prior
-            call.scans[(size_t)(i - first)].pose_dev = m->seq_pose.p; // base scan i - 1 (the last of the chain): its result
-        }
+        call.chain_pose_out = m->seq_pose.p + 4 + 3 * (size_t)(i - lo);
+        if (i > lo) call.scans[0].pose_dev = m->seq_pose.p;              // the query's prior
+        for (int j = std::max(first, lo); j < i; j++)                    // base scans matched earlier in this segment: their results
+            call.scans[(size_t)(1 + j - first)].pose_dev = m->seq_pose.p + 4 + 3 * (size_t)(j - lo);
         if ((rc = launch_call(m, slot))) break;
         slot.in_flight = false; // (collected below, from seq_results)
-        if (m->cache_off || !slot.call.scans[(size_t)(i - first)].cache) { // (the caller made room in the point cache) -- be safe:
+        bool all_direct = true;
+        for (const CallScan &cs : slot.call.scans) all_direct = all_direct && cs.direct;
+        if (!all_direct) { // (cannot happen: the caller admits scans with a trusted structure only) -- be safe:
             enqueued++;
-            rc = set_err(YM_ERR_UNSUPPORTED, "device-chained sequence without a point-cache slot");
+            rc = set_err(YM_ERR_UNSUPPORTED, "device-chained step over a scan without a trusted structure");
             break;
         }
     }
@@ -2101,21 +2124,7 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
     for (int k = 0; k < good; k++) {
         const int i = lo + k;
         state_to_result(m, slot, hs[k], 0, 0, &results[i]);
-        // the point-cache slot scan i got as a base scan was filled at this pose; the host knew it as the prediction
-        auto it = m->cache_index.find(scans[i]->id * 2);
-        if (it != m->cache_index.end()) {
-            ym_matcher::CacheEntry &ce = m->cache_entries[it->second];
-            if (ce.pose[0] == predicted[(size_t)k][0] && ce.pose[1] == predicted[(size_t)k][1] && ce.pose[2] == predicted[(size_t)k][2])
-                for (int q = 0; q < 3; q++) ce.pose[q] = results[i].pose[q];
-        }
         (void)ym_scan_set_pose(scans[i], results[i].pose[0], results[i].pose[1], results[i].pose[2]);
-    }
-    for (int k = good; k < enqueued; k++) { // skipped steps: whatever their slots hold was not computed
-        auto it = m->cache_index.find(scans[lo + k]->id * 2);
-        if (it != m->cache_index.end()) {
-            ym_matcher::CacheEntry &ce = m->cache_entries[it->second];
-            ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
-        }
     }
     *done = good;
     return rc;
@@ -2132,9 +2141,9 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
     for (int i = 0; i < begin; i++) std::memset(&results[i], 0, sizeof results[i]);
     *n_done = begin;
     static const bool debug_host = getenv("YM_DEBUG_HOST") != nullptr;
-    // chained segments need Karto semantics (one pass structure), every scan resident with a slot in the point cache, an
-    // inline descriptor (chain + query <= YM_INLINE_SCANS) and the two-kernel finish
-    const bool can_chain = device_chain && m->cfg.semantics == YM_SEM_KARTO && !m->cache_off && buffer_len + 1 <= YM_INLINE_SCANS &&
+    // chained segments need Karto semantics (one pass structure), resident scans with a trusted structure, an inline
+    // descriptor (chain + query <= YM_INLINE_SCANS) and the two-kernel finish
+    const bool can_chain = device_chain && m->cfg.semantics == YM_SEM_KARTO && buffer_len + 1 <= YM_INLINE_SCANS &&
                            m->finish_form != 2;
     // segment length: a fault (the odometry drifted away from the matches, a response expansion) costs the rest of its
     // segment, so the length halves after one and doubles again after a segment that went through
@@ -2144,28 +2153,17 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
         int rc;
         bool chained = false;
         if (can_chain && n - i >= 2) {
-            // room in the point cache for the slots this segment creates (a growing arena drops every entry: not while the
-            // host does not know the poses they were filled at)
-            const int hi = std::min(n, i + seg_len);
-            size_t need = 0;
-            for (int j = std::max(0, i - buffer_len); j < hi; j++)
-                if (m->cache_index.find(scans[j]->id * 2) == m->cache_index.end()) need += align_up(YM_CACHE_BYTES(scans[j]->n), 16);
-            if (m->cache_used + need > m->cache_arena.cap) {
-                // grow now, between segments, when the host knows every pose: all entries go and are recomputed
-                size_t all = 0;
-                for (int j = std::max(0, i - buffer_len); j < hi; j++) all += align_up(YM_CACHE_BYTES(scans[j]->n), 16);
-                const size_t want = std::min(m->cache_limit, std::max(2 * m->cache_arena.cap, 2 * all));
-                if (want >= all) {
-                    DEV_GUARD(m->device);
-                    HIP_TRY(hipStreamSynchronize(m->stream));
-                    m->cache_entries.clear();
-                    m->cache_index.clear();
-                    m->cache_used = 0;
-                    if (want > m->cache_arena.cap && (rc = m->cache_arena.ensure(want))) return rc;
-                    need = all;
-                }
-            }
-            if (scans[i]->id != 0 && m->cache_used + need <= m->cache_arena.cap) {
+            // every scan a chained step touches must carry a trusted structure (no point-cache slot then, whose pose the
+            // host would not know): the segment ends before the first step that meets another kind
+            const int sem = 0;
+            auto trusted = [&](int j) { return scans[j]->id != 0 && scans[j]->n > 0 && scans[j]->gov_ok[sem] && m->use_scan_structure; };
+            int hi = std::min(n, i + seg_len);
+            // (the structure is trusted within YM_CHAIN_POSE_LIMIT of the origin: stay well inside with predicted poses)
+            bool chain_ok = std::fabs(scans[i - 1]->pose[0]) < 0.9 * YM_CHAIN_POSE_LIMIT && std::fabs(scans[i - 1]->pose[1]) < 0.9 * YM_CHAIN_POSE_LIMIT;
+            for (int j = std::max(0, i - buffer_len); j < i; j++) chain_ok = chain_ok && trusted(j);
+            for (int j = i; j < hi; j++)
+                if (!trusted(j)) { hi = j; break; }
+            if (chain_ok && hi - i >= 2) {
                 int done = 0;
                 rc = sequence_segment_chained(m, scans, odom, i, hi, buffer_len, penalize, refine, results, &done);
                 if (rc) { *n_done = i + done; return rc; }

@@ -168,10 +168,12 @@ struct FinishArgs {
     unsigned long long *stamps;
     uint32_t *host_flag;      // single matches: pinned host word that receives `serial` once host_out[0] is complete (the
     uint32_t serial, pad1;    // caller polls it instead of waiting for a stream event), or null
-    // device-chained sequences (ym_map_sequence): the step's pose goes to seq_pose[0..2] and the next step's odometry prior
-    // = that pose (+) next_diff (tiny_tf's Transform composition) to seq_pose[3..5]; a step that Karto would abort or
-    // repeat with a wider angle range (response expansion) is a fault the host handles
+    // device-chained sequences (ym_map_sequence): the step's pose goes to seq_pose[0..2] (this scan's row of the segment's
+    // pose table) and the next step's odometry prior = that pose (+) next_diff (tiny_tf's Transform composition) to
+    // seq_prior[0..2]; a step that Karto would abort or repeat with a wider angle range (response expansion) is a fault
+    // the host handles
     double *seq_pose;         // null: not a chained step
+    double *seq_prior;
     int32_t *fault;
     double next_diff[3];
     int32_t step, expansion;  // expansion: the matcher's use_response_expansion
@@ -450,9 +452,9 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
 __device__ __forceinline__ void chain_next_pose(const FinishArgs &a, const double pose[3]) {
     const double c = cos(pose[2]), s = sin(pose[2]);
     a.seq_pose[0] = pose[0]; a.seq_pose[1] = pose[1]; a.seq_pose[2] = pose[2];
-    a.seq_pose[3] = pose[0] + c * a.next_diff[0] - s * a.next_diff[1];
-    a.seq_pose[4] = pose[1] + s * a.next_diff[0] + c * a.next_diff[1];
-    a.seq_pose[5] = pose[2] + a.next_diff[2];
+    a.seq_prior[0] = pose[0] + c * a.next_diff[0] - s * a.next_diff[1];
+    a.seq_prior[1] = pose[1] + s * a.next_diff[0] + c * a.next_diff[1];
+    a.seq_prior[2] = pose[2] + a.next_diff[2];
 }
 
 // ---- K6b final: grid (B), 256 threads: fine arg-max / mean, angular covariance, result.

@@ -63,7 +63,7 @@ __device__ __forceinline__ PrepLds prep_lds(unsigned char *raw, int max_n) {
 // beams, wave) by ballot, pass 2 re-reads the ranges (L1) and places each valid beam after everything before it.
 template <int NT>
 __device__ __forceinline__ int project_points(const YmScanRef &sr, double px, double py, double pt, bool yag, double *sx, double *sy,
-                                              int *s_cnt /* (YM_MAX_BEAMS / NT + 1) * NT / 64 */) {
+                                              int *s_cnt /* (YM_MAX_BEAMS / NT + 1) * NT / 64 */, int32_t *cidx_out = nullptr) {
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x;
     const int lane_ = tid & 63, wave_ = tid >> 6;
@@ -93,16 +93,43 @@ __device__ __forceinline__ int project_points(const YmScanRef &sr, double px, do
             before += w < wave_ ? c : 0;
             total += c;
         }
+        const int pos = running + before + __popcll(m & ((1ull << lane_) - 1ull));
         if (ok) {
-            const int pos = running + before + __popcll(m & ((1ull << lane_) - 1ull));
             const double angle = pt + sr.min_angle + i * sr.angle_inc;
             sx[pos] = px + r * cos(angle);
             sy[pos] = py + r * sin(angle);
         }
+        if (cidx_out && i < sr.n) cidx_out[i] = ok ? pos : -1;
         running += total;
     }
     __syncthreads();
     return running;
+}
+
+// The same with the compaction known (YmScanRef::cidx, from structure_kernel: which beams give a point reading, and where
+// it goes, does not depend on the pose): one pass, one round of loads, one barrier.  gov != null: the scan's deciding
+// pairs travel with it into LDS (l.nxt / l.ex are free when no chain is walked).
+template <int NT>
+__device__ __forceinline__ int project_points_indexed(const YmScanRef &sr, double px, double py, double pt, const PrepLds &l, bool with_gov) {
+    for (int i = threadIdx.x; i < sr.n; i += NT) {
+        const int pos = sr.cidx[i];
+        const double r = sr.ranges[i];
+        if (pos >= 0) {
+            const double angle = pt + sr.min_angle + i * sr.angle_inc;
+            l.sx[pos] = px + r * cos(angle);
+            l.sy[pos] = py + r * sin(angle);
+        }
+    }
+    if (with_gov) {
+        const int2 *gov = reinterpret_cast<const int2 *>(sr.gov);
+        for (int i = threadIdx.x; i < sr.cnp; i += NT) {
+            const int2 g = gov[i];
+            l.nxt[i] = g.x;
+            l.ex[i] = g.y;
+        }
+    }
+    __syncthreads();
+    return sr.cnp;
 }
 
 // ---- the query-independent half of the valid-point filter (ScanMatcher::FindValidPoints / validate_points), parallel
@@ -407,7 +434,8 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     const double px = (is_query && yag) ? 0.0 : sr.pose[0];
     const double py = (is_query && yag) ? 0.0 : sr.pose[1];
     const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
-    const int np = project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
+    const bool indexed = sr.cidx != nullptr && sr.n > 0; // (with cidx comes gov: the scan's structure is trusted at this pose)
+    const int np = indexed ? project_points_indexed<NT>(sr, px, py, pt, l, !is_query) : project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
     YM_STAMP(a, 1);
     YM_STAMP_B1(a, 20);
     // world offset of ROI cell (0,0): MatchScan, "set scan pose to be center of grid"
@@ -425,7 +453,10 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     if (!known) mark_chain<NT>(l, np, yag);
     YM_STAMP_B1(a, 22);
     if (sr.cache) store_cache<NT>(sr, l, np, yag);
-    if (known)
+    if (indexed) // (the deciding pairs came into LDS with the points)
+        prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y,
+                          [&](int i) { return make_double2(l.sx[i], l.sy[i]); }, [&](int i) { return make_int2(l.nxt[i], l.ex[i]); });
+    else if (known)
         prepare_cells<NT>(a, b, slot, np, yag, qr.pose[0], qr.pose[1], off_x, off_y,
                           [&](int i) { return make_double2(l.sx[i], l.sy[i]); }, [&](int i) { return known[i]; });
     else
@@ -442,6 +473,7 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
 struct StructureArgs {
     YmScanRef sr;       // ranges + sensor parameters
     int32_t *gov[2];    // [n][2] per semantics: for compacted point i the chain node that decides it and where its run ends
+    int32_t *cidx[2];   // [n] per semantics: beam -> index of its point reading among the compacted ones, or -1
     int32_t *info;      // [2][2]: number of point readings, 1 = a distance test was within the guard band
 };
 template <int NT>
@@ -450,7 +482,7 @@ __global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
     __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
     const bool yag = blockIdx.x == 1;
     const PrepLds l = prep_lds(lds_raw, a.sr.n);
-    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt);
+    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt, a.cidx[blockIdx.x]);
     const int unsafe = mark_chain<NT, true>(l, np, yag);
     int2 *gov = reinterpret_cast<int2 *>(a.gov[blockIdx.x]);
     for (int i = threadIdx.x; i < np; i += NT) gov[i] = gov_walk(l, i, np, yag);
@@ -473,7 +505,8 @@ __global__ __launch_bounds__(YM_POINTS_THREADS) void points_kernel(PrepareArgs a
     const double px = (is_query && yag) ? 0.0 : sr.pose[0];
     const double py = (is_query && yag) ? 0.0 : sr.pose[1];
     const double pt = (is_query && yag) ? 0.0 : sr.pose[2];
-    const int np = project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
+    const int np = (sr.cidx && sr.n > 0) ? project_points_indexed<NT>(sr, px, py, pt, l, false)
+                                         : project_points<NT>(sr, px, py, pt, yag, l.sx, l.sy, s_cnt);
     if (is_query) { // into the scan's query slot of the point cache, else into the call's own buffer
         const int qs = a.job_slot[blockIdx.x];
         store_query_local<NT>(sr, l, np, yag, sr.qcache ? reinterpret_cast<double2 *>(sr.qcache + YM_CACHE_HEADER) : a.qlocal + (size_t)qs * a.max_n);

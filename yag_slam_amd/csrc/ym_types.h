@@ -64,6 +64,9 @@ struct YmScanRef {
     int32_t pad;
     const int32_t *gov;     // DEVICE: the scan's trigger-chain structure [n][2] computed once in the sensor frame (ym_scan_create),
                             // valid at any pose (see structure_kernel); null: compute it from the projected points
+    const int32_t *cidx;    // DEVICE, with gov: beam -> index of its point reading among the compacted ones, or -1 (no reading)
+    int32_t cnp;            // ... and how many point readings there are
+    int32_t pad2;
     const double *pose_dev; // DEVICE pointer to the pose (x, y, heading) when the host does not know it yet -- a scan of a
                             // device-chained sequence whose match is still in flight (ym_map_sequence) --, else null
 };
