@@ -794,6 +794,61 @@ def test_chain_structure_from_scan_creation_equals_the_per_pose_computation():
         ref.close()
 
 
+def test_a_resident_batch_enqueued_again_replays_its_plan_only_while_nothing_moved():
+    """`MatchBatch.run_async` on a slot that still holds the batch's call skips the per-scan host work (rebuilding the call,
+    the point-cache lookups, the descriptor) as long as no scan was re-posed and no cache slot changed hands.  Results
+    against a matcher that is built fresh for every enqueue: identical bits before and after base scans and the query
+    move, with other calls (another batch, single matches, a dropped cache) in between, on the same and on other slots."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    q, base = cfg2_scans()
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    extra = [_mk_native(b) for b in base[:4]]
+    for k, s in enumerate(extra):
+        p = s.corrected_pose
+        s.corrected_pose = Transform(p.x + 0.05 * (k + 1), p.y - 0.03 * k, 0.0, p.euler[-1] + 0.02 * k)
+    chains = [nb, nb[:5], nb[3:] + extra[:2], extra + nb[:3]] * 3
+    other = [extra, nb[::-1]] * 5
+    m = ScanMatcher()
+    batch, batch2 = m.make_batch(nq, chains), m.make_batch(nq, other)
+
+    def fresh():
+        ref = ScanMatcher()
+        out = ref.match_scan_batch(nq, chains, True, True)[0]
+        ref.close()
+        return [(r.response, r.covariance, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1]) for r in out]
+
+    def run(slot):
+        batch.run_async(True, True, slot=slot)
+        per = batch.wait(slot)[0]
+        return [(r.response, r.covariance, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1]) for r in per]
+
+    def move(s, k):
+        p = s.corrected_pose
+        s.corrected_pose = Transform(p.x + 0.011 * k, p.y - 0.007 * k, 0.0, p.euler[-1] + 0.004 * k)
+
+    want = fresh()
+    for slot in (0, 0, 1, 0, 1, 1):            # first use, replay, another slot, replays
+        assert run(slot) == want
+    move(nb[4], 1)                             # a base scan moves: every slot must notice
+    want = fresh()
+    for slot in (0, 1, 0, 2):
+        assert run(slot) == want
+    batch2.run_async(True, True, slot=0)       # the slot is taken by another batch, then by this one again
+    batch2.wait(0)
+    assert run(0) == want and run(0) == want
+    m.match_scan(nq, nb[:6], True, True)       # single matches do not disturb the slots
+    assert run(1) == want
+    m.debug_option(7, 2)                       # the point cache is dropped: a replayed plan would name dead slots
+    assert run(1) == want and run(1) == want and run(0) == want
+    move(nq, 1)                                # the query moves
+    move(extra[1], 2)
+    want = fresh()
+    for slot in (0, 1, 0):
+        assert run(slot) == want
+    m.close()
+
+
 def test_a_failed_call_leaves_no_unwritten_cache_entries():
     """Round-2 advisor finding: the point cache is updated on the host before the kernels that fill its entries are enqueued.
     A call that fails in between (here: an order-dependent smear on a chain of more readings than the select kernels

@@ -24,6 +24,8 @@ namespace {
 
 thread_local std::string g_err;
 
+std::atomic<uint64_t> g_pose_epoch{1}; // bumped by every ym_scan_set_pose: "no scan moved since" is one comparison
+
 int set_err(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -157,6 +159,15 @@ struct Call {
     // a step of a device-chained sequence (ym_map_sequence): the poses of the scans whose matches are still in flight come
     // from the device (CallScan::pose_dev; the host's are dead-reckoned predictions that only size the raster), the
     // result state lands in chain_out, and final_kernel leaves this step's pose and the next step's prior on the device
+    // a resident batch enqueued again (ym_batch_run_async): the batch this Call was built from, the pose epoch it was built
+    // in (no ym_scan_set_pose since: every field is still right), and the point-cache generation its cache / stale fields
+    // were planned in without any slot left to fill -- while all three hold the host plans nothing per scan
+    uint64_t batch_uid = 0, pose_epoch = 0, plan_gen = 0;
+    bool plan_clean = false;
+    std::vector<int32_t> plan_jobs, plan_job_slot, plan_qrep; // what plan_jobs produced for that plan ...
+    int plan_want[4] = {0, 0, -1, -1};                        // ... and the tile rectangle plan_raster found the chains' boxes in,
+    int plan_want_geom[2] = {0, 0};                           // ... for this window (origin, width)
+    bool plan_want_valid = false;
     int chain_step = 0;               // 0: an ordinary call
     double *chain_pose_out = nullptr; // DEVICE: this step's row of the segment's pose table
     double chain_next_diff[3] = {0, 0, 0};
@@ -223,8 +234,7 @@ struct CallPlan {
 struct Slot {
     PinnedBuf desc;    // YmScanRef[] + YmItem[] staged for the H2D copy
     DevBuf<unsigned char> desc_dev;         // the slot's descriptor on the device ...
-    std::vector<unsigned char> desc_shadow; // ... and what was last copied there: a call whose descriptor is byte for byte
-                                            // the slot's previous one (the same resident batch again) skips the 4 MB copy
+    size_t desc_live_bytes = 0;             // != 0: the pinned buffer AND the device copy hold the slot's last descriptor, of this size
     PinnedBuf result;  // YmItemState[] landed by the D2H copy
     hipEvent_t done = nullptr;
     bool in_flight = false;
@@ -284,6 +294,7 @@ struct ym_batch {
     std::vector<int32_t> offsets;
     mutable std::vector<int> cache_hints; // per scan: its entry in the owning matcher's point cache (validated on use)
     mutable int query_hint = -1;
+    uint64_t uid = 0; // unique per created batch
 };
 
 struct ym_matcher {
@@ -322,6 +333,7 @@ struct ym_matcher {
     DevBuf<int32_t> rg_starts;
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
     int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
+    uint64_t cache_gen = 1;      // bumped whenever the point cache changes (entries created, re-posed, dropped) or an option is set
     int64_t seq_segments = 0, seq_faults = 0, seq_sync_steps = 0; // ym_map_sequence: chained segments, those cut short, synchronous steps
     int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
@@ -626,8 +638,9 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     int wh = (int)std::ceil(reach / g.res) + 3;
     // (in steps of 64 cells: the window -- and with it the "this tile is zero" knowledge about its memory -- then stays
     //  the same from match to match while the queries' longest readings differ by less)
-    wh = (wh + 63) / 64 * 64;
-    if (m->last_wh >= wh && m->last_wh - wh <= 256) wh = m->last_wh; // (and not smaller again at once: a window up to 256 cells too wide stays)
+    static const bool no_quant = getenv("YM_NO_WINDOW_QUANTUM") != nullptr; // (development)
+    if (!no_quant) wh = (wh + 63) / 64 * 64;
+    if (!no_quant && m->last_wh >= wh && m->last_wh - wh <= 256) wh = m->last_wh; // (and not smaller again at once: a window up to 256 cells too wide stays)
     m->last_wh = wh;
     wh = wrap ? centre : std::min(wh, centre);
     g.win_origin = centre - wh;
@@ -910,6 +923,7 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
                 m->cache_entries.clear();
                 m->cache_index.clear();
                 m->cache_used = 0;
+                m->cache_gen++;
                 if (want > m->cache_arena.cap) {
                     HIP_TRY(hipStreamSynchronize(m->stream)); // calls in flight still read the old arena
                     int rc = m->cache_arena.ensure(want);
@@ -954,6 +968,7 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
             unsigned char *p = m->cache_arena.p + m->cache_entries[e].off;
             if (kind) { s.qcache = p; s.qstale = stale; s.qcache_hint = e; }
             else { s.cache = p; s.stale = stale; s.cache_hint = e; }
+            if (stale) m->cache_gen++;
         }
         break;
     }
@@ -963,11 +978,31 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
 // Batches: the work list of points_kernel -- every distinct query once (into its query slot, which the items then
 // share) and every base scan whose cache slot this call has to fill once.  Base scans the point cache cannot hold get a
 // slot in a per-call scratch arena, so that cells_kernel reads all of them the same way.
-int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P) {
+int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P, bool replay = false) {
     Call &call = slot.call;
     P.split_prepare = P.B >= 8;
     if (!P.split_prepare) return YM_OK;
     const int n = (int)call.scans.size();
+    auto ensure_lists = [&](int n_q) {
+        int rc;
+        if (P.region26) { // the region correlate's lists: one per query slot
+            if ((rc = m->rg_entries.ensure((size_t)n_q * P.rg_entries_stride))) return rc;
+            if ((rc = m->rg_starts.ensure((size_t)n_q * P.rg_starts_stride))) return rc;
+        }
+        if (P.region) { // the gather correlate's lists: one set per query slot
+            if ((rc = m->ga_units.ensure((size_t)n_q * P.ga_units_stride))) return rc;
+            if ((rc = m->ga_starts.ensure((size_t)n_q * P.ga_starts_stride))) return rc;
+            if ((rc = m->ga_work.ensure((size_t)n_q * P.ga_parts * P.ga_work_stride))) return rc;
+            if ((rc = m->ga_counters.ensure((size_t)n_q * 4 * P.ga_nbins2 * YM_GA_CLS))) return rc;
+        }
+        return (int)YM_OK;
+    };
+    if (replay) { // (the same call planned the same way: see launch_call_body)
+        P.jobs = call.plan_jobs; P.job_slot = call.plan_job_slot; P.qrep = call.plan_qrep;
+        P.n_jobs = (int)P.jobs.size();
+        P.n_qslots = (int)P.qrep.size();
+        return ensure_lists(P.n_qslots);
+    }
     std::vector<int> base_used(n, 0), qslot_of(n, -1);
     for (const CallItem &it : call.items)
         for (int j = 0; j < it.base_count; j++) base_used[it.base_begin + j] = 1;
@@ -1003,83 +1038,89 @@ int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P) {
         if (base_used[i] && call.scans[i].stale) { jobs.push_back(i); job_slot.push_back(0); }
     P.n_jobs = (int)jobs.size();
     P.n_qslots = n_q;
-    if (P.region26) { // the region correlate's lists: one per query slot
-        int rc;
-        if ((rc = m->rg_entries.ensure((size_t)n_q * P.rg_entries_stride))) return rc;
-        if ((rc = m->rg_starts.ensure((size_t)n_q * P.rg_starts_stride))) return rc;
-    }
-    if (P.region) { // the gather correlate's lists: one set per query slot
-        int rc;
-        if ((rc = m->ga_units.ensure((size_t)n_q * P.ga_units_stride))) return rc;
-        if ((rc = m->ga_starts.ensure((size_t)n_q * P.ga_starts_stride))) return rc;
-        if ((rc = m->ga_work.ensure((size_t)n_q * P.ga_parts * P.ga_work_stride))) return rc;
-        if ((rc = m->ga_counters.ensure((size_t)n_q * 4 * P.ga_nbins2 * YM_GA_CLS))) return rc;
-    }
-    return YM_OK;
+    if (call.batch_uid) { call.plan_jobs = jobs; call.plan_job_slot = job_slot; call.plan_qrep = P.qrep; }
+    return ensure_lists(n_q);
 }
 
 // the call descriptor: written into pinned host memory; a single match carries it in the kernel arguments, a batch
 // gets it by one async H2D copy (hundreds of blocks reading pinned host memory directly is slower)
-int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P) {
+int plan_descriptor(ym_matcher *m, Slot &slot, CallPlan &P, bool replay = false) {
     const Call &call = slot.call;
     int rc;
     P.scans_bytes = align_up(sizeof(YmScanRef) * P.nscans, 16);
     const size_t items_bytes = align_up(sizeof(YmItem) * P.B, 16);
     P.desc_bytes = P.scans_bytes + items_bytes + sizeof(int32_t) * (2 * (size_t)P.n_jobs + P.qrep.size());
+    const unsigned char *pinned_before = slot.desc.p;
     if ((rc = slot.desc.ensure(P.desc_bytes))) return rc;
+    if (slot.desc.p != pinned_before) slot.desc_live_bytes = 0;
     if ((rc = slot.result.ensure(align_up(sizeof(YmItemState) * P.B, 64) + 64))) return rc; // (+ the completion word of single matches)
+    P.inline_desc = (P.B == 1 && P.nscans <= YM_INLINE_SCANS && !P.split_prepare);
+    // The slot's pinned buffer still holds its previous call's descriptor, and the device copy equals it (desc_live_bytes:
+    // the slot's previous call is complete -- a slot is handed out again only after it was collected -- so both are free
+    // to be rewritten).  A batch that is enqueued again differs in a few records at most (a re-posed scan, a moved cache
+    // slot): every record is built in registers and WRITTEN ONLY IF IT DIFFERS, and the 5 MB copy to the device is skipped
+    // when none did (round 2 filled the buffer, compared it with a shadow copy and refreshed the shadow: three passes
+    // over 5 MB per enqueue of 4096 chains, 1.9 ms of host time).
+    const bool live = !P.inline_desc && slot.desc_dev.p && slot.desc_live_bytes == P.desc_bytes;
+    bool changed = !live;
     YmScanRef *hs = P.hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
     YmItem *hi = P.hi = reinterpret_cast<YmItem *>(slot.desc.p + P.scans_bytes);
-    for (int i = 0; i < P.nscans; i++) {
+    const bool untouched = replay && live; // (the same Call, planned the same way: every record is what it was)
+    for (int i = 0; i < (untouched ? 0 : P.nscans); i++) {
         const CallScan &s = call.scans[i];
-        hs[i].ranges = s.d_ranges;
-        hs[i].n = s.n;
-        hs[i].stale = s.stale;
-        hs[i].cache = s.cache;
-        hs[i].qcache = s.qcache;
-        hs[i].qstale = s.qstale;
-        hs[i].pad = 0;
-        hs[i].min_angle = s.min_angle;
-        hs[i].angle_inc = s.angle_inc;
-        hs[i].min_range = s.min_range;
-        hs[i].range_threshold = s.range_threshold;
-        hs[i].pose[0] = s.pose[0]; hs[i].pose[1] = s.pose[1]; hs[i].pose[2] = s.pose[2];
-        hs[i].pose_dev = s.pose_dev;
-        hs[i].gov = s.direct ? s.gov : nullptr;
-        hs[i].cidx = s.direct ? s.cidx : nullptr;
-        hs[i].cnp = s.direct ? s.cnp : 0;
-        hs[i].pad2 = 0;
+        YmScanRef r;
+        std::memset(&r, 0, sizeof r);
+        r.ranges = s.d_ranges;
+        r.n = s.n;
+        r.stale = s.stale;
+        r.cache = s.cache;
+        r.qcache = s.qcache;
+        r.qstale = s.qstale;
+        r.min_angle = s.min_angle;
+        r.angle_inc = s.angle_inc;
+        r.min_range = s.min_range;
+        r.range_threshold = s.range_threshold;
+        r.pose[0] = s.pose[0]; r.pose[1] = s.pose[1]; r.pose[2] = s.pose[2];
+        r.pose_dev = s.pose_dev;
+        r.gov = s.direct ? s.gov : nullptr;
+        r.cidx = s.direct ? s.cidx : nullptr;
+        r.cnp = s.direct ? s.cnp : 0;
+        if (!live || std::memcmp(&hs[i], &r, sizeof r) != 0) {
+            hs[i] = r;
+            changed = true;
+        }
     }
-    for (int i = 0; i < P.B; i++) {
-        hi[i].query = call.items[i].query;
-        hi[i].base_begin = call.items[i].base_begin;
-        hi[i].base_count = call.items[i].base_count;
-        hi[i].pad = call.items[i].qslot;
+    for (int i = 0; i < (untouched ? 0 : P.B); i++) {
+        const YmItem it = {call.items[i].query, call.items[i].base_begin, call.items[i].base_count, call.items[i].qslot};
+        if (!live || std::memcmp(&hi[i], &it, sizeof it) != 0) {
+            hi[i] = it;
+            changed = true;
+        }
     }
-    if (P.n_jobs > 0) {
-        int32_t *hj = reinterpret_cast<int32_t *>(slot.desc.p + P.scans_bytes + items_bytes);
-        std::memcpy(hj, P.jobs.data(), sizeof(int32_t) * P.n_jobs);
-        std::memcpy(hj + P.n_jobs, P.job_slot.data(), sizeof(int32_t) * P.n_jobs);
-    }
-    if (!P.qrep.empty())
-        std::memcpy(reinterpret_cast<int32_t *>(slot.desc.p + P.scans_bytes + items_bytes) + 2 * P.n_jobs, P.qrep.data(), sizeof(int32_t) * P.qrep.size());
-    P.inline_desc = (P.B == 1 && P.nscans <= YM_INLINE_SCANS && !P.split_prepare);
+    int32_t *hj = reinterpret_cast<int32_t *>(slot.desc.p + P.scans_bytes + items_bytes);
+    auto put = [&](int32_t *dst, const int32_t *src, size_t count) {
+        if (count && (!live || std::memcmp(dst, src, sizeof(int32_t) * count) != 0)) {
+            std::memcpy(dst, src, sizeof(int32_t) * count);
+            changed = true;
+        }
+    };
+    put(hj, P.jobs.data(), (size_t)P.n_jobs);
+    put(hj + P.n_jobs, P.job_slot.data(), (size_t)P.n_jobs);
+    put(hj + 2 * (size_t)P.n_jobs, P.qrep.data(), P.qrep.size());
     if (!P.inline_desc) {
-        // (the slot's previous call is complete -- a slot is handed out again only after it was collected -- so both its
-        //  pinned buffer and its device copy are free to be rewritten)
-        const bool same = slot.desc_dev.p && slot.desc_shadow.size() == P.desc_bytes &&
-                          std::memcmp(slot.desc_shadow.data(), slot.desc.p, P.desc_bytes) == 0;
-        if (!same) {
-            slot.desc_shadow.clear();
+        if (changed) {
+            slot.desc_live_bytes = 0;
             if ((rc = slot.desc_dev.ensure(P.desc_bytes))) return rc;
             HIP_TRY(hipMemcpyAsync(slot.desc_dev.p, slot.desc.p, P.desc_bytes, hipMemcpyHostToDevice, m->stream));
-            if (P.desc_bytes >= (size_t)1 << 16) slot.desc_shadow.assign(slot.desc.p, slot.desc.p + P.desc_bytes); // (small ones: just copy)
+            slot.desc_live_bytes = P.desc_bytes;
         }
         P.d_scans = reinterpret_cast<const YmScanRef *>(slot.desc_dev.p);
         P.d_items = reinterpret_cast<const YmItem *>(slot.desc_dev.p + P.scans_bytes);
         P.d_jobs = reinterpret_cast<const int32_t *>(slot.desc_dev.p + P.scans_bytes + items_bytes);
         P.d_job_slot = P.d_jobs + P.n_jobs;
         P.d_qrep = P.d_job_slot + P.n_jobs;
+    } else {
+        slot.desc_live_bytes = 0; // (the descriptor travels in the kernel arguments; the device copy is not maintained)
     }
     return YM_OK;
 }
@@ -1111,6 +1152,11 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     // the call, convert to window tiles (+ smear halo, + 1 tile of hysteresis).  Only that sub-grid is launched,
     // extended to the rectangles that may still hold old non-zero bytes in any of this call's items.
     int want[4] = {tiles_x, tiles_y, -1, -1};
+    // (a replayed plan of a resident batch: the same poses, the same rectangle -- kept with the call)
+    const bool want_known = call.plan_want_valid && call.plan_clean && call.pose_epoch == g_pose_epoch.load(std::memory_order_relaxed) &&
+                            call.batch_uid != 0 && call.plan_want_geom[0] == g.win_origin && call.plan_want_geom[1] == g.win_w;
+    if (want_known) for (int k = 0; k < 4; k++) want[k] = call.plan_want[k];
+    else
     for (const CallItem &it : call.items) {
         double wx0 = 1e300, wy0 = 1e300, wx1 = -1e300, wy1 = -1e300; // the chain's boxes joined (kept with the scans' poses)
         for (int j = 0; j < it.base_count; j++) {
@@ -1126,6 +1172,12 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
         const double cy0 = (wy0 - offy) / g.res + g.border - g.win_origin - pad, cy1 = (wy1 - offy) / g.res + g.border - g.win_origin + pad;
         want[0] = std::min(want[0], (int)std::floor(cx0 / YM_TILE_W) - 1); want[2] = std::max(want[2], (int)std::floor(cx1 / YM_TILE_W) + 1);
         want[1] = std::min(want[1], (int)std::floor(cy0 / YM_TILE_H) - 1); want[3] = std::max(want[3], (int)std::floor(cy1 / YM_TILE_H) + 1);
+    }
+    if (call.batch_uid != 0 && !want_known) {
+        Call &wc = slot.call;
+        for (int k = 0; k < 4; k++) wc.plan_want[k] = want[k];
+        wc.plan_want_geom[0] = g.win_origin; wc.plan_want_geom[1] = g.win_w;
+        wc.plan_want_valid = true;
     }
     if (call.chain_step) { // (predicted poses: 64 cells more each way; a negative margin, debug option 25, provokes faults)
         const int mg = m->chain_margin;
@@ -1495,11 +1547,20 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     mark(0);
     if ((rc = plan_sizes(m, slot, P))) return rc;
     mark(1);
-    if ((rc = plan_cache(m, slot, P))) return rc;
+    // a resident batch again, no scan moved, no cache slot changed hands, nothing was left to fill: last time's plan holds
+    Call &pc = slot.call;
+    const bool replay = pc.batch_uid != 0 && pc.plan_clean && pc.plan_gen == m->cache_gen && pc.pose_epoch == g_pose_epoch.load(std::memory_order_relaxed);
+    if (!replay && (rc = plan_cache(m, slot, P))) return rc;
     mark(2);
-    if ((rc = plan_jobs(m, slot, P))) return rc;
+    if ((rc = plan_jobs(m, slot, P, replay))) return rc;
     mark(3);
-    if ((rc = plan_descriptor(m, slot, P))) return rc;
+    if ((rc = plan_descriptor(m, slot, P, replay))) return rc;
+    if (pc.batch_uid != 0 && !replay) {
+        bool clean = !m->cache_off;
+        for (const CallScan &cs : pc.scans) clean = clean && !cs.stale && !cs.qstale;
+        pc.plan_clean = clean;
+        pc.plan_gen = m->cache_gen;
+    }
     mark(4);
     hipStream_t st = m->stream;
     hipEvent_t ev_call = nullptr;
@@ -1569,7 +1630,8 @@ int launch_call(ym_matcher *m, Slot &slot) {
         if (m->call_counter != before)
             for (ym_matcher::CacheEntry &ce : m->cache_entries)
                 if (ce.stale_in_call == m->call_counter) ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
-        slot.desc_shadow.clear();
+        slot.desc_live_bytes = 0;
+        slot.call.plan_clean = false;
         slot.in_flight = false;
     }
     return rc;
@@ -1944,6 +2006,7 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
 
 int ym_scan_set_pose(ym_scan *s, double x, double y, double heading) {
     if (!s) return set_err(YM_ERR_INVALID, "null scan");
+    g_pose_epoch.fetch_add(1, std::memory_order_relaxed);
     s->pose[0] = x; s->pose[1] = y; s->pose[2] = heading;
     world_bbox(s->lbox, s->pose, s->wbox);
     return YM_OK;
@@ -2225,7 +2288,9 @@ ym_batch *ym_batch_create(ym_matcher *m, const ym_scan *query, const ym_scan *co
     if (query->device != m->device) { set_err(YM_ERR_INVALID, "query scan lives on another device"); return nullptr; }
     for (int i = 0; i < n_scans; i++)
         if (!scans[i] || scans[i]->device != m->device) { set_err(YM_ERR_INVALID, "scan %d is null or lives on another device", i); return nullptr; }
+    static std::atomic<uint64_t> next_uid{1};
     ym_batch *b = new ym_batch();
+    b->uid = next_uid.fetch_add(1);
     b->query = query;
     b->scans.assign(scans, scans + n_scans);
     b->offsets.assign(chain_offsets, chain_offsets + n_chains + 1);
@@ -2244,27 +2309,39 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     if (slot.in_flight) return set_err(YM_ERR_BUSY, "slot %d still holds an uncollected call", slot_idx);
     const int n_chains = (int)b->offsets.size() - 1, n_scans = (int)b->scans.size();
     Call &call = slot.call;
-    call.scans.resize(1 + (size_t)n_scans);
-    int rc = scan_to_call(b->query, m->cfg.semantics, &call.scans[0]);
-    if (rc) return rc;
-    b->cache_hints.resize(n_scans, -1);
-    call.scans[0].qcache_hint = b->query_hint;
-    for (int i = 0; i < n_scans; i++) {
-        if ((rc = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
-        call.scans[1 + i].cache_hint = b->cache_hints[i];
+    const uint64_t epoch = g_pose_epoch.load(std::memory_order_relaxed);
+    // the slot still holds this batch's Call and no scan anywhere has moved since it was built: nothing to rebuild
+    // (40 961 scattered ym_scan objects are not even looked at; 1.7 ms per enqueue of 4096 chains otherwise)
+    const bool same = call.batch_uid == b->uid && call.pose_epoch == epoch && call.scans.size() == 1 + (size_t)n_scans &&
+                      call.penalize == (penalize ? 1 : 0) && call.refine == (refine ? 1 : 0) && !call.slice && !call.chain_step;
+    int rc;
+    if (!same) {
+        call = Call();
+        call.scans.resize(1 + (size_t)n_scans);
+        if ((rc = scan_to_call(b->query, m->cfg.semantics, &call.scans[0]))) return rc;
+        b->cache_hints.resize(n_scans, -1);
+        call.scans[0].qcache_hint = b->query_hint;
+        for (int i = 0; i < n_scans; i++) {
+            if ((rc = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[1 + i]))) return rc;
+            call.scans[1 + i].cache_hint = b->cache_hints[i];
+        }
+        call.items.resize(n_chains);
+        for (int c = 0; c < n_chains; c++) call.items[c] = CallItem{0, 1 + b->offsets[c], b->offsets[c + 1] - b->offsets[c]};
+        call.penalize = penalize ? 1 : 0;
+        call.refine = refine ? 1 : 0;
+        call.batch_uid = b->uid;
+        call.pose_epoch = epoch;
     }
-    call.items.resize(n_chains);
-    for (int c = 0; c < n_chains; c++) call.items[c] = CallItem{0, 1 + b->offsets[c], b->offsets[c + 1] - b->offsets[c]};
-    call.penalize = penalize ? 1 : 0;
-    call.refine = refine ? 1 : 0;
     call.coarse_angle_off = m->cfg.coarse_search_angle_offset;
     slot.chain_id_base = chain_id_base;
     slot.dev_best_out = dev_best_out;
     slot.dev_best_user = dev_best_out;
     rc = launch_call(m, slot);
     slot.dev_best_out = nullptr; // a response-expansion re-run must not overwrite the caller's buffer
-    for (int i = 0; i < n_scans; i++) b->cache_hints[i] = call.scans[1 + i].cache_hint;
-    b->query_hint = call.scans[0].qcache_hint;
+    if (!same) {
+        for (int i = 0; i < n_scans; i++) b->cache_hints[i] = call.scans[1 + i].cache_hint;
+        b->query_hint = call.scans[0].qcache_hint;
+    }
     return rc;
 }
 
@@ -2484,6 +2561,7 @@ int ym_match_map(ym_matcher *m, const ym_map *mp, double ox, double oy, const ym
     if ((rc = slot.desc.ensure(scans_bytes + sizeof(YmItemState)))) return rc;
     if ((rc = slot.result.ensure(sizeof(YmItemState)))) return rc;
     if ((rc = m->desc_dev.ensure(scans_bytes))) return rc;
+    slot.desc_live_bytes = 0; // (the slot's pinned descriptor buffer is rewritten here)
     YmScanRef *hs = reinterpret_cast<YmScanRef *>(slot.desc.p);
     std::memset(hs, 0, scans_bytes);
     for (int i = 0; i < n_queries; i++) {
@@ -2718,6 +2796,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
 }
 
 int ym_debug_option(ym_matcher *m, int option, int value) {
+    if (m) m->cache_gen++; // (whatever the option changes, no earlier plan is reused)
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
     if (option == 0) return set_err(YM_ERR_INVALID, "debug option 0 (an experimental correlate form) no longer exists");
     else if (option == 2) m->full_raster = value;
