@@ -11,3 +11,6 @@ for spec in "fetch:FETCH_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum" "tcp:TCP_TOTAL_CACH
   rocprofv3 --pmc $ctr --kernel-exclude-regex "rocclr|at::native" --output-format csv -d $out/${tag}_$name -o ${tag} -- python3 bench.py --only cfg2x --no-production-legs --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_$name.log
   ls -la $out/${tag}_$name
 done
+# the counter CSVs are too large to travel: summarise here, keep the summaries
+python3 scripts/summarise_profiles.py ${tag} ${2:-4096} $out/${tag}_summary > $out/${tag}_summary.log 2>&1
+find $out -name "*counter_collection.csv" -size +5M -delete

@@ -32,7 +32,9 @@ def kernel_means(tag, name):
 def main():
     tag, batch = sys.argv[1], int(sys.argv[2])
     short = tag[:3] + "_" + tag[3:] if len(tag) == 4 else tag
-    prof = os.path.join(REPO, "profiles")
+    # (on the GPU box the counter CSVs are hundreds of MB: summarise there into a directory under gpurun_out/ and copy that)
+    prof = os.path.join(REPO, sys.argv[3]) if len(sys.argv) > 3 else os.path.join(REPO, "profiles")
+    os.makedirs(prof, exist_ok=True)
     for src, dst in (("stats", "bench_kernel_stats"), ("single", "single_match_kernel_stats"), ("stress", "stress_kernel_stats")):
         f = os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, src), "%s_kernel_stats.csv" % tag)
         if os.path.exists(f):
@@ -86,7 +88,7 @@ def main():
     if dom:
         k, fz, h, m, ca, ta, iv, il, la, lc = dom[0]
         json.dump({"kernel": k, "batch": batch, "fetch_size_kib_per_launch": fz, "gfx950_wide_read_correction": 2.0,
-                   "hbm_bytes_per_launch": fz * 1024 * 2.0, "l2_hit_rate": h / max(h + m, 1.0), "source": os.path.relpath(pmc_csv, REPO)},
+                   "hbm_bytes_per_launch": fz * 1024 * 2.0, "l2_hit_rate": h / max(h + m, 1.0), "source": "profiles/" + os.path.basename(pmc_csv)},
                   open(os.path.join(prof, "traffic_correlate.json"), "w"), indent=1)
         dur = stats.get(k)
         if dur and "region" in k and iv:
@@ -101,7 +103,7 @@ def main():
                        "waves": sq2.get(k),
                        "lds": {"counter": "SQ_LDS_IDX_ACTIVE", "cycles_per_launch": la, "bank_conflict_cycles": lc,
                                "frac": la / (CU * clk), "peak_source": "LDS busy cycles / (256 CUs x kernel clocks)"},
-                       "source": os.path.relpath(pmc_csv, REPO)},
+                       "source": "profiles/" + os.path.basename(pmc_csv)},
                       open(os.path.join(prof, "issue_correlate.json"), "w"), indent=1)
         elif dur and ca:
             per_cu_clk = ca / (CU * dur * 1e-9 * CLOCK_HZ)
@@ -110,7 +112,7 @@ def main():
                        "peak_per_cu_clk": 1.0, "frac": per_cu_clk / 1.0,
                        "peak_source": "profiles/r02_ta_coalescing_experiment.md: one cache-line visit per clock per CU "
                                       "(64 lanes in 64 lines = 65 clk per wave load)",
-                       "source": os.path.relpath(pmc_csv, REPO)},
+                       "source": "profiles/" + os.path.basename(pmc_csv)},
                       open(os.path.join(prof, "l1_correlate.json"), "w"), indent=1)
     print(open(pmc_csv).read())
     for n in ("traffic_correlate.json", "issue_correlate.json"):
