@@ -201,17 +201,42 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[N], double *scratch /*
         v[j] = r;
     }
 }
+// The same when most threads hold exact zeros (`mine` = this thread's v is not all zero; tie sums: one thread, one tie,
+// nearly always).  With at most one contributor the sum IS its values -- x + 0.0 = x whatever the order -- so they are
+// handed around through LDS: two barriers, no reduction tree (1.4 -> 0.4 us on the critical path of every match).
+template <int N>
+__device__ __forceinline__ void block_sum_vec_sparse(double (&v)[N], double *scratch /* >= 16*N */, bool mine) {
+    const int contributors = __syncthreads_count(mine ? 1 : 0);
+    if (contributors > 1) { block_sum_vec<N>(v, scratch); return; }
+    if (mine)
+#pragma unroll
+        for (int j = 0; j < N; j++) scratch[j] = v[j];
+    __syncthreads();
+    if (contributors == 1)
+#pragma unroll
+        for (int j = 0; j < N; j++) v[j] = scratch[j];
+}
 
-// tie-set mean of CorrelateScan: accumulate one hypothesis
+// tie-set mean of CorrelateScan: accumulate one hypothesis.  trig[k] = (cos, sin) of the heading of lattice angle k
+// (tie_trig_table): a single lane computing an fp64 sin and cos AFTER the winner is known is a 1.3 us dependent chain
+// on the critical path of every match; computed for all angles by as many lanes at the start of the phase it hides behind
+// the loads of the block maxima.
 __device__ __forceinline__ void tie_accumulate(double (&acc)[5], const YmLattice &L, int h, double cxw, double cyw,
-                                               double start_angle) {
+                                               const double2 *trig) {
     const int nxy = L.nx * L.ny;
     const int k = h / nxy, c = h - k * nxy, iy = c / L.nx, ix = c - iy * L.nx;
     const double x = -L.off_x + ix * L.step_x, y = -L.off_y + iy * L.step_y;
-    const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
     acc[0] += cxw + x; acc[1] += cyw + y;
-    acc[2] += cos(hd); acc[3] += sin(hd);
+    acc[2] += trig[k].x; acc[3] += trig[k].y;
     acc[4] += 1.0;
+}
+// (a barrier must separate this from the first tie_accumulate)
+template <int NT>
+__device__ __forceinline__ void tie_trig_table(const YmLattice &L, double start_angle, double2 *trig) {
+    for (int k = threadIdx.x; k < L.nt; k += NT) {
+        const double hd = kt_normalize_angle(start_angle + k * L.angle_res);
+        trig[k] = make_double2(cos(hd), sin(hd));
+    }
 }
 
 // Coarse tail of CorrelateScan for one item: best response, mean of all hypotheses with
@@ -221,13 +246,19 @@ template <int NT>
 __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const double *resp, const double *bm,
                                                        int n_blocks, const double pose[3], double mean[3], int *status,
                                                        double *scratch /* >= 80 */, int *s_list /* NT */, int *s_tmp /* NT */,
-                                                       int *s_nlist) {
+                                                       int *s_nlist, double2 *s_trig /* L.nt */) {
     const int tid = threadIdx.x;
     const int nh = L.nx * L.ny * L.nt;
     const double start_angle = pose[2] - L.angle_off;
     if (tid == 0) *s_nlist = 0;
     double lb = -1.0;
-    for (int i0 = tid; i0 < n_blocks; i0 += 4 * NT) {
+    double v0[4]; // (the first round of block maxima is in flight while the table is computed)
+#pragma unroll
+    for (int u = 0; u < 4; u++) v0[u] = (tid + u * NT) < n_blocks ? bm[tid + u * NT] : -1.0;
+    tie_trig_table<NT>(L, start_angle, s_trig);
+#pragma unroll
+    for (int u = 0; u < 4; u++) lb = v0[u] > lb ? v0[u] : lb;
+    for (int i0 = tid + 4 * NT; i0 < n_blocks; i0 += 4 * NT) {
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = (i0 + u * NT) < n_blocks ? bm[i0 + u * NT] : -1.0;
@@ -245,7 +276,7 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
             if (at < NT) s_tmp[at] = i; else overflow = 1;
         }
     overflow = __syncthreads_or(overflow);
-    if (!overflow) {
+    if (!overflow && *s_nlist > 1) { // (block-uniform; one candidate block, the usual case, needs no order)
         const int n = *s_nlist;
         if (tid < n) {
             const int mine = s_tmp[tid];
@@ -259,19 +290,20 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
     if (tid < YM_CANON) {
         if (!overflow) {
             const int nlist = *s_nlist;
+            const int *list = nlist > 1 ? s_list : s_tmp;
             const int nxy = L.nx * L.ny, ncb = (nxy + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
             for (int w = tid; w < nlist * YM_SCORE_THREADS; w += YM_CANON) {
-                const int bid = s_list[w / YM_SCORE_THREADS]; // block = (angle k, block cb of cells)
+                const int bid = list[w / YM_SCORE_THREADS]; // block = (angle k, block cb of cells)
                 const int k = bid / ncb, c = (bid - k * ncb) * YM_SCORE_THREADS + (w % YM_SCORE_THREADS);
                 const int h = k * nxy + c;
-                if (c < nxy && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+                if (c < nxy && kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], s_trig);
             }
         } else {
             for (int h = tid; h < nh; h += YM_CANON)
-                if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], start_angle);
+                if (kt_double_equal(resp[h], best)) tie_accumulate(acc, L, h, pose[0], pose[1], s_trig);
         }
     }
-    block_sum_vec<5>(acc, scratch);
+    block_sum_vec_sparse<5>(acc, scratch, acc[4] != 0.0);
     if (acc[4] > 0.0) {
         const double cnt = acc[4]; // exact small integer, same value as Karto's int count
         mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
@@ -350,6 +382,7 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     __shared__ double s_cs[2];
     __shared__ int s_cx[64], s_cy[64];
     __shared__ unsigned s_sum[YM_MAX_FINE_HYP];
+    __shared__ double2 s_trig[YM_MAX_COARSE_NT];
     int k;
     const int b = xcd_item_of_block_2d(k); // the blocks of an item share its grid patch: keep them on one XCD
     const int tid = threadIdx.x, lane = tid & 63;
@@ -363,7 +396,7 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     int status = 0;
     const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride,
                                                  a.blockmax + (size_t)b * a.n_blocks, a.n_blocks, pose, mean, &status,
-                                                 scratch, s_list, s_tmp, &s_nlist);
+                                                 scratch, s_list, s_tmp, &s_nlist, s_trig);
     if (k == (a.refine ? a.lf.nt : 0)) { // extra block: coarse result + positional covariance for final_kernel
         double cov[9];
         positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
@@ -462,7 +495,10 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
     constexpr int NT = YM_FINISH_THREADS;
     __shared__ double scratch[16 * 5];
     __shared__ double s_fresp[YM_MAX_FINE_HYP];
+    __shared__ unsigned s_fsum[YM_MAX_FINE_HYP]; // the fine sums as loaded (the angular covariance reads one column of them)
     __shared__ unsigned s_asum[YM_MAX_FINE_NT];
+    __shared__ double2 s_trig[YM_MAX_FINE_NT];
+    __shared__ int s_hit[2];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63;
     YM_STAMP(a, 16);
@@ -504,19 +540,24 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
         const uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride;
         double lb = -1.0;
+        uint32_t f0 = tid < nh ? fs[tid] : 0u; // (in flight while the tie table is computed)
+        tie_trig_table<NT>(L, start_angle, s_trig);
         for (int h = tid; h < nh; h += NT) {
             const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
             const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-            const double r = hyp_response(a.g, L.penalize, fs[h], nq, x * x + y * y, start_angle + k * L.angle_res, ct);
+            const uint32_t fsum = h == tid ? f0 : fs[h];
+            const double r = hyp_response(a.g, L.penalize, fsum, nq, x * x + y * y, start_angle + k * L.angle_res, ct);
             s_fresp[h] = r;
+            s_fsum[h] = fsum;
             lb = r > lb ? r : lb;
         }
         for (int k = tid; k < nt; k += NT) s_asum[k] = 0u;
+        if (tid < 2) s_hit[tid] = -1;
         best = block_reduce(lb, OpMaxD(), -1.0, scratch);
         double acc[5] = {0, 0, 0, 0, 0};
         for (int h = tid; h < nh && tid < YM_CANON; h += YM_CANON)
-            if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
-        block_sum_vec<5>(acc, scratch);
+            if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, s_trig);
+        block_sum_vec_sparse<5>(acc, scratch, acc[4] != 0.0);
         if (acc[4] > 0.0) {
             const double cnt = acc[4];
             mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
@@ -531,17 +572,16 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         const int gy = world_to_grid(mean[1], off_y, a.g.scale) + a.g.border - a.g.win_origin;
         const int base = gy * lin_pitch(a.g) + gx;
         const int32_t *foff = a.foffsets + (size_t)b * a.nt_stride * a.max_n;
-        __syncthreads(); // s_asum cleared above
         // GetResponse(angle k, cell of the mean pose) uses the fine pass's own lookup offsets, so when that cell is one
         // of the fine lattice's cells (always, unless fp rounding puts the tie mean outside) the sum IS the fine
-        // pass's integer sum for (k, that cell): take it instead of gathering the scan again.
-        int hit_x = -1, hit_y = -1;
-        for (int i = 0; i < nx; i++)
-            if (hyp_cell(cxw, start_x, i, L.step_x, off_x, a.g) == gx) hit_x = i;
-        for (int i = 0; i < ny; i++)
-            if (hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g) == gy) hit_y = i;
+        // pass's integer sum for (k, that cell): take it instead of gathering the scan again.  Lattice column i is looked
+        // at by thread i, row i by thread 64 + i (the last match wins, as in a loop over i: the cells increase with i).
+        if (tid < nx && hyp_cell(cxw, start_x, tid, L.step_x, off_x, a.g) == gx) atomicMax(&s_hit[0], tid);
+        if (tid >= 64 && tid - 64 < ny && hyp_cell(cyw, start_y, tid - 64, L.step_y, off_y, a.g) == gy) atomicMax(&s_hit[1], tid - 64);
+        __syncthreads(); // s_asum cleared above, the hits in
+        const int hit_x = s_hit[0], hit_y = s_hit[1];
         if (hit_x >= 0 && hit_y >= 0) {
-            for (int k = tid; k < nt; k += NT) s_asum[k] = fs[(size_t)k * nxy + hit_y * nx + hit_x];
+            for (int k = tid; k < nt; k += NT) s_asum[k] = s_fsum[k * nxy + hit_y * nx + hit_x];
         } else {
             // work item = (angle, beam); beams padded to whole waves so that a wave shares one angle
             const int nq_pad = (nq + 63) & ~63;
@@ -591,7 +631,17 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         st.response = response;
         st.coarse_response = coarse_response;
         st.status = status;
-        if (a.host_out) a.host_out[b] = st;
+        if (a.host_out) {
+            // what the host reads of a result (state_to_result), straight from registers: copying `st` would first read
+            // the whole state back from device memory -- one more round trip at the very end of the chain
+            YmItemState *ho = a.host_out + b;
+            for (int i = 0; i < 9; i++) ho->cov[i] = cov[i];
+            for (int i = 0; i < 3; i++) { ho->mean[i] = mean[i]; ho->center[i] = mean[i]; }
+            ho->response = response;
+            ho->coarse_response = coarse_response;
+            ho->nq = nq;
+            ho->status = status;
+        }
         if (a.host_flag) { __threadfence_system(); *reinterpret_cast<volatile uint32_t *>(a.host_flag) = a.serial; }
         if (a.seq_pose) {
             if (status != 0 || (a.expansion && kt_double_equal(coarse_response, 0.0))) atomicCAS(a.fault, 0, a.step);
@@ -617,6 +667,7 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
     __shared__ int s_list[NT], s_tmp[NT];
     __shared__ int s_nlist;
     __shared__ double2 s_cs[YM_MAX_FINE_NT];
+    __shared__ double2 s_trig[YM_MAX_COARSE_NT > YM_MAX_FINE_NT ? YM_MAX_COARSE_NT : YM_MAX_FINE_NT]; // tie tables: coarse, then fine
     __shared__ int s_cx[64], s_cy[64];
     const int nh_fine = a.refine ? a.lf.nx * a.lf.ny * a.lf.nt : 0;
     double *s_fresp = reinterpret_cast<double *>(fin_lds);                      // [nh_fine]
@@ -642,7 +693,7 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
     double mean[3], cov[9];
     int status = 0;
     double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride, a.blockmax + (size_t)b * a.n_blocks,
-                                           a.n_blocks, pose, mean, &status, scratch, s_list, s_tmp, &s_nlist);
+                                           a.n_blocks, pose, mean, &status, scratch, s_list, s_tmp, &s_nlist, s_trig);
     positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
     const double coarse_response = best > 1.0 ? 1.0 : best;
     const double cmean[3] = {mean[0], mean[1], mean[2]};
@@ -659,6 +710,7 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
             const double angle = start_angle + k * L.angle_res;
             s_cs[k] = make_double2(cos(angle), sin(angle));
         }
+        tie_trig_table<NT>(L, start_angle, s_trig); // (the coarse table is done with: positional_covariance ends with barriers)
         for (int i = tid; i < nx; i += NT) s_cx[i] = hyp_cell(cxw, start_x, i, L.step_x, off_x, a.g);
         for (int i = tid; i < ny; i += NT) s_cy[i] = hyp_cell(cyw, start_y, i, L.step_y, off_y, a.g);
         for (int h = tid; h < nh; h += NT) s_sum[h] = 0u;
@@ -723,8 +775,8 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
         best = block_reduce(lb, OpMaxD(), -1.0, scratch);
         double acc[5] = {0, 0, 0, 0, 0};
         for (int h = tid; h < nh && tid < YM_CANON; h += YM_CANON)
-            if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, start_angle);
-        block_sum_vec<5>(acc, scratch);
+            if (kt_double_equal(s_fresp[h], best)) tie_accumulate(acc, L, h, cxw, cyw, s_trig);
+        block_sum_vec_sparse<5>(acc, scratch, acc[4] != 0.0);
         if (acc[4] > 0.0) {
             const double cnt = acc[4];
             mean[0] = acc[0] / cnt; mean[1] = acc[1] / cnt;
