@@ -335,6 +335,7 @@ struct ym_matcher {
     int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
     uint64_t cache_gen = 1;      // bumped whenever the point cache changes (entries created, re-posed, dropped) or an option is set
     int64_t seq_segments = 0, seq_faults = 0, seq_sync_steps = 0; // ym_map_sequence: chained segments, those cut short, synchronous steps
+    int prepare_threads = 0;     // development: 512 = the single-item prepare kernel with 512 threads per scan too
     int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
@@ -1255,7 +1256,12 @@ void enqueue_prepare(ym_matcher *m, const CallPlan &P) {
         if (P.n_jobs > 0) hipLaunchKernelGGL(ym::points_kernel, dim3(P.n_jobs), dim3(YM_POINTS_THREADS), lds, m->stream, a);
         hipLaunchKernelGGL(ym::cells_kernel, dim3(P.max_base + 1, P.B), dim3(256), 0, m->stream, a);
     } else {
-        hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(P.max_base + 1, P.B), dim3(512), lds, m->stream, a);
+        // (query, base scans, item).  One item: 1024 threads per scan -- a 1081-beam scan is then one pass of every phase
+        // plus a tail instead of three passes, and the blocks have the chip to themselves
+        if (P.B == 1 && m->prepare_threads != 512)
+            hipLaunchKernelGGL(ym::prepare_kernel<1024>, dim3(P.max_base + 2, P.B), dim3(1024), lds, m->stream, a);
+        else
+            hipLaunchKernelGGL(ym::prepare_kernel<512>, dim3(P.max_base + 2, P.B), dim3(512), lds, m->stream, a);
     }
 }
 
@@ -1885,6 +1891,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(ym::points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2814,6 +2822,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 23) m->poll_completion = value != 0;
     else if (option == 24) m->use_scan_structure = value != 0;
     else if (option == 25) m->chain_margin = value;
+    else if (option == 26) m->prepare_threads = value;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;

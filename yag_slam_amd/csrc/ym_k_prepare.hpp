@@ -228,6 +228,7 @@ __device__ __forceinline__ void store_query_local(const YmScanRef &sr, const Pre
 
 // everything of an item that depends on its query's pose and the lattice, but not on the query's readings:
 // state, (cos, sin) per coarse angle (GridIndexLookup::ComputeOffsets), hypothesis cells
+// (np < 0: the number of point readings is written by someone else -- prepare_kernel's query block)
 template <int NT>
 __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmItem &it, const YmScanRef &sr, int np, int qslot,
                                           const double2 *ql, double off_x, double off_y) {
@@ -238,7 +239,7 @@ __device__ __forceinline__ void init_item(const PrepareArgs &a, int b, const YmI
         st.center[0] = sr.pose[0]; st.center[1] = sr.pose[1]; st.center[2] = sr.pose[2];
         st.off_x = off_x;
         st.off_y = off_y;
-        st.nq = np;
+        if (np >= 0) st.nq = np;
         st.status = 0;
         st.regular[0] = st.regular[1] = 0;
         st.base_count = it.base_count;
@@ -399,8 +400,9 @@ __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, in
     }
 }
 
-// ---- K1, fused form (a few items): grid (max_base + 1, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).
-// blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain.  A base scan whose slot of
+// ---- K1, fused form (a few items): grid (max_base + 2, B), NT threads, dynamic LDS = YM_PREP_LDS_BYTES(max_n).
+// blockIdx.x == 0: the query scan; blockIdx.x == 1 + j: base scan j of the item's chain; the last block: the item's
+// state, coarse-angle table and hypothesis cells.  A base scan whose slot of
 // the point cache is current takes the short path; otherwise it is projected here (and its slot filled).
 template <int NT>
 __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
@@ -412,6 +414,18 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     const YmItem it = a.use_inline ? a.inl.item : a.items[b];
     const bool is_query = blockIdx.x == 0;
     const int slot = (int)blockIdx.x - 1;
+    if ((int)blockIdx.x == a.max_base + 1) {
+        // the item's block: everything that depends on the query's POSE and the lattice but not on its readings (state,
+        // (cos, sin) per coarse angle -- fp64 sin / cos on a handful of lanes is a 1.3 us chain --, hypothesis cells, the
+        // cleared maxima) runs beside the query's projection instead of after it
+        YmScanRef qr = a.use_inline ? a.inl.scans[it.query] : a.scans[it.query];
+        if (qr.pose_dev) { qr.pose[0] = qr.pose_dev[0]; qr.pose[1] = qr.pose_dev[1]; qr.pose[2] = qr.pose_dev[2]; }
+        const double off_x = qr.pose[0] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+        const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
+        init_item<NT>(a, b, it, qr, -1, b, a.qlocal + (size_t)b * a.max_n, off_x, off_y);
+        YM_STAMP_B1(a, 21);
+        return;
+    }
     if (!is_query && slot >= it.base_count) {
         clear_slot<NT>(a, b, slot);
         return;
@@ -443,9 +457,8 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     const double off_y = qr.pose[1] - (0.5 * (a.g.roi_w - 1) * a.g.res);
     if (is_query) {
         store_query_local<NT>(sr, l, np, yag, a.qlocal + (size_t)b * a.max_n);
-        if (threadIdx.x == 0) a.qnp[b] = np;
+        if (threadIdx.x == 0) { a.qnp[b] = np; a.states[b].nq = np; } // (the rest of the state: the item's block)
         YM_STAMP(a, 2);
-        init_item<NT>(a, b, it, sr, np, b, a.qlocal + (size_t)b * a.max_n, off_x, off_y);
         YM_STAMP(a, 18);
         return;
     }
