@@ -146,6 +146,13 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
 int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, int n, int start, int buffer_len,
                     int penalize, int refine, int device_chain, ym_result *results, int32_t *n_done);
 
+/* The same for ONE scan, for callers that receive their scans one at a time (GraphSlam.process_scan itself): prior =
+ * chain[n_chain-1]'s pose (+) (odom_query (-) odom_last), the query's pose is set to it, the match runs against `chain`,
+ * and the query's pose becomes the result's (it stays at the prior if result->status != 0).  Bit-identical to setting the
+ * prior with ym_scan_set_pose and calling ym_match_scans; it only saves the caller the arithmetic and two calls. */
+int ym_process_scan(ym_matcher *m, ym_scan *query, ym_scan *const *chain, int n_chain, const double *odom_last,
+                    const double *odom_query, int penalize, int refine, ym_result *result);
+
 /* counters of ym_map_sequence since ym_create: device-chained segments enqueued, segments a fault cut short, steps run
  * synchronously (all of them without device_chain) */
 int ym_sequence_stats(const ym_matcher *m, int64_t *segments, int64_t *faults, int64_t *sync_steps);

@@ -78,7 +78,22 @@ def test_process_scans_in_the_library_equals_the_per_scan_loop():
     _, ref_scans = synth.trajectory_scans(n + 1)
     _, lib_scans = synth.trajectory_scans(n + 1)
     ref = SequentialMapper(ScanMatcher())
-    ref_out = [ref.process_scan(s) for s in ref_scans[:n]]
+    ref_out = [ref.process_scan(s) for s in ref_scans[:n]]        # (ym_process_scan: one library call per scan)
+
+    class LongWay(object):                                         # any other plugin: prior, match_scan, pose in Python
+        def __init__(self):
+            self.m = ScanMatcher()
+
+        def match_scan(self, *a):
+            return self.m.match_scan(*a)
+    _, long_scans = synth.trajectory_scans(n + 1)
+    lw = SequentialMapper(LongWay())
+    long_out = [lw.process_scan(s) for s in long_scans[:n]]
+    for i in range(1, n):
+        a, b = ref_out[i], long_out[i]
+        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta, i
+        pa, pb = ref_scans[i].corrected_pose, long_scans[i].corrected_pose
+        assert (pa.x, pa.y, pa.euler[-1]) == (pb.x, pb.y, pb.euler[-1]), i
     lib = SequentialMapper(ScanMatcher())
     lib_out = lib.process_scans(lib_scans[:1]) + lib.process_scans(lib_scans[1:4])     # chain shorter than the buffer
     lib_out += [lib.process_scan(lib_scans[4])]                                        # mixed with the per-scan call

@@ -2136,6 +2136,25 @@ static int sequence_step_sync(ym_matcher *m, ym_scan *const *scans, const double
     return ym_scan_set_pose(scans[i], result->pose[0], result->pose[1], result->pose[2]);
 }
 
+// GraphSlam.process_scan's matcher work for ONE scan (graph_slam.py:320-337), for callers that get their scans one at a
+// time: prior = chain[n_chain - 1]'s pose (+) (odom_query (-) odom_last), match against the chain, pose := result.
+extern "C" int ym_process_scan(ym_matcher *m, ym_scan *query, ym_scan *const *chain, int n_chain, const double *odom_last,
+                               const double *odom_query, int penalize, int refine, ym_result *result) {
+    if (!m || !query || !chain || !odom_last || !odom_query || !result) return set_err(YM_ERR_INVALID, "null argument");
+    if (n_chain < 1) return set_err(YM_ERR_INVALID, "process_scan needs at least one scan to match against");
+    for (int i = 0; i < n_chain; i++)
+        if (!chain[i]) return set_err(YM_ERR_INVALID, "null scan %d", i);
+    double inv[3], diff[3], prior[3];
+    tf_inverse(odom_last, inv);
+    tf_compose(inv, odom_query, diff);
+    tf_compose(chain[n_chain - 1]->pose, diff, prior);
+    int rc = ym_scan_set_pose(query, prior[0], prior[1], prior[2]);
+    if (rc) return rc;
+    if ((rc = ym_match_scans(m, query, chain, n_chain, penalize, refine, result))) return rc;
+    if (result->status != 0) return YM_OK;
+    return ym_scan_set_pose(query, result->pose[0], result->pose[1], result->pose[2]);
+}
+
 // Steps [lo, hi) of ym_map_sequence enqueued back to back, no host round trip between them: step i's final_kernel leaves
 // scan i's pose and scan i + 1's odometry prior on the device (seq_pose), the kernels of step i + 1 read them from there
 // (YmScanRef::pose_dev), and the host -- which plans step i + 1 before step i has run -- sizes the raster from poses it

@@ -26,10 +26,13 @@ class SequentialMapper(object):
             return None
         last_scan = self.running_scans[-1]
         query.num = last_scan.num + 1
-        odom_diff = query.odom_pose - last_scan.odom_pose
-        query.corrected_pose = last_scan.corrected_pose + odom_diff
-        res = self.seq_matcher.match_scan(query, self.running_scans, True, True)
-        query.corrected_pose = res.best_pose
+        fast = getattr(self.seq_matcher, "process_scan", None)
+        res = fast(query, self.running_scans, True, True) if fast is not None else None
+        if res is None:  # (any matcher plugin: the three steps of graph_slam.py:320-327)
+            odom_diff = query.odom_pose - last_scan.odom_pose
+            query.corrected_pose = last_scan.corrected_pose + odom_diff
+            res = self.seq_matcher.match_scan(query, self.running_scans, True, True)
+            query.corrected_pose = res.best_pose
         self.running_scans.append(query)
         self.running_scans = self.running_scans[-self.scan_buffer_len:]
         self.results.append(res)

@@ -180,6 +180,35 @@ class ScanMatcher(object):
                                 "range (scan %d of the sequence)" % done.value)
         return res
 
+    def process_scan(self, query, chain, penalty=True, do_fine=True):
+        """`GraphSlam.process_scan`'s matcher work for one scan in one library call (`ym_process_scan`): the odometry
+        prior from `chain[-1]` and the two `odom_pose`s, the match, `query.corrected_pose` = the result.  Resident scans
+        only (returns None otherwise: the caller does it the long way).  Same bits as the three separate steps."""
+        dev = self.device
+        scans = (query, *chain)
+        for s in scans:
+            if type(s) is not LocalizedRangeScan or s._native is None or s._native_device != dev:
+                if not isinstance(s, LocalizedRangeScan):
+                    return None
+                s.native(dev)
+        n = len(chain)
+        arr = (C.c_void_p * n)(*[s._native for s in chain])
+        lo, qo = chain[-1].odom_pose, query.odom_pose
+        a = (C.c_double * 3)(lo.x, lo.y, lo.euler[-1])
+        b = (C.c_double * 3)(qo.x, qo.y, qo.euler[-1])
+        res = _capi.YmResult()
+        rc = self._lib.ym_process_scan(self._m, query._native, arr, n, a, b, 1 if penalty else 0, 1 if do_fine else 0, C.byref(res))
+        if rc:
+            _capi.check(rc)
+        pose = (C.c_double * 3)()
+        if res.status != 0:
+            _capi.check(self._lib.ym_scan_get_pose(query._native, pose))
+            query._corrected_pose = Transform(pose[0], pose[1], 0.0, pose[2])  # (the prior, where the long way leaves it)
+            raise _capi.YmError(res.status, "Mapper FATAL ERROR - unable to find best position / index out of range")
+        r = _result(res)
+        query._corrected_pose = r.best_pose  # (the device twin already has it)
+        return r
+
     def sequence_stats(self):
         """(device-chained segments, segments cut short by a fault, synchronous steps) of map_sequence so far"""
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
