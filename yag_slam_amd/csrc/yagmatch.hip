@@ -877,7 +877,8 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
         s.cache = s.qcache = nullptr;
         s.stale = s.qstale = 0;
         // the scan's creation-time structure holds at this pose (ym_k_prepare.hpp, structure_kernel)
-        s.direct = m->use_scan_structure && s.gov && s.cidx && std::fabs(s.pose[0]) < YM_CHAIN_POSE_LIMIT && std::fabs(s.pose[1]) < YM_CHAIN_POSE_LIMIT;
+        s.direct = m->use_scan_structure && s.gov && s.cidx && std::fabs(s.pose[0]) < YM_CHAIN_POSE_LIMIT && std::fabs(s.pose[1]) < YM_CHAIN_POSE_LIMIT &&
+                   std::fabs(s.pose[2]) < YM_CHAIN_HEADING_LIMIT;
     }
     if (m->cache_off) return YM_OK;
     const uint64_t this_call = ++m->call_counter;
@@ -2249,7 +2250,8 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
             auto trusted = [&](int j) { return scans[j]->id != 0 && scans[j]->n > 0 && scans[j]->gov_ok[sem] && m->use_scan_structure; };
             int hi = std::min(n, i + seg_len);
             // (the structure is trusted within YM_CHAIN_POSE_LIMIT of the origin: stay well inside with predicted poses)
-            bool chain_ok = std::fabs(scans[i - 1]->pose[0]) < 0.9 * YM_CHAIN_POSE_LIMIT && std::fabs(scans[i - 1]->pose[1]) < 0.9 * YM_CHAIN_POSE_LIMIT;
+            bool chain_ok = std::fabs(scans[i - 1]->pose[0]) < 0.9 * YM_CHAIN_POSE_LIMIT && std::fabs(scans[i - 1]->pose[1]) < 0.9 * YM_CHAIN_POSE_LIMIT &&
+                            std::fabs(scans[i - 1]->pose[2]) < 0.9 * YM_CHAIN_HEADING_LIMIT;
             for (int j = std::max(0, i - buffer_len); j < i; j++) chain_ok = chain_ok && trusted(j);
             for (int j = i; j < hi; j++)
                 if (!trusted(j)) { hi = j; break; }

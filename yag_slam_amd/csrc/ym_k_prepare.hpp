@@ -139,10 +139,12 @@ __device__ __forceinline__ int project_points_indexed(const YmScanRef &sr, doubl
 // (3) one thread per entered segment marks the chain nodes inside it.
 // GUARD: also report (block-wide) whether any distance test came within YM_CHAIN_GUARD of the threshold.  The chain is a
 // function of those tests' outcomes alone; squared distances between the same two readings computed at two different
-// poses differ by rounding only (< 1e-12 m^2 for poses within 10 km: coordinates below 2^14 m carry errors below 4e-12 m,
-// distances are at most 0.2 m), so a scan without a near test has the SAME chain at every such pose.
+// poses differ by rounding only (< 1e-11 m^2 for poses within 10 km and headings within 1000 rad: coordinates below 2^14 m
+// carry errors below 4e-12 m, distances are at most 0.2 m), so a scan without a near test has the SAME chain at every
+// such pose.
 #define YM_CHAIN_GUARD 1e-9
 #define YM_CHAIN_POSE_LIMIT 1.0e4
+#define YM_CHAIN_HEADING_LIMIT 1.0e3 // (a heading of 1000 rad costs a beam angle 1e-13 rad of rounding: 3e-12 m at 30 m)
 template <int NT, bool GUARD = false>
 __device__ __forceinline__ int mark_chain(const PrepLds &l, int np, bool yag) {
     const int tid = threadIdx.x;
