@@ -103,10 +103,12 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         if (hn > 256) hn = -1; // (more than the list holds: scan)
     }
     if (tid == 0) s_nhits = hn >= 0 ? hn : 0;
+    int4 bb_first = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN); // this thread's first box: kept for the second pass
     if (!listed) { // decide "no box at all" before touching LDS
         int my_hits = 0;
         for (int c = tid; c < n_boxes; c += NT) {
             const int4 bb = bbox[c];
+            if (c == tid) bb_first = bb;
             my_hits += (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) ? 1 : 0;
         }
         if (__syncthreads_or(my_hits) == 0) {
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         }
     } else
     for (int c = tid; c < n_boxes; c += NT) {
-        const int4 bb = bbox[c];
+        const int4 bb = (!listed && c == tid) ? bb_first : bbox[c]; // (a single match: 170 boxes, one per thread, no second load)
         if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
             const int at = atomicAdd(&s_nhits, 1);
             if (at < 256) { // the chunk's first cell and how many it holds (the division once per hit, not per cell)
