@@ -946,7 +946,12 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
     angles of an item shared out over 1, 2, 3 and 21 blocks (option 17), 1 to 4 angles per wave (15), regions cut into chunks
     of 64 units (19), an LDS budget that makes the regions small (20), its per-cell kernel."""
     from oracle import oracle as orc
-    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.scan_matching import ScanMatcher as _ScanMatcher
+
+    def ScanMatcher(*args, **kw):  # (the LDS correlates from 8 chains on, as production takes them from 64)
+        m_ = _ScanMatcher(*args, **kw)
+        m_.debug_option(28, 8)
+        return m_
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     cut = lambda s, n: PlainScan(s.ranges[:n], s.min_angle, s.angle_increment, s.min_range, 20.0, (3.0, 3.0, 0.0))
@@ -1039,7 +1044,12 @@ def test_region_correlate_lattice_widths(nx):
     """The gather correlate gives a lane 16 x-adjacent hypotheses of one lattice row, a wave up to 32 rows of two such
     segments; lattices past 32 rows or two segments take two or three waves per angle: every shape from one short lane to
     three full segments over 47 rows, sums against the direct kernel, results against single calls."""
-    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.scan_matching import ScanMatcher as _ScanMatcher
+
+    def ScanMatcher(*args, **kw):  # (the LDS correlates from 8 chains on, as production takes them from 64)
+        m_ = _ScanMatcher(*args, **kw)
+        m_.debug_option(28, 8)
+        return m_
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     cfg = {"search_size": (nx - 1) * 0.02, "coarse_search_angle_offset": 0.07 if (nx < 13 or nx > 33) else 0.349}
@@ -1069,7 +1079,12 @@ def test_region_correlate_on_the_loop_config_with_multiplicities():
     against the direct kernel with and without its own run merging, against the oracle, and with the gather's work forced
     into other shapes; a short-range query (runs of 10+ beams per cell) as well."""
     from oracle import oracle as orc
-    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.scan_matching import ScanMatcher as _ScanMatcher
+
+    def ScanMatcher(*args, **kw):  # (the LDS correlates from 8 chains on, as production takes them from 64)
+        m_ = _ScanMatcher(*args, **kw)
+        m_.debug_option(28, 8)
+        return m_
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     near = PlainScan(np.minimum(q.ranges, 0.6), q.min_angle, q.angle_increment, q.min_range, 20.0, (3.0, 3.0, 0.0))

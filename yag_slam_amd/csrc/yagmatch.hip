@@ -335,6 +335,10 @@ struct ym_matcher {
     int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
     uint64_t cache_gen = 1;      // bumped whenever the point cache changes (entries created, re-posed, dropped) or an option is set
     int64_t seq_segments = 0, seq_faults = 0, seq_sync_steps = 0; // ym_map_sequence: chained segments, those cut short, synchronous steps
+    // Batches below this size take the direct correlate kernel: a block of either LDS correlate walks all regions of its item,
+    // ~190 us whatever the batch, while the direct kernel's time grows with the batch from ~15 us (measured, both lattices:
+    // 8 chains 142 / 109 us against 220 / 225 per enqueue, 64 chains equal, 256 chains 675 / 759 against 485 / 452)
+    int lds_min_batch = 64;
     int prepare_threads = 0;     // development: 512 = the single-item prepare kernel with 512 threads per scan too
     int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
@@ -721,7 +725,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : 8;
         if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
         P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
-        P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
+        P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
                      lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         if (P.region26) {
             P.n_groups = P.rg_ng;
@@ -732,7 +736,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         }
     }
     // Other batches on lattices of at most 48 x 64: the general form (ym_k_gather.hpp).
-    P.region = !wrap && !P.region26 && !yag && !call.slice && P.sx == 2 && B >= 8 && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
+    P.region = !wrap && !P.region26 && !yag && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
     if (P.region) {
         // lanes: a lane owns 16 x-adjacent hypotheses of one lattice row; a group of 32 lanes = up to 32 rows of one
         // segment (conflict-free LDS reads), or the rows past 32 of several segments; a wave = two groups
@@ -2844,6 +2848,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 24) m->use_scan_structure = value != 0;
     else if (option == 25) m->chain_margin = value;
     else if (option == 26) m->prepare_threads = value;
+    else if (option == 28) m->lds_min_batch = std::max(8, value);
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
