@@ -15,6 +15,11 @@ def chains_of(B):
         out.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
     return out
 loop = "loop" in sys.argv
+ALT = [(14, 1)]
+for v in list(sys.argv):
+    if v.startswith("alt="):
+        ALT = [tuple(int(x) for x in kv.split(":")) for kv in v[4:].split(",")]
+        sys.argv.remove(v)
 pen, fine = (False, False) if loop else (True, True)
 for B in [int(v) for v in sys.argv[1:] if v != "loop"] or [8, 16, 32, 64, 128, 256]:
     chains = chains_of(B)
@@ -22,7 +27,8 @@ for B in [int(v) for v in sys.argv[1:] if v != "loop"] or [8, 16, 32, 64, 128, 2
     for opt in (0, 1):
         m = ScanMatcher(None, loop=loop)
         if opt:
-            m.debug_option(14, 1)
+            for o_, v_ in ALT:
+                m.debug_option(o_, v_)
         b = m.make_batch(q, chains)
         for _ in range(3):
             b.run_async(pen, fine, slot=0); b.wait(0, per_chain=False)
@@ -36,4 +42,4 @@ for B in [int(v) for v in sys.argv[1:] if v != "loop"] or [8, 16, 32, 64, 128, 2
         wall = (time.perf_counter() - t) / 10
         row.append((ms / k * 1e3, wall * 1e6))
         m.close()
-    print("B %4d: default %.0f us GPU (%.0f wall) | direct kernel %.0f us GPU (%.0f wall)" % (B, row[0][0], row[0][1], row[1][0], row[1][1]))
+    print("B %4d: default %.0f us GPU (%.0f wall) | alternative %.0f us GPU (%.0f wall)" % (B, row[0][0], row[0][1], row[1][0], row[1][1]))

@@ -1019,7 +1019,7 @@ def test_raster_grid_shorter_than_the_tile_list():
     from yag_slam_amd.scan_matching import ScanMatcher
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
-    chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:], nb[5:6]]
+    chains = [nb, nb[:3], nb[2:9], nb[::-1], nb[4:5], nb[1:], nb[:7], nb[3:], nb[5:6]] * 6  # (tile lists: from 48 items on)
     ref = None
     for gx, hits in ((0, 0), (0, 0), (1, 0), (7, 0), (40, 0), (0, -1), (0, 1), (0, 4)):
         # (hits: room in the per-tile lists of chunk boxes the tiles kernel builds, option 18; -1 = none, 1 and 4 per tile =

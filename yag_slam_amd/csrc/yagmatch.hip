@@ -1216,8 +1216,10 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
         if (P.ltx <= 0 || P.lty <= 0) { P.cell_box[0] = P.cell_box[1] = INT32_MAX; P.cell_box[2] = P.cell_box[3] = INT32_MIN; } // nothing launched
     }
     P.tile_cap = std::max(1, P.ltx * P.lty);
-    // a work list pays for its extra launch from a handful of items on (raster 210 -> 159 us on 256 items)
-    P.use_tile_list = B >= 8 && P.ltx * P.lty > 0 && tiles_x * tiles_y < 32768;
+    // a work list pays for its extra launch once the items are many
+    // (from 48 items on: 256 items 210 -> 159 us, but 8 items 93 us per enqueue with the list against 80 without, 32 items
+    //  148 / 144, 64 items 241 / 247)
+    P.use_tile_list = B >= 48 && P.ltx * P.lty > 0 && tiles_x * tiles_y < 32768;
     if (P.use_tile_list) {
         if ((rc = m->tile_list.ensure((size_t)B * P.tile_cap))) return rc;
         if ((rc = m->tile_count.ensure(B))) return rc;
@@ -1505,7 +1507,10 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     a.k_begin = P.k_begin; a.k_end = P.k_end; a.lane_layout = P.region26 ? 1 : 0;
     a.write_blockmax = slot.call.slice ? 0 : 1; // a slice's maxima are recomputed once the volume is whole
     if (P.region || P.fuse_score) return; // the LDS correlates score their sums themselves
-    if (P.B >= 8) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
+    // (a thread of score_kernel walks all angles of its cell: fine when the batch fills the chip, 36 us on 8 items, where
+    //  one thread per hypothesis takes 5)
+    //  (score_kernel also is the one that reads the region correlate's lane-ordered sums)
+    if (P.B >= 64 || P.region26) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
     else if (P.k_end > P.k_begin)
         hipLaunchKernelGGL(ym::score_hyp_kernel, dim3(P.cell_blocks, P.k_end - P.k_begin, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
 }
@@ -1531,7 +1536,9 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
         a.expansion = (m->cfg.semantics == YM_SEM_KARTO && m->cfg.use_response_expansion) ? 1 : 0;
     }
     slot.poll_serial = 0;
-    if ((P.B >= 8 && m->finish_form != 1) || m->finish_form == 2) {
+    // (one block per item from 128 items on; below, a block per fine angle and item is faster: 8 items 124 against 142 us per
+    //  enqueue, 64 items 241 against 254, 128 equal, 256 items 506 against 482)
+    if ((P.B >= 128 && m->finish_form != 1) || m->finish_form == 2) {
         const size_t lds = YM_FINISH_LDS_BYTES(call.refine ? (size_t)lf.nx * lf.ny * lf.nt : 0);
         const bool small_blocks = m->finish_threads ? m->finish_threads == 256 : P.B >= 512;
         if (small_blocks) hipLaunchKernelGGL(ym::finish_kernel<256>, dim3(P.B), dim3(256), lds, st, a);
