@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyagmatch.so")
+LIB_PATH = os.environ.get("YM_LIB_PATH") or os.path.join(_HERE, "libyagmatch.so")  # (the override: A/B timing of two builds)
 
 YM_OK = 0
 SEM = {"karto": 0, "yagpy": 1}

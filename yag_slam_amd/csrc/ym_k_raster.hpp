@@ -282,13 +282,11 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         us2 mn2[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
-        unsigned long long m = (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask; // bit t: halo row y + t, dy = t - h
-        while (m) {
-            const int t = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
+        const unsigned long long m64 = (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask; // bit t: halo row y + t, dy = t - h
+        auto tap = [&](int t) {
             const int dy = t - h;
             const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + t) * TW + x8]);
-            const unsigned short d2 = (unsigned short)(dy * dy);
+            const unsigned short d2 = (unsigned short)__mul24(dy, dy); // (v_mul_i32_i24: full rate; a 32-bit multiply issues at a quarter)
             const us2 dd = (us2){d2, d2};
             const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
 #pragma unroll
@@ -296,6 +294,21 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                 us2 gq;
                 __builtin_memcpy(&gq, &u[q], 4);
                 mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 (none) is larger than any real distance
+            }
+        };
+        if (2 * h + 1 <= 32) { // (block-uniform; the usual kernels: the tap mask is a 32-bit word, its scan half the instructions)
+            unsigned m = (unsigned)m64;
+            while (m) {
+                const int t = __ffs((int)m) - 1;
+                m &= m - 1u;
+                tap(t);
+            }
+        } else {
+            unsigned long long m = m64;
+            while (m) {
+                const int t = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                tap(t);
             }
         }
         unsigned mn[8];
