@@ -76,10 +76,13 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     const size_t plane_bytes = (size_t)(a.g.pitch / 2) * a.g.win_w;
     uint8_t *planes = a.planes + (size_t)bi * a.grid_stride;
     // the window row-major and its even / odd column planes (v_perm_b32 byte gathers) for 8 cells of tile row y
+    // (offsets inside an item's window as 32-bit numbers -- the host refuses windows beyond 2 GB --: a 64-bit multiply-add per
+    //  address issues at a quarter of the rate)
     auto store8 = [&](int y, uint32_t p0, uint32_t p1) {
         if (ty0 + y < a.g.win_w) {
-            *reinterpret_cast<uint2 *>(grid + (size_t)(ty0 + y) * a.g.pitch + tx0 + x8) = make_uint2(p0, p1);
-            uint8_t *pl = planes + (size_t)(ty0 + y) * (a.g.pitch / 2) + (tx0 + x8) / 2;
+            const uint32_t row = (uint32_t)(ty0 + y), col = (uint32_t)(tx0 + x8);
+            *reinterpret_cast<uint2 *>(grid + (row * (uint32_t)a.g.pitch + col)) = make_uint2(p0, p1);
+            uint8_t *pl = planes + (row * (uint32_t)(a.g.pitch / 2) + col / 2u);
             *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
             *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
         }
@@ -283,6 +286,10 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
         const unsigned long long m64 = (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask; // bit t: halo row y + t, dy = t - h
+        if (m64 == 0ull) { // no wall in reach of these eight cells (whole waves of a tile are like that)
+            store8(y, 0u, 0u);
+            continue;
+        }
         auto tap = [&](int t) {
             const int dy = t - h;
             const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + t) * TW + x8]);
@@ -311,15 +318,16 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                 tap(t);
             }
         }
+        // (lut[max_d2 + 1] = 0: anything farther is clamped to that index, two cells per v_pk_min_u16, no branch per cell)
+        const unsigned short cap = (unsigned short)(max_d2 + 1u);
+#pragma unroll
+        for (int q = 0; q < 4; q++) mn2[q] = __builtin_elementwise_min(mn2[q], (us2){cap, cap});
         unsigned mn[8];
         mn[0] = mn2[0].x; mn[2] = mn2[0].y; mn[1] = mn2[1].x; mn[3] = mn2[1].y;
         mn[4] = mn2[2].x; mn[6] = mn2[2].y; mn[5] = mn2[3].x; mn[7] = mn2[3].y;
         uint32_t packed[2] = {0u, 0u};
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const unsigned v = lut[mn[q] <= max_d2 ? mn[q] : max_d2 + 1u]; // (lut[max_d2 + 1] = 0: no branch per cell)
-            packed[q >> 2] |= v << (8 * (q & 3));
-        }
+        for (int q = 0; q < 8; q++) packed[q >> 2] |= (uint32_t)lut[mn[q]] << (8 * (q & 3));
         store8(y, packed[0], packed[1]);
     }
     YM_STAMP(a, 7);
