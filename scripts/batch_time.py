@@ -9,7 +9,7 @@ from yag_slam_amd.scan_matching import ScanMatcher
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 loop = len(sys.argv) > 2 and sys.argv[2] == "loop"
 q, base = cfg2_scans()
-m = ScanMatcher(None, loop=loop)
+m = ScanMatcher({"use_response_expansion": False} if os.environ.get("YM_NO_EXPANSION") else None, loop=loop)
 nq, nb = _mk_native(q), [_mk_native(b) for b in base]
 chains = [nb for _ in range(B)]
 pen, fine = (False, False) if loop else (True, True)
