@@ -643,9 +643,8 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     int wh = (int)std::ceil(reach / g.res) + 3;
     // (in steps of 64 cells: the window -- and with it the "this tile is zero" knowledge about its memory -- then stays
     //  the same from match to match while the queries' longest readings differ by less)
-    static const bool no_quant = getenv("YM_NO_WINDOW_QUANTUM") != nullptr; // (development)
-    if (!no_quant) wh = (wh + 63) / 64 * 64;
-    if (!no_quant && m->last_wh >= wh && m->last_wh - wh <= 256) wh = m->last_wh; // (and not smaller again at once: a window up to 256 cells too wide stays)
+    wh = (wh + 63) / 64 * 64;
+    if (m->last_wh >= wh && m->last_wh - wh <= 256) wh = m->last_wh; // (and not smaller again at once: a window up to 256 cells too wide stays)
     m->last_wh = wh;
     wh = wrap ? centre : std::min(wh, centre);
     g.win_origin = centre - wh;
