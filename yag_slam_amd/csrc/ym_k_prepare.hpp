@@ -342,7 +342,7 @@ __device__ __forceinline__ void clear_slot(const PrepareArgs &a, int b, int slot
 // waits three round trips per Q * NT points instead of three per NT.
 template <int NT>
 __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, int slot, const YmScanRef &sr, const YmScanRef &qr, bool yag) {
-    constexpr int Q = 4;
+    constexpr int Q = NT == 256 ? 3 : 4; // (cells_kernel, measured: Q = 4 398 us per 4096 items at 86 VGPRs, Q = 3 326 at 72, Q = 2 360 at 58)
     const double2 *__restrict__ cpts = reinterpret_cast<const double2 *>(sr.cache + YM_CACHE_HEADER);
     const int2 *__restrict__ cgov = reinterpret_cast<const int2 *>(sr.cache + YM_CACHE_HEADER + (size_t)sr.n * 16);
     const int np = *reinterpret_cast<const int *>(sr.cache);
