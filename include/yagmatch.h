@@ -116,6 +116,9 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *desc);
 int ym_scan_set_pose(ym_scan *s, double x, double y, double heading);
 int ym_scan_get_pose(const ym_scan *s, double pose[3]);
 int ym_scan_size(const ym_scan *s);
+/* 1: the scan's trigger-chain structure, computed once at creation in the sensor frame, holds at every pose (no distance
+ * test of the valid-point filter came within 1e-9 m^2 of its threshold); 0: the matchers recompute it per pose */
+int ym_scan_structure_trusted(const ym_scan *s, int semantics);
 void ym_scan_destroy(ym_scan *s);
 
 /* ---- the hot path ---- */

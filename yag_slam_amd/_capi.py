@@ -16,7 +16,7 @@ SEM = {"karto": 0, "yagpy": 1}
 EXPORTS = (
     "ym_version", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
     "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scan_get_pose",
-    "ym_scan_size", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_map_sequence", "ym_process_scan", "ym_sequence_stats", "ym_async_slots",
+    "ym_scan_size", "ym_scan_structure_trusted", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_map_sequence", "ym_process_scan", "ym_sequence_stats", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
     "ym_batch_run_async", "ym_batch_wait", "ym_debug_grid_info",
     "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_option", "ym_debug_stamps",
@@ -178,6 +178,7 @@ def lib():
     L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]
     L.ym_cache_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ym_coarse_dims.argtypes = [vp, ip]
+    L.ym_scan_structure_trusted.argtypes = [vp, C.c_int]
     L.ym_process_scan.argtypes = [vp, vp, C.POINTER(vp), C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(YmResult)]
     L.ym_sequence_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ym_map_sequence.argtypes = [vp, C.POINTER(vp), dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YmResult), ip]

@@ -2039,6 +2039,11 @@ int ym_scan_get_pose(const ym_scan *s, double pose[3]) {
 
 int ym_scan_size(const ym_scan *s) { return s ? s->n : YM_ERR_INVALID; }
 
+int ym_scan_structure_trusted(const ym_scan *s, int semantics) {
+    if (!s) return set_err(YM_ERR_INVALID, "null scan");
+    return s->gov_ok[semantics == YM_SEM_YAGPY ? 1 : 0] ? 1 : 0;
+}
+
 void ym_scan_destroy(ym_scan *s) {
     if (!s) return;
     DevGuard guard(s->device);
