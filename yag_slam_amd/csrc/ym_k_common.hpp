@@ -103,6 +103,15 @@ __device__ __forceinline__ int half_wave_reduce(int v, Op op) {
     const int hi = op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
     return (threadIdx.x & 32) ? hi : lo;
 }
+// the same over each row of 16 lanes (min / max: the rotations visit every lane of the row)
+template <typename Op>
+__device__ __forceinline__ int row16_reduce(int v, Op op) {
+    v = op(v, dpp_i32<YM_DPP_QUAD_1032>(v));
+    v = op(v, dpp_i32<YM_DPP_QUAD_2301>(v));
+    v = op(v, dpp_i32<YM_DPP_ROW_ROR4>(v));
+    v = op(v, dpp_i32<YM_DPP_ROW_ROR8>(v));
+    return v;
+}
 template <typename Op>
 __device__ __forceinline__ unsigned wave_reduce(unsigned v, Op op) {
     struct Wrap { Op op; __device__ int operator()(int a, int b) const { return (int)op((unsigned)a, (unsigned)b); } };
@@ -173,7 +182,7 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 // raster tile (also used by prepare_kernel, which builds the raster's work list)
 // cells per chunk box (consecutive readings of one base scan whose window bounding box the raster tests against its tile):
 // 32 = half a wave.  (64 listed a third more tiles than hold a cell in reach and loaded 11 x 64 cells per tile.)
-#define YM_BOX_CELLS 32
+#define YM_BOX_CELLS 16
 #define YM_N_BOXES(n) (((n) + YM_BOX_CELLS - 1) / YM_BOX_CELLS)
 #define YM_TILE_W 64
 #define YM_TILE_H 32

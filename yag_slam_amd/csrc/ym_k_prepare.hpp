@@ -288,7 +288,7 @@ __device__ __forceinline__ void prepare_cells(const PrepareArgs &a, int b, int s
     int2 *cells = a.cells + ((size_t)b * a.max_base + slot) * a.max_n;
     int4 *bbox = a.bbox + ((size_t)b * a.max_base + slot) * n_cchunks;
     for (int i0 = 0; i0 < n_cchunks * YM_BOX_CELLS; i0 += NT) {
-        const int i = i0 + tid; // half a wave covers one chunk of YM_BOX_CELLS cells
+        const int i = i0 + tid; // a row of 16 lanes covers one chunk of YM_BOX_CELLS cells
         int2 c = make_int2(YM_CELL_NONE, YM_CELL_NONE);
         if (i < np) {
             bool keep = false;
@@ -321,8 +321,8 @@ __device__ __forceinline__ void prepare_cells(const PrepareArgs &a, int b, int s
         // bounding box of the chunk's rasterised cells: the raster kernel reads a chunk only when
         // this box touches its tile
         const bool has = c.x != YM_CELL_NONE;
-        const int x0 = half_wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = half_wave_reduce(has ? c.y : INT32_MAX, OpMinI());
-        const int x1 = half_wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = half_wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+        const int x0 = row16_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = row16_reduce(has ? c.y : INT32_MAX, OpMinI());
+        const int x1 = row16_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = row16_reduce(has ? c.y : INT32_MIN, OpMaxI());
         if ((tid & (YM_BOX_CELLS - 1)) == 0 && i / YM_BOX_CELLS < n_cchunks) bbox[i / YM_BOX_CELLS] = make_int4(x0, y0, x1, y1);
     }
 }
@@ -395,8 +395,8 @@ __device__ __forceinline__ void cells_from_cache(const PrepareArgs &a, int b, in
             if (i < a.max_n) cells[i] = c;
             chain_check_cell(a, c);
             const bool has = c.x != YM_CELL_NONE;
-            const int x0 = half_wave_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = half_wave_reduce(has ? c.y : INT32_MAX, OpMinI());
-            const int x1 = half_wave_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = half_wave_reduce(has ? c.y : INT32_MIN, OpMaxI());
+            const int x0 = row16_reduce(has ? c.x : INT32_MAX, OpMinI()), y0 = row16_reduce(has ? c.y : INT32_MAX, OpMinI());
+            const int x1 = row16_reduce(has ? c.x : INT32_MIN, OpMaxI()), y1 = row16_reduce(has ? c.y : INT32_MIN, OpMaxI());
             if ((tid & (YM_BOX_CELLS - 1)) == 0 && i / YM_BOX_CELLS < n_cchunks) bbox[i / YM_BOX_CELLS] = make_int4(x0, y0, x1, y1);
         }
     }
