@@ -282,8 +282,10 @@ __device__ __forceinline__ void ga_accumulate(uint32_t (&E)[4], uint32_t (&S)[4]
 __device__ __forceinline__ uint32_t ga_odd(uint32_t E, uint32_t S) { return S - ((E >> 16) << 8); } // sum(4j + 1) | sum(4j + 3) << 16
 
 // Two pair units (four patches) of one alignment half Q; u0 / u1 = the units' records, the same in every lane (decoded by
-// vector instructions).  All twelve reads are issued at once; the first unit is accumulated while the second one's reads
-// are in flight (LDS reads return in order: lgkmcnt(6) = the first six are back).
+// vector instructions).  A unit's six reads are issued and waited for, then accumulated, then the next unit's (issuing all
+// twelve at once and accumulating the first unit under the second one's reads was measured again at the end of round 3:
+// 4573 against 4585 us per 4096 loop-lattice items, i.e. nothing -- the other waves of the SIMD hide the LDS latency --,
+// for 12 more registers).
 // The registers an asm statement that only ISSUES a read names as outputs are not written when the statement ends, and
 // the compiler is free to copy them right there: every such register is either waited for inside the issuing statement
 // or passes through the statement that waits for it ("+v") before anything else touches it.
