@@ -1,5 +1,6 @@
 #!/bin/bash
-# development aid (GPU box): kernel stats of the metric workload under two library builds (YM_LIB_PATH), alternating
+# development aid (GPU box): kernel stats of the metric workload under two library builds (scripts/dev/ab/libA.so, libB.so
+# through YM_LIB_PATH), alternating.   scripts/dev/kernel_ab.sh <kernel name substring>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
 for v in A B; do
