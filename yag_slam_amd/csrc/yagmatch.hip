@@ -331,6 +331,7 @@ struct ym_matcher {
     DevBuf<uint16_t> partial;  // per beam-chunk partial sums of the coarse lattice
     DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
     DevBuf<int32_t> rg_starts;
+    DevBuf<uint32_t> rg_rbox;    // per query slot, region and angle block: the box its patches read of the region
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
     int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
     uint64_t cache_gen = 1;      // bumped whenever the point cache changes (entries created, re-posed, dropped) or an option is set
@@ -993,6 +994,7 @@ int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P, bool replay = false) {
         if (P.region26) { // the region correlate's lists: one per query slot
             if ((rc = m->rg_entries.ensure((size_t)n_q * P.rg_entries_stride))) return rc;
             if ((rc = m->rg_starts.ensure((size_t)n_q * P.rg_starts_stride))) return rc;
+            if ((rc = m->rg_rbox.ensure((size_t)n_q * P.rg_nrx * P.rg_nry * P.rg_parts))) return rc;
         }
         if (P.region) { // the gather correlate's lists: one set per query slot
             if ((rc = m->ga_units.ensure((size_t)n_q * P.ga_units_stride))) return rc;
@@ -1394,11 +1396,12 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         r.g = P.g; r.lat = P.lc; r.grid = m->grid.p; r.planes = m->planes.p; r.grid_stride = P.grid_stride; r.ctrig = m->ctrig.p;
         r.hypcell = m->hypcell.p; r.states = m->states.p; r.qrep = P.d_qrep; r.entries = m->rg_entries.p; r.entries_stride = P.rg_entries_stride;
         r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
+        r.rbox = m->rg_rbox.p; r.rbox_stride = (size_t)P.rg_nrx * P.rg_nry * P.rg_parts; r.nw = P.rg_nw; r.parts = P.rg_parts;
         r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
         r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
         r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
         r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
-        const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride);
+        const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nrx * P.rg_nry * P.rg_parts);
         if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
             m->bin_lds_limit = bin_lds;
@@ -1922,7 +1925,7 @@ void ym_destroy(ym_matcher *m) {
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->tile_hit_start.release(); m->sel_scratch.release();
-    m->rg_entries.release(); m->rg_starts.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
+    m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();

@@ -46,7 +46,7 @@ static_assert(16 * YM_RG_SEGS >= YM_RG_W + 2 * YM_RG_G + 3 && YM_RG_PITCH >= 16 
 #define YM_RG_MAX_ENTRIES 28672
 #define YM_RG_FLUSH 652                       // patches per set of 16-bit sums: 652 x 100 < 65536 (a multiple of four)
 #define YM_BIN_THREADS 1024
-#define YM_BIN_LDS_BYTES(nbins, entries) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT + YM_RG_MAX_BINS / 32 + 1) * 4 + (size_t)(nbins) * 8 + (size_t)(entries) * 2)
+#define YM_BIN_LDS_BYTES(nbins, entries, nboxes) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT + YM_RG_MAX_BINS / 32 + 1) * 4 + (size_t)(nbins) * 8 + ((size_t)(entries) * 2 + 15) / 16 * 16 + (size_t)(nboxes) * 16)
 
 struct RegionArgs {
     YmGeom g;
@@ -62,6 +62,12 @@ struct RegionArgs {
     size_t entries_stride;  // list per QUERY SLOT of the call (the pairs depend on the query alone, not on the chain)
     int32_t *starts;        // [Q][starts_stride]: first entry of bin (region * nt + angle); [nbins] = total, or -1: no list
     size_t starts_stride;
+    // [Q][rbox_stride]: per (region, block of nw angles) the box of its patches' origins inside the region, rmin | rmax << 8 |
+    // xmin << 16 | xmax << 24 (class rows and bytes): a correlate block stages only the rows and 16-byte segments its own
+    // patches read -- a wall crosses a region, it does not fill it
+    uint32_t *rbox;
+    size_t rbox_stride;
+    int32_t nw, parts;      // waves (= angles) per correlate block, blocks per item
     uint16_t *partial;      // [B][ng][nt][64 lanes][16]: ng sets of 16-bit sums, each of at most YM_RG_FLUSH patches
     size_t partial_stride;
     int32_t nt_stride, dim_stride;
@@ -108,6 +114,8 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(regions_used + 1);             // [nbins] four 16-bit counters (one per
                                                                                          // misalignment), later the runs' first positions
     unsigned short *ent = reinterpret_cast<unsigned short *>(cnt + a.nbins);             // [entries_stride]
+    const int nboxes = a.nrx * a.nry * a.parts;
+    unsigned (*box)[4] = reinterpret_cast<unsigned (*)[4]>(bin_smem + ((reinterpret_cast<unsigned char *>(ent + a.entries_stride) - bin_smem) + 15) / 16 * 16); // [nboxes] rmin, rmax, xmin, xmax
     const int qs = blockIdx.x, b = a.qrep[qs], tid = threadIdx.x, lane = tid & 63;
     const YmItemState &st = a.states[b];
     const int nq = st.nq, nt = a.lat.nt;
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     if (tid < YM_MAX_COARSE_NT) angle_tot[tid] = 0;
     if (tid < YM_RG_MAX_BINS / 32) region_bits[tid] = 0u;
     if (tid == 0) *regions_used = 0;
+    for (int i = tid; i < nboxes; i += YM_BIN_THREADS) { box[i][0] = 255u; box[i][1] = 0u; box[i][2] = 255u; box[i][3] = 0u; }
     __syncthreads();
     // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
     // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
@@ -143,10 +152,18 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
                 const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
                 key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
                 rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
+                // the box of the patch origins of this (region, angle block): class row and byte inside the region
+                const unsigned in_cls = e % (unsigned)YM_RG_CLS, er = in_cls / (unsigned)YM_RG_PITCH, ex = in_cls - er * (unsigned)YM_RG_PITCH;
+                unsigned *bx = box[(bin / nt) * a.parts + k / a.nw];
+                atomicMin(&bx[0], er); atomicMax(&bx[1], er); atomicMin(&bx[2], ex); atomicMax(&bx[3], ex);
             }
         }
     }
     __syncthreads();
+    {
+        uint32_t *rb = a.rbox + (size_t)qs * a.rbox_stride;
+        for (int i = tid; i < nboxes; i += YM_BIN_THREADS) rb[i] = box[i][0] | box[i][1] << 8 | box[i][2] << 16 | box[i][3] << 24;
+    }
     // exclusive scan of the padded bin sizes: thread t owns the bins [t * per, (t + 1) * per)
     const int per = (a.nbins + YM_BIN_THREADS - 1) / YM_BIN_THREADS;
     const int first = tid * per;
@@ -283,9 +300,10 @@ __device__ __forceinline__ void rg_odd(uint32_t (&acc)[8]) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three blocks per CU: 80 VGPRs */) void correlate_region_kernel(RegionArgs a) {
     constexpr int NT = 64 * NW;
-    constexpr int TASKS = 4 * YM_RG_ROWS * YM_RG_SEGS, PER = (TASKS + NT - 1) / NT;
+    constexpr int PER = (YM_RG_ROWS + (NT / 4) / YM_RG_SEGS - 1) / ((NT / 4) / YM_RG_SEGS); // copy tasks per thread (rows of its segment)
     __shared__ __attribute__((aligned(16))) unsigned char region[YM_RG_LDS_BYTES]; // four class images + the zero patch
     __shared__ int rlist[YM_RG_MAX_REGIONS];
+    __shared__ uint32_t rboxl[YM_RG_MAX_REGIONS];     // per listed region: first row | last row << 8 | first segment << 16 | last << 24 to stage
     __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][2]; // per wave and listed region: its first entry and the end
     __shared__ uint2 elist[NW][64];                   // per wave: its first 256 entries of the region being gathered
     __shared__ int rcount;
@@ -343,39 +361,66 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         }
         __syncthreads();
         const int nlist = rcount;
+        {
+            // what this block's patches read of a listed region: rows rmin .. rmax + ny - 1, bytes (xmin & ~3) .. xmax + 15 (+ 13 for
+            // the second half of a lattice row)
+            const uint32_t *rb = a.rbox + (size_t)st.qslot * a.rbox_stride;
+            const uint32_t reach = (uint32_t)(nx > YM_RG_G ? 15 + YM_RG_G : 15);
+            for (int i = tid; i < nlist; i += NT) {
+                const uint32_t v = rb[(size_t)rlist[i] * a.parts + p];
+                const uint32_t r0 = v & 0xffu, r1 = min((uint32_t)(YM_RG_ROWS - 1), ((v >> 8) & 0xffu) + (uint32_t)ny - 1u);
+                const uint32_t s0 = ((v >> 16) & 0xfcu) >> 4, s1 = min((uint32_t)(YM_RG_SEGS - 1), ((v >> 24) + reach) >> 4);
+                rboxl[i] = r0 | r1 << 8 | s0 << 16 | s1 << 24;
+            }
+        }
         if (kvalid)
             for (int i = lane; i < nlist; i += 64) {
                 const int32_t *srow = starts + (size_t)rlist[i] * nt + k;
                 seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1];
             }
         __syncthreads();
-        // copy task t = (class, row, 16-byte block): thread tid takes t = tid, tid + NT, ... (the last ones take task TASKS - 1
-        // again).  Its source offset inside a region is fixed, so a load is one instruction: uniform region base + that
-        // offset.  Nothing is range-checked: rows past the window and blocks past a plane row are other bytes of the
-        // planes buffer (the host allocates YM_RG_PLANES_SLACK bytes past the last item), and no patch the window holds
-        // ever reads them.
+        // Copy tasks.  A thread owns one 16-byte segment `seg` of the rows r0, r0 + RSTEP, ... of ONE class image: its source
+        // and LDS offsets are a base plus a constant stride per task (two registers instead of one per task), and whether a
+        // task lies inside the box a region's patches read (`bx`: first row | last row << 8 | first segment << 16 | last << 24,
+        // wave-uniform, rboxl) is one segment test per region and two row compares per task.
+        // Nothing is range-checked against the window: rows past it and blocks past a plane row are other bytes of the planes
+        // buffer (the host allocates YM_RG_PLANES_SLACK bytes past the last item), and no patch the window holds reads them.
+        constexpr int TPC = NT / 4;                       // threads per class image
+        constexpr int LPS = TPC / YM_RG_SEGS;             // rows the threads of a class cover at once
+        constexpr int RSTEP = LPS;
+        static_assert(LPS >= 1 && LPS * PER >= YM_RG_ROWS, "the copy tasks must cover a class image");
+        const uint32_t cls = (uint32_t)tid / TPC, j = (uint32_t)tid - cls * TPC;
+        const uint32_t seg = j % YM_RG_SEGS, r0 = j / YM_RG_SEGS;
+        const bool copier = j < (uint32_t)(LPS * YM_RG_SEGS);
+        const uint32_t src0 = (cls & 1u) * (uint32_t)plane_bytes + (2u * r0 + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
+        const uint32_t src_step = 2u * RSTEP * (uint32_t)half_pitch;
+        const uint32_t dst0 = (cls * YM_RG_ROWS + r0) * YM_RG_PITCH + 16u * seg;
         uint4 v[PER];
-        uint32_t src_rel[PER];
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const uint32_t t = min((uint32_t)(tid + q * NT), (uint32_t)(TASKS - 1));
-            const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS; // rowidx = class * ROWS + row
-            const uint32_t cls = rowidx / YM_RG_ROWS, r = rowidx - cls * YM_RG_ROWS;
-            src_rel[q] = (cls & 1u) * (uint32_t)plane_bytes + (2u * r + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
-        }
-        auto stage_load = [&](int R) {
+        auto in_box = [&](int q, uint32_t bx, bool seg_in) {
+            const uint32_t r = r0 + (uint32_t)(q * RSTEP);
+            return seg_in && r >= (bx & 0xffu) && r <= ((bx >> 8) & 0xffu);
+        };
+        // task q of every thread is one of the rows q * RSTEP .. + RSTEP - 1: a band the box does not reach is skipped by the
+        // whole block (a scalar branch: no load or store instruction is issued for it)
+        auto band_in = [&](int q, uint32_t bx) {
+            return (uint32_t)(q * RSTEP) <= ((bx >> 8) & 0xffu) && (uint32_t)(q * RSTEP + RSTEP - 1) >= (bx & 0xffu);
+        };
+        auto stage_load = [&](int R, uint32_t bx) {
             const int RX = R % a.nrx, RY = R / a.nrx;
             const uint8_t *src = planes + ((size_t)(2 * RY * YM_RG_H) * half_pitch + (size_t)RX * YM_RG_W); // (wave-uniform)
+            const bool seg_in = copier && seg >= ((bx >> 16) & 0xffu) && seg <= (bx >> 24);
+            // (a task outside the box loads the region's first bytes -- one line for all of them -- and stores nothing; a load
+            //  under a per-lane predicate costs the kernel 28 bytes of scratch per lane and is slower)
 #pragma unroll
-            for (int q = 0; q < PER; q++) v[q] = *reinterpret_cast<const uint4 *>(src + src_rel[q]);
+            for (int q = 0; q < PER; q++)
+                if (band_in(q, bx)) v[q] = *reinterpret_cast<const uint4 *>(src + (in_box(q, bx, seg_in) ? src0 + (uint32_t)q * src_step : 0u));
         };
-        auto stage_store = [&]() {
+        auto stage_store = [&](uint32_t bx) {
+            const bool seg_in = copier && seg >= ((bx >> 16) & 0xffu) && seg <= (bx >> 24);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
-                const uint32_t t = min((uint32_t)(tid + q * NT), (uint32_t)(TASKS - 1));
-                const uint32_t rowidx = t / YM_RG_SEGS, seg = t - rowidx * YM_RG_SEGS;
-                uint32_t *d = reinterpret_cast<uint32_t *>(region + rowidx * YM_RG_PITCH + 16u * seg); // class images are contiguous
-                d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+                uint32_t *d = reinterpret_cast<uint32_t *>(region + dst0 + (uint32_t)(q * RSTEP * YM_RG_PITCH)); // class images are contiguous
+                if (band_in(q, bx) && in_box(q, bx, seg_in)) { d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w; }
             }
         };
         // this wave's entries of a region: [t0, t2) (a multiple of four entries)
@@ -417,10 +462,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         };
         int s0 = 0, s2 = 0;
         if (nlist > 0) {
+            const uint32_t bx = __builtin_amdgcn_readfirstlane(rboxl[0]);
             segment(0, s0, s2);
             entries_load(s0, s2);
-            stage_load(rlist[0]);
-            stage_store();
+            stage_load(rlist[0], bx);
+            stage_store(bx);
             elist[wave][lane] = ev;
         }
         __syncthreads();
@@ -428,15 +474,17 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             // two-stage pipeline: the global loads of the next region are in flight (registers) while this one is gathered
             const bool has_next = ri + 1 < nlist;
             int n0 = 0, n2 = 0;
+            uint32_t nbx = 0u;
             if (has_next) {
+                nbx = __builtin_amdgcn_readfirstlane(rboxl[ri + 1]);
                 segment(ri + 1, n0, n2);
                 entries_load(n0, n2);
-                stage_load(rlist[ri + 1]);
+                stage_load(rlist[ri + 1], nbx);
             }
             gather(s0, s2);
             __syncthreads(); // every wave is done with region ri
             if (has_next) {
-                stage_store();
+                stage_store(nbx);
                 elist[wave][lane] = ev;
             }
             s0 = n0; s2 = n2;
