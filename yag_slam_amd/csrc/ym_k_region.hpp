@@ -397,8 +397,8 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         const uint32_t dst0 = (cls * YM_RG_ROWS + r0) * YM_RG_PITCH + 16u * seg;
         uint4 v[PER];
         auto in_box = [&](int q, uint32_t bx, bool seg_in) {
-            const uint32_t r = r0 + (uint32_t)(q * RSTEP);
-            return seg_in && r >= (bx & 0xffu) && r <= ((bx >> 8) & 0xffu);
+            (void)q; (void)bx;
+            return seg_in; // (rows: whole bands, see band_in -- a per-lane row test costs more vector instructions than the rows it saves)
         };
         // task q of every thread is one of the rows q * RSTEP .. + RSTEP - 1: a band the box does not reach is skipped by the
         // whole block (a scalar branch: no load or store instruction is issued for it)
