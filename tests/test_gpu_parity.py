@@ -1112,3 +1112,40 @@ def test_region_correlate_on_the_loop_config_with_multiplicities():
         o = orc.Oracle(None, "karto", loop=True)
         o.match_scan(query, base, False, False)
         assert np.array_equal(ref[0][0], o.sums(0))
+
+
+def test_scan_pool_staging_and_recycled_blocks_are_invisible():
+    """ym_scan_create uploads through a ring of 64 pinned staging slots with one launch and no synchronisation, and the
+    blocks of destroyed scans are handed out again after the pool's next device-wide synchronisation: scans created
+    faster than the ring turns, used at once, and scans living in blocks that held other readings before must match
+    exactly like the first time, and the structure's info must be the same whenever it is read."""
+    from yag_slam_amd import _capi, synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    L = _capi.lib()
+    truth, scans = synth.trajectory_scans(260)
+    m = ScanMatcher()
+
+    def run(seq):
+        out = []
+        for k in range(20, len(seq), 24):
+            r = m.match_scan(seq[k], seq[k - 20:k], True, True)
+            out.append((r.response, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1], r.covariance, r.meta))
+        return out
+
+    for s in scans:       # 260 creations back to back: the ring wraps four times before anything waits
+        s.native(0)
+    first = run(scans)    # ... and the first use follows at once
+    trusted = [L.ym_scan_structure_trusted(s.native(0), 0) for s in scans]
+    for s in scans:
+        s._release()
+    # other readings go through the freed blocks ...
+    other = synth.trajectory_scans(200, scene=synth.Scene(seed=7))[1]
+    for s in other:
+        s.native(0)
+    for s in other:
+        s._release()
+    # ... and the first set comes back, in another order of creation
+    for s in reversed(scans):
+        s.native(0)
+    assert [L.ym_scan_structure_trusted(s.native(0), 0) for s in scans] == trusted
+    assert run(scans) == first

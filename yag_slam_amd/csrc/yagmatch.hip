@@ -13,6 +13,7 @@
 #include <cstring>
 #include <ctime>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -264,8 +265,12 @@ struct ym_scan {
     double *d_ranges;
     int32_t *d_gov[2] = {nullptr, nullptr}; // trigger-chain structure per semantics (structure_kernel), inside d_ranges' allocation;
     int32_t *d_cidx[2] = {nullptr, nullptr}; // ... the compaction (beam -> point reading) that goes with it,
-    int32_t cnp[2] = {0, 0};                 // ... the number of point readings,
-    bool gov_ok[2] = {false, false};        // ... and whether it holds at every pose (no distance test near the threshold)
+    // ... the number of point readings, and whether the structure holds at every pose (no distance test near the threshold):
+    // written by structure_kernel into the scan's staging slot and read when the scan is first used (scan_resolve)
+    mutable int32_t cnp[2] = {0, 0};
+    mutable bool gov_ok[2] = {false, false};
+    mutable struct ScanStage *stage = nullptr; // != null: the upload + structure launch of ym_scan_create is not known to be complete yet
+    size_t block_bytes = 0;                 // != 0: d_ranges is a block of this size of the device's scan pool (0: its own hipMalloc)
     int n;
     double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
     double pose[3];
@@ -274,6 +279,161 @@ struct ym_scan {
     double lbox[4]; // sensor-frame bounding box (xmin, ymin, xmax, ymax) of every reading that can become a point
     double wbox[4]; // the box at the current pose, in the world: kept with the pose so that a call need not rotate 40 000 boxes
 };
+
+// ---- the scans' device memory and upload.
+// ym_scan_create costs one kernel launch and no synchronisation: the readings are copied into a pinned staging slot,
+// structure_kernel reads them from there (that IS the upload), writes them and the scan's chain structure into a block
+// of the device's scan pool and finally its info words and a serial number into the slot.  Whoever first needs the scan
+// (a matcher building a call, ym_scan_structure_trusted, ym_scan_destroy) waits for the serial number -- normally long
+// there.  Blocks of destroyed scans are parked and become reusable after the next device-wide synchronisation, which
+// the pool performs itself once kRecycleAt blocks are parked (hipFree would synchronise at every destroy).
+// The pool keeps its memory for the life of the process (35 KB per 1081-beam scan ever alive at the same time).
+struct ScanStage {
+    const ym_scan *owner = nullptr; // the scan whose launch last used the slot and has not been waited for
+    uint32_t serial = 0;
+    unsigned char *host = nullptr, *dev = nullptr; // [ranges: YM_MAX_BEAMS doubles][info int32[4]][done uint32[2]]
+};
+namespace {
+constexpr int kScanStages = 64;
+constexpr size_t kStageInfoOffset = sizeof(double) * YM_MAX_BEAMS;
+constexpr size_t kStageBytes = kStageInfoOffset + 64;
+constexpr size_t kRecycleAt = 64;
+constexpr size_t kSlabBytes = 4u << 20;
+
+struct ScanPool {
+    std::mutex mu;
+    int device = -1;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    unsigned char *stage_host = nullptr;
+    ScanStage stages[kScanStages];
+    uint32_t next_stage = 0, serial = 0;
+    std::unordered_map<size_t, std::vector<void *>> free_blocks; // by block size
+    std::vector<std::pair<void *, size_t>> parked;               // of destroyed scans; a kernel in flight may still read them
+};
+
+ScanPool &scan_pool(int device) {
+    static ScanPool pools[64];
+    return pools[device & 63];
+}
+
+// (p.mu held, p's device current)
+void stage_wait(ScanPool &p, ScanStage &st) {
+    const ym_scan *s = st.owner;
+    if (!s) return;
+    const volatile uint32_t *done = reinterpret_cast<const volatile uint32_t *>(st.host + kStageInfoOffset + 16);
+    bool seen = false;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        for (int spin = 0; spin < 2048 && !seen; spin++) {
+            seen = done[0] == st.serial && done[1] == st.serial;
+            if (!seen) __builtin_ia32_pause();
+        }
+        if (seen) break;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 5.0) break;
+    }
+    if (!seen) { // slow or failed launch: ask the stream
+        (void)hipStreamSynchronize(p.stream);
+        seen = done[0] == st.serial && done[1] == st.serial;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (seen) {
+        const int32_t *info = reinterpret_cast<const int32_t *>(st.host + kStageInfoOffset);
+        s->cnp[0] = info[0]; s->gov_ok[0] = info[1] == 0;
+        s->cnp[1] = info[2]; s->gov_ok[1] = info[3] == 0;
+    } else { // the launch never ran: upload the readings the plain way; the matchers compute the chain per pose
+        (void)hipGetLastError();
+        (void)hipMemcpy(s->d_ranges, st.host, sizeof(double) * s->n, hipMemcpyHostToDevice);
+        s->gov_ok[0] = s->gov_ok[1] = false;
+    }
+    s->stage = nullptr;
+    st.owner = nullptr;
+}
+
+void *pool_block(ScanPool &p, size_t bytes) {
+    std::vector<void *> &f = p.free_blocks[bytes];
+    if (f.empty() && p.parked.size() >= kRecycleAt) {
+        if (hipDeviceSynchronize() == hipSuccess) { // nothing in flight can read a parked block any more
+            for (auto &b : p.parked) p.free_blocks[b.second].push_back(b.first);
+            p.parked.clear();
+        }
+    }
+    if (f.empty()) {
+        const size_t count = std::max<size_t>(1, kSlabBytes / bytes);
+        unsigned char *slab = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&slab), count * bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        for (size_t i = count; i-- > 0;) f.push_back(slab + i * bytes);
+    }
+    void *b = f.back();
+    f.pop_back();
+    return b;
+}
+
+// (p.mu held, p's device current)  block + staging slot + the one launch
+int pool_create_scan(ScanPool &p, ym_scan *s, const double *ranges, size_t total, unsigned char **base_out) {
+    if (!p.ready) {
+        HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.stage_host), kStageBytes * kScanStages, hipHostMallocMapped));
+        unsigned char *dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p.stage_host, 0));
+        std::memset(p.stage_host, 0, kStageBytes * kScanStages);
+        for (int i = 0; i < kScanStages; i++) { p.stages[i].host = p.stage_host + kStageBytes * i; p.stages[i].dev = dev + kStageBytes * i; }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
+        p.device = s->device;
+        p.ready = true;
+    }
+    const size_t bytes = align_up(total, 1024);
+    unsigned char *base = static_cast<unsigned char *>(pool_block(p, bytes));
+    if (!base) return set_err(YM_ERR_HIP, "cannot allocate device ranges");
+    ScanStage &st = p.stages[p.next_stage++ % kScanStages];
+    stage_wait(p, st); // (the slot's previous user, 64 creations ago)
+    std::memcpy(st.host, ranges, sizeof(double) * s->n);
+    st.serial = ++p.serial ? p.serial : ++p.serial;
+    s->d_ranges = reinterpret_cast<double *>(base);
+    s->block_bytes = bytes;
+    const size_t n1 = (size_t)s->n;
+    const size_t ranges_bytes = align_up(sizeof(double) * n1, 16), gov_bytes = align_up(sizeof(int32_t) * 2 * n1, 16);
+    const size_t cidx_bytes = align_up(sizeof(int32_t) * n1, 16);
+    ym::StructureArgs sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sr.ranges = reinterpret_cast<const double *>(st.dev); sa.sr.n = s->n; sa.sr.min_angle = s->min_angle; sa.sr.angle_inc = s->angle_inc;
+    sa.sr.min_range = s->min_range; sa.sr.range_threshold = s->range_threshold;
+    sa.gov[0] = reinterpret_cast<int32_t *>(base + ranges_bytes);
+    sa.gov[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + gov_bytes);
+    sa.cidx[0] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes);
+    sa.cidx[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes + cidx_bytes);
+    sa.info = reinterpret_cast<int32_t *>(st.dev + kStageInfoOffset);
+    sa.ranges_out = s->d_ranges;
+    sa.done = reinterpret_cast<uint32_t *>(st.dev + kStageInfoOffset + 16);
+    sa.serial = st.serial;
+    hipLaunchKernelGGL(ym::structure_kernel<512>, dim3(2), dim3(512), YM_PREP_LDS_BYTES(s->n), p.stream, sa);
+    if (hipGetLastError() != hipSuccess) { // the plain way
+        if (hipMemcpy(s->d_ranges, ranges, sizeof(double) * s->n, hipMemcpyHostToDevice) != hipSuccess) {
+            p.free_blocks[bytes].push_back(base);
+            s->d_ranges = nullptr;
+            return set_err(YM_ERR_HIP, "cannot upload ranges");
+        }
+    } else {
+        st.owner = s;
+        s->stage = &st;
+    }
+    *base_out = base;
+    return YM_OK;
+}
+
+// the scan's creation launch has completed and its info words are in the ym_scan
+inline void scan_resolve(const ym_scan *s) {
+    if (!s->stage) return;
+    ScanPool &p = scan_pool(s->device);
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (!s->stage) return;
+    DevGuard guard(s->device);
+    stage_wait(p, *s->stage);
+}
+}  // namespace
 
 struct ym_map {
     int device;
@@ -1785,6 +1945,7 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->beam_spacing = s->beam_spacing;
     o->cache_hint = o->qcache_hint = -1;
     const int sem = semantics == YM_SEM_YAGPY ? 1 : 0;
+    scan_resolve(s);
     o->gov = s->gov_ok[sem] ? s->d_gov[sem] : nullptr;
     o->cidx = s->gov_ok[sem] ? s->d_cidx[sem] : nullptr;
     o->cnp = s->cnp[sem];
@@ -1795,10 +1956,18 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
 void local_bbox(const double *r, int n, double min_angle, double inc, double rt, double box[4]) {
     box[0] = box[1] = 1e300;
     box[2] = box[3] = -1e300;
+    // the beams' directions: one table per sensor geometry (a node's scans all come from the same sensor)
+    struct Directions { double min_angle = 0, inc = 0; std::vector<double> c, s; };
+    static thread_local Directions dir;
+    if ((int)dir.c.size() < n || dir.min_angle != min_angle || dir.inc != inc) {
+        dir.min_angle = min_angle; dir.inc = inc;
+        dir.c.resize(n); dir.s.resize(n);
+        for (int i = 0; i < n; i++) { const double a = min_angle + i * inc; dir.c[i] = std::cos(a); dir.s[i] = std::sin(a); }
+    }
     for (int i = 0; i < n; i++) {
         const double v = r[i];
         if (v > rt || std::isnan(v)) continue;
-        const double a = min_angle + i * inc, x = v * std::cos(a), y = v * std::sin(a);
+        const double x = v * dir.c[i], y = v * dir.s[i];
         box[0] = std::min(box[0], x); box[1] = std::min(box[1], y);
         box[2] = std::max(box[2], x); box[3] = std::max(box[3], y);
     }
@@ -1983,11 +2152,28 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     world_bbox(s->lbox, s->pose, s->wbox);
     s->beam_spacing = median_beam_spacing(d->ranges, d->n, d->min_range, d->range_threshold, d->angle_increment);
     DevGuard guard(device);
-    // one allocation: ranges[n], the chain structure per semantics ([2][n][2] + [2][n] ints), its info words [4]
+    // one block: ranges[n], the chain structure per semantics ([2][n][2] + [2][n] ints), its info words [4]
     const size_t n1 = (size_t)std::max(1, d->n);
     const size_t ranges_bytes = align_up(sizeof(double) * n1, 16), gov_bytes = align_up(sizeof(int32_t) * 2 * n1, 16);
     const size_t cidx_bytes = align_up(sizeof(int32_t) * n1, 16);
-    if (!guard.ok || hipMalloc(reinterpret_cast<void **>(&s->d_ranges), ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes + 16) != hipSuccess) {
+    const size_t total = ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes + 16;
+    const bool structured = d->n > 0 && d->n <= YM_MAX_BEAMS;
+    if (!guard.ok) { set_err(YM_ERR_HIP, "cannot select device %d", device); delete s; return nullptr; }
+    if (structured) {
+        unsigned char *base = nullptr;
+        {
+            ScanPool &p = scan_pool(device);
+            std::lock_guard<std::mutex> lk(p.mu);
+            if (pool_create_scan(p, s, d->ranges, total, &base) != YM_OK) { delete s; return nullptr; }
+        }
+        s->d_gov[0] = reinterpret_cast<int32_t *>(base + ranges_bytes);
+        s->d_gov[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + gov_bytes);
+        s->d_cidx[0] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes);
+        s->d_cidx[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes + cidx_bytes);
+        return s;
+    }
+    // no readings, or more than the kernels stage at once (such a scan is refused by the matchers): a plain allocation
+    if (hipMalloc(reinterpret_cast<void **>(&s->d_ranges), total) != hipSuccess) {
         set_err(YM_ERR_HIP, "cannot allocate device ranges");
         delete s;
         return nullptr;
@@ -1997,31 +2183,6 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
         (void)hipFree(s->d_ranges);
         delete s;
         return nullptr;
-    }
-    if (d->n > 0 && d->n <= YM_MAX_BEAMS) {
-        unsigned char *base = reinterpret_cast<unsigned char *>(s->d_ranges);
-        s->d_gov[0] = reinterpret_cast<int32_t *>(base + ranges_bytes);
-        s->d_gov[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + gov_bytes);
-        s->d_cidx[0] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes);
-        s->d_cidx[1] = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes + cidx_bytes);
-        int32_t *d_info = reinterpret_cast<int32_t *>(base + ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes);
-        static std::atomic<int> lds_raised{0};
-        if (!lds_raised.exchange(1))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
-        ym::StructureArgs sa;
-        std::memset(&sa, 0, sizeof sa);
-        sa.sr.ranges = s->d_ranges; sa.sr.n = s->n; sa.sr.min_angle = s->min_angle; sa.sr.angle_inc = s->angle_inc;
-        sa.sr.min_range = s->min_range; sa.sr.range_threshold = s->range_threshold;
-        sa.gov[0] = s->d_gov[0]; sa.gov[1] = s->d_gov[1]; sa.cidx[0] = s->d_cidx[0]; sa.cidx[1] = s->d_cidx[1]; sa.info = d_info;
-        hipLaunchKernelGGL(ym::structure_kernel<512>, dim3(2), dim3(512), YM_PREP_LDS_BYTES(s->n), 0, sa);
-        int32_t info[4] = {0, 1, 0, 1};
-        if (hipGetLastError() == hipSuccess && hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost) == hipSuccess) {
-            s->gov_ok[0] = info[1] == 0;
-            s->gov_ok[1] = info[3] == 0;
-            s->cnp[0] = info[0];
-            s->cnp[1] = info[2];
-        } // (a failure only means the matchers compute the chain per pose)
     }
     return s;
 }
@@ -2044,13 +2205,21 @@ int ym_scan_size(const ym_scan *s) { return s ? s->n : YM_ERR_INVALID; }
 
 int ym_scan_structure_trusted(const ym_scan *s, int semantics) {
     if (!s) return set_err(YM_ERR_INVALID, "null scan");
+    scan_resolve(s);
     return s->gov_ok[semantics == YM_SEM_YAGPY ? 1 : 0] ? 1 : 0;
 }
 
 void ym_scan_destroy(ym_scan *s) {
     if (!s) return;
     DevGuard guard(s->device);
-    if (s->d_ranges) (void)hipFree(s->d_ranges);
+    scan_resolve(s); // (its creation launch writes into the block)
+    if (s->block_bytes) {
+        ScanPool &p = scan_pool(s->device);
+        std::lock_guard<std::mutex> lk(p.mu);
+        p.parked.push_back({s->d_ranges, s->block_bytes});
+    } else if (s->d_ranges) {
+        (void)hipFree(s->d_ranges);
+    }
     delete s;
 }
 
@@ -2265,7 +2434,10 @@ int ym_map_sequence(ym_matcher *m, ym_scan *const *scans, const double *odom, in
             // every scan a chained step touches must carry a trusted structure (no point-cache slot then, whose pose the
             // host would not know): the segment ends before the first step that meets another kind
             const int sem = 0;
-            auto trusted = [&](int j) { return scans[j]->id != 0 && scans[j]->n > 0 && scans[j]->gov_ok[sem] && m->use_scan_structure; };
+            auto trusted = [&](int j) {
+                scan_resolve(scans[j]);
+                return scans[j]->id != 0 && scans[j]->n > 0 && scans[j]->gov_ok[sem] && m->use_scan_structure;
+            };
             int hi = std::min(n, i + seg_len);
             // (the structure is trusted within YM_CHAIN_POSE_LIMIT of the origin: stay well inside with predicted poses)
             bool chain_ok = std::fabs(scans[i - 1]->pose[0]) < 0.9 * YM_CHAIN_POSE_LIMIT && std::fabs(scans[i - 1]->pose[1]) < 0.9 * YM_CHAIN_POSE_LIMIT &&
@@ -2613,6 +2785,7 @@ int ym_match_map(ym_matcher *m, const ym_map *mp, double ox, double oy, const ym
     std::memset(hs, 0, scans_bytes);
     for (int i = 0; i < n_queries; i++) {
         const ym_scan *q = queries[i];
+        scan_resolve(q);
         hs[i].ranges = q->d_ranges; hs[i].n = q->n;
         hs[i].min_angle = q->min_angle; hs[i].angle_inc = q->angle_inc; hs[i].min_range = q->min_range;
         hs[i].range_threshold = q->range_threshold;
@@ -2690,6 +2863,7 @@ ym_occupancy *ym_occupancy_create(const ym_scan *const *scans, int n_scans, doub
     std::memset(hs.data(), 0, sizeof(YmScanRef) * n_scans);
     for (int i = 0; i < n_scans; i++) {
         const ym_scan *q = scans[i];
+        scan_resolve(q);
         hs[i].ranges = q->d_ranges; hs[i].n = q->n;
         hs[i].min_angle = q->min_angle; hs[i].angle_inc = q->angle_inc; hs[i].min_range = q->min_range;
         hs[i].range_threshold = q->max_range; // the laser's MAXIMUM range travels in this field (see occ_trace_kernel)

@@ -490,6 +490,11 @@ struct StructureArgs {
     int32_t *gov[2];    // [n][2] per semantics: for compacted point i the chain node that decides it and where its run ends
     int32_t *cidx[2];   // [n] per semantics: beam -> index of its point reading among the compacted ones, or -1
     int32_t *info;      // [2][2]: number of point readings, 1 = a distance test was within the guard band
+    double *ranges_out; // null, or where block 0 copies the readings (sr.ranges is then the pinned host buffer they were staged in:
+                        // the one launch is the upload)
+    uint32_t *done;     // null, or [2] (pinned host memory): each block stores `serial` here when everything it writes is visible
+    uint32_t serial;
+    uint32_t pad;
 };
 template <int NT>
 __global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
@@ -501,7 +506,16 @@ __global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
     const int unsafe = mark_chain<NT, true>(l, np, yag);
     int2 *gov = reinterpret_cast<int2 *>(a.gov[blockIdx.x]);
     for (int i = threadIdx.x; i < np; i += NT) gov[i] = gov_walk(l, i, np, yag);
+    if (a.ranges_out && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.sr.n; i += NT) a.ranges_out[i] = a.sr.ranges[i];
     if (threadIdx.x == 0) { a.info[2 * blockIdx.x] = np; a.info[2 * blockIdx.x + 1] = unsafe; }
+    if (a.done) {
+        __syncthreads(); // every lane's stores are issued and waited for ...
+        if (threadIdx.x == 0) {
+            __threadfence_system(); // ... and written back before the host (and the kernels it launches next) can see the word
+            __hip_atomic_store(a.done + blockIdx.x, a.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- K1 for batches, first half: the heavy, query-independent work ONCE per distinct scan of the call.
