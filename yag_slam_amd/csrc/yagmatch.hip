@@ -179,6 +179,7 @@ struct Call {
 // strides, the descriptor, and which tiles the raster covers.  Filled in by the plan_* functions below.
 struct CallPlan {
     int B = 0, nscans = 0, max_n = 1, max_base = 1;
+    bool lists_on_side_stream = false; // the region path's bin_kernel went to the matcher's second stream (join before the region kernel)
     bool yag = false;
     YmGeom g;
     YmLattice lc, lf;
@@ -461,6 +462,11 @@ struct ym_matcher {
     ym_config cfg;
     int device;
     hipStream_t own_stream, stream;
+    // the region path's pair lists (bin_kernel: ONE block per query of the call, ~85 us) need nothing of the raster: they are
+    // built on a second stream next to tiles + raster and joined before the region kernel
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_lists = true;
     YmGeom geom;                 // config part filled at create; window part per call
     std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)
     std::vector<double> kernel_f; // yagpy: the float kernel (helpers.py:86-97), for maps built from occupancy images
@@ -1539,6 +1545,47 @@ void enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
 }
 
 // ---- K4 coarse correlate
+ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
+    ym::RegionArgs r;
+    r.g = P.g; r.lat = P.lc; r.grid = m->grid.p; r.planes = m->planes.p; r.grid_stride = P.grid_stride; r.ctrig = m->ctrig.p;
+    r.hypcell = m->hypcell.p; r.states = m->states.p; r.qrep = P.d_qrep; r.entries = m->rg_entries.p; r.entries_stride = P.rg_entries_stride;
+    r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
+    r.rbox = m->rg_rbox.p; r.rbox_stride = (size_t)P.rg_nrx * P.rg_nry * P.rg_parts; r.nw = P.rg_nw; r.parts = P.rg_parts;
+    r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
+    r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
+    r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
+    r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
+    return r;
+}
+
+// bin_kernel, once per query slot of the call: after the prepare stage (item states, hypothesis cells, angle tables)
+int enqueue_region_lists(ym_matcher *m, const CallPlan &P, hipStream_t st) {
+    const ym::RegionArgs r = region_args(m, P);
+    const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nrx * P.rg_nry * P.rg_parts);
+    if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+        m->bin_lds_limit = bin_lds;
+    }
+    hipLaunchKernelGGL(ym::bin_kernel, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
+    return YM_OK;
+}
+
+// the lists on the matcher's second stream: fork here (the prepare stage is enqueued), join in enqueue_correlate
+int enqueue_region_lists_aside(ym_matcher *m, CallPlan &P) {
+    if (!m->side_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(m->ev_fork, m->stream));
+    HIP_TRY(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+    int rc = enqueue_region_lists(m, P, m->side_stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(m->ev_join, m->side_stream));
+    P.lists_on_side_stream = true;
+    return YM_OK;
+}
+
 int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     hipStream_t st = m->stream;
     ym::CorrArgs a;
@@ -1552,21 +1599,9 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     int rc;
     hipEvent_t ev_k = nullptr;
     if (P.region26) {
-        ym::RegionArgs r;
-        r.g = P.g; r.lat = P.lc; r.grid = m->grid.p; r.planes = m->planes.p; r.grid_stride = P.grid_stride; r.ctrig = m->ctrig.p;
-        r.hypcell = m->hypcell.p; r.states = m->states.p; r.qrep = P.d_qrep; r.entries = m->rg_entries.p; r.entries_stride = P.rg_entries_stride;
-        r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
-        r.rbox = m->rg_rbox.p; r.rbox_stride = (size_t)P.rg_nrx * P.rg_nry * P.rg_parts; r.nw = P.rg_nw; r.parts = P.rg_parts;
-        r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
-        r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
-        r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
-        r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
-        const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nrx * P.rg_nry * P.rg_parts);
-        if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
-            m->bin_lds_limit = bin_lds;
-        }
-        hipLaunchKernelGGL(ym::bin_kernel, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r); // once per query slot
+        const ym::RegionArgs r = region_args(m, P);
+        if (P.lists_on_side_stream) HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
+        else if ((rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts, P.B);
         switch (P.rg_nw) {
@@ -1753,6 +1788,7 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     emark(0);
     enqueue_prepare(m, P);
     emark(1);
+    if (P.region26 && !P.yag && m->overlap_lists && !P.stamps && P.k_end > P.k_begin && (rc = enqueue_region_lists_aside(m, P))) return rc;
     if ((rc = enqueue_select(m, P))) return rc;
     if ((rc = enqueue_raster(m, P))) return rc;
     emark(2);
@@ -2108,6 +2144,9 @@ void ym_destroy(ym_matcher *m) {
     for (auto &p : m->prof)
         for (auto &e : p.pairs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     delete m;
 }
 
@@ -3037,6 +3076,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 25) m->chain_margin = value;
     else if (option == 26) m->prepare_threads = value;
     else if (option == 28) m->lds_min_batch = std::max(8, value);
+    else if (option == 29) m->overlap_lists = value != 0;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;

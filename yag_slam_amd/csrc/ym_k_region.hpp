@@ -86,13 +86,19 @@ struct RegionArgs {
 // the bin of one (beam, angle) pair and its entry = the LDS offset of the patch's first byte once the region is staged;
 // false if the patch origin is outside the regions (never for a patch the window holds; kept so that nothing is ever
 // written out of bounds)
-__device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int cx0, int cy0, int k, int i, int &bin, unsigned &entry) {
+// (region = its index, er / ex = the patch origin's class row and byte inside the region)
+__device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int cx0, int cy0, int k, int &bin, unsigned &entry, int &region,
+                                             unsigned &er, unsigned &ex) {
     const int X = cx0 + cell.x, Y = cy0 + cell.y;
-    const int xc = X >> 1, yc = Y >> 1;
-    const int rx = xc / YM_RG_W, ry = yc / YM_RG_H;
-    if (X < 0 || Y < 0 || rx >= a.nrx || ry >= a.nry) return false;
-    bin = (ry * a.nrx + rx) * a.lat.nt + k;
-    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS + (yc - ry * YM_RG_H) * YM_RG_PITCH + (xc - rx * YM_RG_W));
+    if (X < 0 || Y < 0) return false;
+    const unsigned xc = (unsigned)X >> 1, yc = (unsigned)Y >> 1;
+    const unsigned rx = xc / (unsigned)YM_RG_W, ry = yc / (unsigned)YM_RG_H;
+    if ((int)rx >= a.nrx || (int)ry >= a.nry) return false;
+    region = (int)(ry * (unsigned)a.nrx + rx);
+    bin = region * a.lat.nt + k;
+    er = yc - ry * YM_RG_H;
+    ex = xc - rx * YM_RG_W;
+    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS) + er * YM_RG_PITCH + ex;
     return true;
 }
 
@@ -140,25 +146,41 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     unsigned rank_hi[(MAXP + 3) / 4];
 #pragma unroll
     for (int q = 0; q < (MAXP + 3) / 4; q++) rank_hi[q] = 0u;
+    // A thread takes `per` CONSECUTIVE pairs (beam i of angle k, stepped from one pair to the next): neighbouring beams of one
+    // angle mostly share their bin and nearly always their box, so the lanes of a wave -- `per` beams apart -- spread over
+    // the counters (64 lanes' atomics on one LDS word take turns: 59 of this kernel's 85 us went there while lane = beam), and a thread
+    // keeps the box of its run of pairs in registers and sends it when the box changes.
+    const int per_thread = (total + YM_BIN_THREADS - 1) / YM_BIN_THREADS;
+    const unsigned inv_nw = 65536u / (unsigned)a.nw + 1u; // (angle block k / nw as a multiplication: exact for k < 256, nw <= 256)
+    const int p0 = tid * per_thread;
+    int k = p0 / max(nq, 1), i = p0 - k * nq;
+    int cur = -1;                                 // the box the thread is collecting, and its extent so far
+    unsigned r0 = 255u, r1 = 0u, x0 = 255u, x1 = 0u;
+    auto send_box = [&]() {
+        if (cur >= 0) {
+            unsigned *bx = box[cur];
+            atomicMin(&bx[0], r0); atomicMax(&bx[1], r1); atomicMin(&bx[2], x0); atomicMax(&bx[3], x1);
+        }
+    };
 #pragma unroll
     for (int q = 0; q < MAXP; q++) {
-        const int p = tid + q * YM_BIN_THREADS;
+        const int p = p0 + q;
         key[q] = 0xffffffffu;
-        if (p < total) {
-            const int k = p / nq, i = p - k * nq;
+        if (q < per_thread && p < total) {
             const double2 cs = trig[k];
-            int bin; unsigned e;
-            if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, i, bin, e)) {
+            int bin, region; unsigned e, er, ex;
+            if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, bin, e, region, er, ex)) {
                 const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
                 key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
                 rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
-                // the box of the patch origins of this (region, angle block): class row and byte inside the region
-                const unsigned in_cls = e % (unsigned)YM_RG_CLS, er = in_cls / (unsigned)YM_RG_PITCH, ex = in_cls - er * (unsigned)YM_RG_PITCH;
-                unsigned *bx = box[(bin / nt) * a.parts + k / a.nw];
-                atomicMin(&bx[0], er); atomicMax(&bx[1], er); atomicMin(&bx[2], ex); atomicMax(&bx[3], ex);
+                const int bi = region * a.parts + (int)(((unsigned)k * inv_nw) >> 16);
+                if (bi != cur) { send_box(); cur = bi; r0 = r1 = er; x0 = x1 = ex; }
+                else { r0 = min(r0, er); r1 = max(r1, er); x0 = min(x0, ex); x1 = max(x1, ex); }
             }
         }
+        if (++i >= nq) { i = 0; k++; }
     }
+    send_box();
     __syncthreads();
     {
         uint32_t *rb = a.rbox + (size_t)qs * a.rbox_stride;
