@@ -266,10 +266,10 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     win, allrec, per = sh.match(records[0], False, False, slot=0)
     sync()
     one_shot = time.perf_counter() - t0
-    hyp_local = sum(p.meta["hypotheses"] for p in per) if per else 0
+    hyp_local = int(per.array["hypotheses"].sum()) if per else 0
     local_best = None
     if per:
-        resp = np.array([p.response for p in per])
+        resp = per.array["response"]
         local_best = (float(resp.max()), lo + int(np.argmax(resp)))
     # pipelined repetitions
     w = once(0)

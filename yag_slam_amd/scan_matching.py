@@ -63,22 +63,57 @@ _RESULT_DTYPE = np.dtype([("response", "<f8"), ("pose", "<f8", (3,)), ("cov", "<
 assert _RESULT_DTYPE.itemsize == C.sizeof(_capi.YmResult)
 
 
+class BatchResults(object):
+    """The per-chain results of a batch as a read-only sequence of ScanMatcherResult, built when an entry is looked at:
+    a loop closure asks for the few chains above its thresholds, and 4096 result objects cost more Python time (4.5 ms)
+    than the GPU spends on the 4096 matches.  `.array` is the numpy record view of the ym_result array
+    (include/yagmatch.h): response, pose, cov, coarse_response, hypotheses, coarse_dims, fine_dims, n_query_points,
+    expansions, status -- the form to filter and sort in."""
+
+    __slots__ = ("array",)
+
+    def __init__(self, array):
+        self.array = array
+
+    def __len__(self):
+        return int(self.array.shape[0])
+
+    def _one(self, i):
+        r = self.array[i]
+        p = r["pose"]
+        return ScanMatcherResult(float(r["response"]), r["cov"].reshape(3, 3).tolist(), Transform(float(p[0]), float(p[1]), 0.0, float(p[2])),
+                                 {"coarse_response": float(r["coarse_response"]), "hypotheses": int(r["hypotheses"]),
+                                  "coarse_dims": tuple(r["coarse_dims"].tolist()), "fine_dims": tuple(r["fine_dims"].tolist()),
+                                  "n_query_points": int(r["n_query_points"]), "expansions": int(r["expansions"]),
+                                  "status": int(r["status"])})
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._one(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("chain index out of range")
+        return self._one(i)
+
+    def __iter__(self):
+        return (self._one(i) for i in range(len(self)))
+
+    def best(self):
+        """index of the chain with the highest response (the first of equals, like ym_batch_wait's best_chain)"""
+        return int(np.argmax(self.array["response"])) if len(self) else -1
+
+
 def _results(per, check=False):
-    """list of ScanMatcherResult from a ctypes array of YmResult, converted column-wise.  check: raise like
-    match_scan does when any chain reports Karto's "unable to find best position / index out of range"."""
-    a = np.frombuffer(per, dtype=_RESULT_DTYPE)
+    """BatchResults over a copy of a ctypes array of YmResult.  check: raise like match_scan does when any chain reports
+    Karto's "unable to find best position / index out of range"."""
+    a = np.frombuffer(per, dtype=_RESULT_DTYPE).copy()
     if check and a["status"].any():
         bad = int(np.flatnonzero(a["status"])[0])
         raise _capi.YmError(int(a["status"][bad]), "Mapper FATAL ERROR - unable to find best position / index out of range "
                             "(chain %d)" % bad)
-    resp, pose, cov = a["response"].tolist(), a["pose"].tolist(), a["cov"].reshape(-1, 3, 3).tolist()
-    cresp, hyp = a["coarse_response"].tolist(), a["hypotheses"].tolist()
-    cd, fd = a["coarse_dims"].tolist(), a["fine_dims"].tolist()
-    nq, ex, stt = a["n_query_points"].tolist(), a["expansions"].tolist(), a["status"].tolist()
-    return [ScanMatcherResult(resp[i], cov[i], Transform(pose[i][0], pose[i][1], 0.0, pose[i][2]),
-                              {"coarse_response": cresp[i], "hypotheses": hyp[i], "coarse_dims": tuple(cd[i]),
-                               "fine_dims": tuple(fd[i]), "n_query_points": nq[i], "expansions": ex[i], "status": stt[i]})
-            for i in range(len(resp))]
+    return BatchResults(a)
 
 
 class ScanMatcher(object):
