@@ -27,4 +27,4 @@ for i in range(3):
     print("  ym_batch_wait %.2f ms, _results %.2f ms" % ((tb - ta) * 1e3, (tc - tb) * 1e3))
     t2 = time.perf_counter()
     print("GPU ms: correlate %.2f raster %.2f call %.2f" % tuple(m.profile_read(w)[0] for w in range(3)))
-    print("run_async %.2f ms, wait incl. results %.2f ms, expansions max %d, count %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, max(p.meta["expansions"] for p in per), sum(1 for p in per if p.meta["expansions"])))
+    print("run_async %.2f ms, wait incl. results %.2f ms, expansions max %d, count %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, int(per.array["expansions"].max()), int((per.array["expansions"] > 0).sum())))
