@@ -7,7 +7,7 @@ for v in A B; do
   export YM_LIB_PATH=$GRAFT_REPO_ROOT/scripts/dev/ab/lib$v.so
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab$v -o ab -- python3 bench.py --only cfg2x --no-production-legs --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2>&1
   echo "== $v"
-  grep "$1" gpurun_out/ab$v/ab_kernel_stats.csv | cut -d, -f1-4
+  grep "$1" gpurun_out/ab$v/ab_kernel_stats.csv | sed "s/\"[^\"]*\"/K/" | cut -d, -f1-4
   find gpurun_out/ab$v -size +1M -delete
 done
 done

@@ -1149,3 +1149,38 @@ def test_scan_pool_staging_and_recycled_blocks_are_invisible():
         s.native(0)
     assert [L.ym_scan_structure_trusted(s.native(0), 0) for s in scans] == trusted
     assert run(scans) == first
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 8, 11, 14])
+def test_raster_tile_height_is_invisible(seed):
+    """Large batches over large windows rasterise in 64 x 64 tiles, everything else in 64 x 32 (a host decision per call):
+    forced either way on the same matcher in turn (debug option 30: the tile-zero flags and dirty rectangles of one tiling
+    must not leak into the other), single matches and batches give the same window bytes and results, and the tall
+    tiling's bytes are the oracle's."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    cfg, query, base, penalty, fine, _ = _random_case(seed)
+    o = orc.Oracle(cfg, "karto")
+    ro = o.match_scan(query, base, penalty, fine)
+    m = ScanMatcher(cfg)
+    nq, nb = _mk_native(query), [_mk_native(b) for b in base]
+    chains = [nb[:max(1, len(nb) - (c % 3))] for c in range(50)]  # (50 items: tile work lists + hit lists)
+    seen = {}
+    for th in (64, 32, 64, 0):
+        m.debug_option(30, th)
+        r = m.match_scan(nq, nb, penalty, fine)
+        g, info = m.debug_grid()
+        per, _ = m.match_scan_batch(nq, chains, penalty, fine)
+        gb, _ = m.debug_grid(item=49)
+        key = (r.response, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1], r.covariance, r.meta,
+               tuple((p.response, p.best_pose.x, p.best_pose.y, p.best_pose.euler[-1]) for p in per))
+        if seen:
+            assert key == seen["key"], "results differ at tile height %d" % th
+            assert np.array_equal(g, seen["g"]) and np.array_equal(gb, seen["gb"]), "window bytes differ at tile height %d" % th
+        else:
+            seen = {"key": key, "g": g.copy(), "gb": gb.copy()}
+            if ro["n_query_points"] > 0 and ro["expansions"] == 0 and r.meta["expansions"] == 0:
+                og, oinfo = o.grid_u8()
+                sub = og[info.origin_y:info.origin_y + info.height, info.origin_x:info.origin_x + info.width]
+                assert np.array_equal(g, sub), "tall tiles: grid window differs from the oracle's in %d cells" % int((g != sub).sum())
+    assert abs(r.response - ro["response"]) <= 1e-12

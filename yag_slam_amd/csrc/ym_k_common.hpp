@@ -185,6 +185,7 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 #define YM_BOX_CELLS 16
 #define YM_N_BOXES(n) (((n) + YM_BOX_CELLS - 1) / YM_BOX_CELLS)
 #define YM_TILE_W 64
-#define YM_TILE_H 32
+#define YM_TILE_H 32      // raster tile: 64 x 32 cells -- or 64 x 64 (YM_TILE_H_TALL) on large batches with large windows, chosen per call
+#define YM_TILE_H_TALL 64
 
 }  // namespace ym

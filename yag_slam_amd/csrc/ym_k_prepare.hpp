@@ -591,6 +591,7 @@ struct TilesArgs {
     uint16_t *hits;          // [B][hit_cap] box indices, tile after tile; null = no lists (the raster scans)
     int32_t *hit_start;      // [B][tile_cap + 1] first hit of sub-grid tile i; [0] = -1: the lists did not fit hit_cap
     int32_t hit_cap;
+    int32_t tile_h;          // rows per tile in this call (YM_TILE_H or YM_TILE_H_TALL)
 };
 // grid (B), dynamic LDS = 4 * ceil(tiles_x * tiles_y / 32) bytes (+ 4 bytes per tile of the rectangle with hit lists)
 __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
         if (bb.x > bb.z) continue;
         // tiles whose halo-extended rectangle [t*T - h, t*T + T + h - 1] meets the box (the raster kernel's own test)
         const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
-        const int ty0 = max(ly0, max(bb.y - h, 0) / YM_TILE_H), ty1 = min(ly1, (bb.w + h) / YM_TILE_H);
+        const int ty0 = max(ly0, max(bb.y - h, 0) / a.tile_h), ty1 = min(ly1, (bb.w + h) / a.tile_h);
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 const int t = ty * a.tiles_x + tx;
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
         const int4 bb = bbox[c];
         if (bb.x > bb.z) continue;
         const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
-        const int ty0 = max(ly0, max(bb.y - h, 0) / YM_TILE_H), ty1 = min(ly1, (bb.w + h) / YM_TILE_H);
+        const int ty0 = max(ly0, max(bb.y - h, 0) / a.tile_h), ty1 = min(ly1, (bb.w + h) / a.tile_h);
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) hits[atomicAdd(&cnt[(ty - ly0) * ltx + (tx - lx0)], 1)] = (uint16_t)c;
     }

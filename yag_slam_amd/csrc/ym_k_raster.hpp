@@ -41,16 +41,19 @@ struct RasterArgs {
 //   column pass m(y, x) = min over |dy| <= h of dy^2 + g(y+dy, x)^2        (8 cells per lane)
 // NT = 256: one tile row per thread, shortest latency (single match); NT = 128: two rows per thread, twice the
 // blocks per CU -- the tiles with work are latency-bound, so a batch gains (raster 160 -> 140 us on 256 items)
-template <int NT, bool OVERFLOW>
+// TH = 32 rows per tile, or 64: half the blocks, a sixth less halo (4096 items: raster 1.63 -> 1.44 ms), but longer
+// blocks -- a single match loses 6 us, the loop lattice's small windows 3 % --, so the host picks per call.
+template <int NT, bool OVERFLOW, int TH>
 __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
-    constexpr int TW = YM_TILE_W, TH = YM_TILE_H, HM = YM_MAX_KERNEL_HALF;
+    constexpr int TW = YM_TILE_W, HM = YM_MAX_KERNEL_HALF;
+    constexpr int MAXHITS = 256 * TH / 32;             // chunk boxes a block lists for its tile before it walks all boxes
     constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
     constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
     __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
     __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
     __shared__ unsigned char lut[2 * HM * HM + 8];
     __shared__ unsigned colany[TW / 8][4]; // per 8-cell column group: bit ry = the row pass found a wall within reach in halo row ry
-    __shared__ int s_hits[256], s_left[256];
+    __shared__ int s_hits[MAXHITS], s_left[MAXHITS];
     __shared__ int s_nhits;
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         const int ti = (tiy - a.tile_y0) * a.ltx + (tix - a.tile_x0);
         h0 = hstart[ti];
         hn = hstart[ti + 1] - h0;
-        if (hn > 256) hn = -1; // (more than the list holds: scan)
+        if (hn > MAXHITS) hn = -1; // (more than the list holds: scan)
     }
     if (tid == 0) s_nhits = hn >= 0 ? hn : 0;
     int4 bb_first = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN); // this thread's first box: kept for the second pass
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         const int4 bb = (!listed && c == tid) ? bb_first : bbox[c]; // (a single match: 170 boxes, one per thread, no second load)
         if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
             const int at = atomicAdd(&s_nhits, 1);
-            if (at < 256) { // the chunk's first cell and how many it holds (the division once per hit, not per cell)
+            if (at < MAXHITS) { // the chunk's first cell and how many it holds (the division once per hit, not per cell)
                 const int slot = c / n_cchunks, first = (c - slot * n_cchunks) * YM_BOX_CELLS;
                 s_hits[at] = slot * a.max_n + first;
                 s_left[at] = a.max_n - first;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     const int2 *cells = a.cells + (size_t)bi * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
-    if (nhits <= 256) {
+    if (nhits <= MAXHITS) {
         // work item = (hit chunk, cell of the chunk); 4 items per thread in flight
         const int nwork = nhits * YM_BOX_CELLS;
         for (int w0 = 0; w0 < nwork; w0 += 4 * NT) {
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const unsigned max_d2 = (unsigned)(2 * h * h);
     const unsigned *ca = colany[x8 / 8];
-    const unsigned long long ca_lo = (unsigned long long)ca[0] | (unsigned long long)ca[1] << 32, ca_hi = ca[2]; // (y + 2h <= 71)
+    const unsigned long long ca_lo = (unsigned long long)ca[0] | (unsigned long long)ca[1] << 32, ca_hi = (unsigned long long)ca[2] | (unsigned long long)ca[3] << 32; // (y + 2h <= TH - 1 + 40 < 128)
     const unsigned long long tapmask = (1ull << (2 * h + 1)) - 1ull;
     for (int y = y0; y < TH; y += NT / LPR) {
         us2 mn2[4];
