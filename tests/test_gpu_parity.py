@@ -1184,3 +1184,27 @@ def test_raster_tile_height_is_invisible(seed):
                 sub = og[info.origin_y:info.origin_y + info.height, info.origin_x:info.origin_x + info.width]
                 assert np.array_equal(g, sub), "tall tiles: grid window differs from the oracle's in %d cells" % int((g != sub).sum())
     assert abs(r.response - ro["response"]) <= 1e-12
+
+
+def test_a_query_matched_right_after_its_creation_is_read_from_its_staging_slot():
+    """ym_scan_create returns before the scan's upload has completed; a synchronous match whose QUERY is such a scan reads
+    the readings from the pinned staging slot instead of waiting (debug option 31 = 0: it waits).  Same results either
+    way, the scan works as a base scan afterwards, and a sequence of create-match steps equals the one with waits."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+
+    def run(staged):
+        truth, scans = synth.trajectory_scans(120)
+        m = ScanMatcher()
+        m.debug_option(31, 1 if staged else 0)
+        mapper = SequentialMapper(m)
+        out = []
+        for s in scans:
+            s.native(0)                      # created now ...
+            r = mapper.process_scan(s)       # ... and matched at once
+            p = s.corrected_pose
+            out.append((p.x, p.y, p.euler[-1], None if r is None else r.response))
+        return out
+
+    assert run(True) == run(False)

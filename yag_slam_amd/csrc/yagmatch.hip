@@ -21,6 +21,8 @@
 #include "../../include/yagmatch.h"
 #include "ym_kernels.hpp"
 
+struct ScanStage; // (the pinned staging slot of a scan, see the scan pool)
+
 namespace {
 
 thread_local std::string g_err;
@@ -130,6 +132,7 @@ struct CallScan {
     int cache_hint = -1;            // entry of the matcher's point cache this scan used last time (ym_batch remembers it)
     unsigned char *cache = nullptr; // this call's cache slot (device), or null
     int stale = 0;                  // the slot must be (re)computed by this call
+    ScanStage *staged = nullptr;    // the call reads the readings from the scan's staging slot (see staged_query)
     int qcache_hint = -1;           // the same three for the scan as the QUERY of a batch
     unsigned char *qcache = nullptr;
     int qstale = 0;
@@ -294,6 +297,7 @@ struct ScanStage {
     const ym_scan *owner = nullptr; // the scan whose launch last used the slot and has not been waited for
     uint32_t serial = 0;
     unsigned char *host = nullptr, *dev = nullptr; // [ranges: YM_MAX_BEAMS doubles][info int32[4]][done uint32[2]]
+    std::atomic<int> readers{0};    // synchronous matches in flight that read the staged readings themselves (staged_query)
 };
 namespace {
 constexpr int kScanStages = 64;
@@ -392,6 +396,7 @@ int pool_create_scan(ScanPool &p, ym_scan *s, const double *ranges, size_t total
     if (!base) return set_err(YM_ERR_HIP, "cannot allocate device ranges");
     ScanStage &st = p.stages[p.next_stage++ % kScanStages];
     stage_wait(p, st); // (the slot's previous user, 64 creations ago)
+    while (st.readers.load(std::memory_order_acquire) > 0) __builtin_ia32_pause(); // (another thread's match is reading it)
     std::memcpy(st.host, ranges, sizeof(double) * s->n);
     st.serial = ++p.serial ? p.serial : ++p.serial;
     s->d_ranges = reinterpret_cast<double *>(base);
@@ -468,6 +473,7 @@ struct ym_matcher {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_lists = true;
+    bool staged_queries = true;       // a synchronous match reads a just-created query scan from its staging slot instead of waiting
     int tile_h_forced = 0;            // tests: 32 or 64 rows per raster tile whatever the call
     int tall_tiles_min_window = 768;  // window width (cells) from which a batch of 256+ items gets 64-row tiles
     YmGeom geom;                 // config part filled at create; window part per call
@@ -1978,9 +1984,35 @@ int finish_call(ym_matcher *m, Slot &slot, ym_result *out /* n_items entries */)
     return YM_OK;
 }
 
-int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
+// A scan matched right after its creation (a node that receives its scans one by one) need not wait for its creation
+// launch: as the QUERY of a synchronous match it needs its readings only, and those are in its pinned staging slot --
+// the prepare kernel reads them from there while structure_kernel is still at work on the pool's stream.  The slot is
+// pinned for the duration of the call (readers).  Returns the slot, or null when the launch has completed (the usual
+// device copy and the scan's structure serve) or the scan was never staged.
+ScanStage *staged_query(const ym_scan *s) {
+    if (!s->stage) return nullptr;
+    ScanPool &p = scan_pool(s->device);
+    std::lock_guard<std::mutex> lk(p.mu);
+    ScanStage *st = s->stage;
+    if (!st) return nullptr;
+    const volatile uint32_t *done = reinterpret_cast<const volatile uint32_t *>(st->host + kStageInfoOffset + 16);
+    if (done[0] == st->serial && done[1] == st->serial) { // already there: take the info, no wait
+        DevGuard guard(s->device);
+        stage_wait(p, *st);
+        return nullptr;
+    }
+    st->readers.fetch_add(1, std::memory_order_acq_rel);
+    return st;
+}
+void release_staged(Call &call) {
+    for (CallScan &cs : call.scans)
+        if (cs.staged) { cs.staged->readers.fetch_sub(1, std::memory_order_acq_rel); cs.staged = nullptr; }
+}
+
+int scan_to_call(const ym_scan *s, int semantics, CallScan *o, bool staged_ok = false) {
     if (!s) return set_err(YM_ERR_INVALID, "null scan");
-    o->d_ranges = s->d_ranges;
+    o->staged = staged_ok ? staged_query(s) : nullptr;
+    o->d_ranges = o->staged ? reinterpret_cast<const double *>(o->staged->dev) : s->d_ranges;
     o->n = s->n;
     o->min_angle = s->min_angle;
     o->angle_inc = s->angle_inc;
@@ -1993,6 +2025,7 @@ int scan_to_call(const ym_scan *s, int semantics, CallScan *o) {
     o->beam_spacing = s->beam_spacing;
     o->cache_hint = o->qcache_hint = -1;
     const int sem = semantics == YM_SEM_YAGPY ? 1 : 0;
+    if (o->staged) { o->gov = o->cidx = nullptr; o->cnp = 0; return YM_OK; } // (the points are counted and compacted by the call)
     scan_resolve(s);
     o->gov = s->gov_ok[sem] ? s->d_gov[sem] : nullptr;
     o->cidx = s->gov_ok[sem] ? s->d_cidx[sem] : nullptr;
@@ -2063,12 +2096,13 @@ int check_desc(const ym_scan_desc *d) {
     return YM_OK;
 }
 
+// staged_query_ok: the caller waits for the call before it returns (and calls release_staged)
 int build_single_call(ym_matcher *m, const ym_scan *query, const ym_scan *const *base, int n_base, int penalize,
-                      int refine, Call *call) {
+                      int refine, Call *call, bool staged_query_ok = false) {
     if (!m || !query) return set_err(YM_ERR_INVALID, "null argument");
     if (n_base < 0 || (n_base > 0 && !base)) return set_err(YM_ERR_INVALID, "bad base scan list");
     call->scans.resize(1 + n_base);
-    int rc = scan_to_call(query, m->cfg.semantics, &call->scans[0]);
+    int rc = scan_to_call(query, m->cfg.semantics, &call->scans[0], staged_query_ok && m->staged_queries);
     if (rc) return rc;
     if (query->device != m->device) return set_err(YM_ERR_INVALID, "query scan lives on another device");
     for (int i = 0; i < n_base; i++) {
@@ -2283,11 +2317,13 @@ int ym_match_scans(ym_matcher *m, const ym_scan *query, const ym_scan *const *ba
     if (slot.in_flight && slot.call.slice)
         return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
     Call call;
-    int rc = build_single_call(m, query, base, n_base, penalize, refine, &call);
-    if (rc) return rc;
+    int rc = build_single_call(m, query, base, n_base, penalize, refine, &call, true);
+    if (rc) { release_staged(call); return rc; }
     slot.call = call;
-    if ((rc = launch_call(m, slot))) return rc;
-    return finish_call(m, slot, out);
+    if ((rc = launch_call(m, slot)) == YM_OK) rc = finish_call(m, slot, out);
+    else if (slot.in_flight) (void)hipStreamSynchronize(m->stream);
+    release_staged(slot.call);
+    return rc;
 }
 
 int ym_match(ym_matcher *m, const ym_scan_desc *query, const ym_scan_desc *base, int n_base, int penalize, int refine,
@@ -2368,9 +2404,11 @@ static int sequence_step_sync(ym_matcher *m, ym_scan *const *scans, const double
     if (slot.in_flight && slot.call.slice)
         return set_err(YM_ERR_BUSY, "an angle-sliced match is in flight on this matcher: finish it (ym_match_slice_finish) first");
     slot.call = Call();
-    if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call))) return rc;
-    if ((rc = launch_call(m, slot))) return rc;
-    if ((rc = finish_call(m, slot, result))) return rc;
+    if ((rc = build_single_call(m, scans[i], scans + first, i - first, penalize, refine, &slot.call, true))) { release_staged(slot.call); return rc; }
+    if ((rc = launch_call(m, slot)) == YM_OK) rc = finish_call(m, slot, result);
+    else if (slot.in_flight) (void)hipStreamSynchronize(m->stream);
+    release_staged(slot.call);
+    if (rc) return rc;
     if (result->status != 0) return YM_OK;
     return ym_scan_set_pose(scans[i], result->pose[0], result->pose[1], result->pose[2]);
 }
@@ -3089,6 +3127,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 26) m->prepare_threads = value;
     else if (option == 28) m->lds_min_batch = std::max(8, value);
     else if (option == 29) m->overlap_lists = value != 0;
+    else if (option == 31) m->staged_queries = value != 0;
     else if (option == 30) m->tile_h_forced = value == YM_TILE_H || value == YM_TILE_H_TALL ? value : 0;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
