@@ -14,21 +14,23 @@ def chains_of(B):
         rng = np.random.default_rng(100000 + c)
         out.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
     return out
+LOOP = bool(os.environ.get("AB_LOOP"))
+PF = (False, False) if LOOP else (True, True)
 for B in [int(v) for v in sys.argv[1:]] or [64, 128, 512, 4096]:
     chains = chains_of(B)
     res = []
     OPT = int(os.environ.get("AB_OPT", "29"))
     VALS = [int(v) for v in os.environ.get("AB_VALS", "1,0,1,0").split(",")]
     for overlap in VALS:
-        m = ScanMatcher()
+        m = ScanMatcher(None, loop=LOOP)
         m.debug_option(OPT, overlap)
         b = m.make_batch(q, chains)
         for _ in range(3):
-            b.run_async(True, True, slot=0); out = b.wait(0, per_chain=True)
+            b.run_async(*PF, slot=0); out = b.wait(0, per_chain=True)
         n = 40 if B <= 512 else 10
         t = time.perf_counter()
         for i in range(n):
-            b.run_async(True, True, slot=i % 4)
+            b.run_async(*PF, slot=i % 4)
             if i >= 3: b.wait((i - 3) % 4, per_chain=False)
         for i in range(n - 3, n): b.wait(i % 4, per_chain=False)
         dt = (time.perf_counter() - t) / n
