@@ -475,7 +475,7 @@ struct ym_matcher {
     bool overlap_lists = true;
     bool staged_queries = true;       // a synchronous match reads a just-created query scan from its staging slot instead of waiting
     int tile_h_forced = 0;            // tests: 32 or 64 rows per raster tile whatever the call
-    int tall_tiles_min_window = 768;  // window width (cells) from which a batch of 256+ items gets 64-row tiles
+    int tall_tiles_min_window = 768;  // window width (cells) from which a batch of 512+ items gets 64-row tiles (256 items: 108 against 111 us of raster)
     YmGeom geom;                 // config part filled at create; window part per call
     std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)
     std::vector<double> kernel_f; // yagpy: the float kernel (helpers.py:86-97), for maps built from occupancy images
@@ -828,7 +828,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if (wrap) { g.win_origin = 0; g.win_w = g.storage_w; }
     // tall tiles where the raster is throughput-bound and the window large (measured: 4096 items of the default config
     // gain 12 % of the raster, a single match loses 6 us, the loop config's 5 cm windows lose 3 %)
-    P.tile_h = m->tile_h_forced ? m->tile_h_forced : (B >= 256 && g.win_w >= m->tall_tiles_min_window) ? YM_TILE_H_TALL : YM_TILE_H;
+    P.tile_h = m->tile_h_forced ? m->tile_h_forced : (B >= 512 && g.win_w >= m->tall_tiles_min_window) ? YM_TILE_H_TALL : YM_TILE_H;
     P.tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
     P.tiles_y = (g.win_w + P.tile_h - 1) / P.tile_h;
     g.pitch = P.tiles_x * YM_TILE_W + 64;
