@@ -1208,3 +1208,43 @@ def test_a_query_matched_right_after_its_creation_is_read_from_its_staging_slot(
         return out
 
     assert run(True) == run(False)
+
+
+def test_scan_pool_under_threads():
+    """Four threads create scans (one pool, one ring of staging slots per device), match each at once against their own
+    running chain on their own matcher -- so queries are read from staging slots while other threads turn the ring -- and
+    retire the oldest: every thread gets the poses of the same run done alone."""
+    import threading
+    from yag_slam_amd import synth
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.scan_matching import ScanMatcher
+
+    def run(n):
+        truth, scans = synth.trajectory_scans(n)
+        mapper = SequentialMapper(ScanMatcher())
+        out = []
+        for i, s in enumerate(scans):
+            s.native(0)
+            mapper.process_scan(s)
+            p = s.corrected_pose
+            out.append((p.x, p.y, p.euler[-1]))
+            if i >= 80:
+                scans[i - 80]._release()
+        return out
+
+    want = run(240)
+    got, errors = {}, []
+
+    def work(t):
+        try:
+            got[t] = run(240)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(got[t] == want for t in range(4))
