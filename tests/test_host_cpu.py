@@ -386,3 +386,29 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
                 text = open(os.path.join(d, f), errors="replace").read()
                 assert not pat.search(text), os.path.join(d, f)
+
+
+def test_batch_results_is_a_lazy_sequence_over_the_records():
+    """The per-chain results of a batch: built from the ym_result records when an entry is looked at, with the list
+    behaviours callers of the reference's per-chain loop rely on (len, index, negative index, slice, iteration)."""
+    import numpy as np
+    from yag_slam_amd.scan_matching import BatchResults, _RESULT_DTYPE
+    a = np.zeros(5, dtype=_RESULT_DTYPE)
+    a["response"] = [0.1, 0.7, 0.7, 0.2, 0.0]
+    a["pose"] = [[i, 2.0 * i, 0.1 * i] for i in range(5)]
+    a["cov"] = [np.eye(3).ravel() * (i + 1) for i in range(5)]
+    a["hypotheses"] = 14295
+    a["coarse_dims"] = (26, 26, 21)
+    a["fine_dims"] = (3, 3, 11)
+    a["n_query_points"] = 1081
+    res = BatchResults(a)
+    assert len(res) == 5 and bool(res) and res.best() == 1  # (the first of equal responses, like ym_batch_wait)
+    r = res[3]
+    assert r.response == 0.2 and (r.best_pose.x, r.best_pose.y) == (3.0, 6.0) and abs(r.best_pose.euler[-1] - 0.3) < 1e-15
+    assert r.covariance == [[4.0, 0.0, 0.0], [0.0, 4.0, 0.0], [0.0, 0.0, 4.0]]
+    assert r.meta["coarse_dims"] == (26, 26, 21) and r.meta["fine_dims"] == (3, 3, 11) and r.meta["hypotheses"] == 14295
+    assert res[-1].response == 0.0 and [x.response for x in res[1:3]] == [0.7, 0.7]
+    assert [x.response for x in res] == [0.1, 0.7, 0.7, 0.2, 0.0]
+    with pytest.raises(IndexError):
+        res[5]
+    assert not BatchResults(a[:0]) and BatchResults(a[:0]).best() == -1
