@@ -304,13 +304,14 @@ constexpr int kScanStages = 64;
 constexpr size_t kStageInfoOffset = sizeof(double) * YM_MAX_BEAMS;
 constexpr size_t kStageBytes = kStageInfoOffset + 64;
 constexpr size_t kRecycleAt = 64;
+constexpr int kPoolStreams = 4;
 constexpr size_t kSlabBytes = 4u << 20;
 
 struct ScanPool {
     std::mutex mu;
     int device = -1;
     bool ready = false;
-    hipStream_t stream = nullptr;
+    hipStream_t streams[kPoolStreams] = {}; // creation launches go round them: structure_kernel is two blocks, several run side by side
     unsigned char *stage_host = nullptr;
     ScanStage stages[kScanStages];
     uint32_t next_stage = 0, serial = 0;
@@ -341,7 +342,7 @@ void stage_wait(ScanPool &p, ScanStage &st) {
         if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 5.0) break;
     }
     if (!seen) { // slow or failed launch: ask the stream
-        (void)hipStreamSynchronize(p.stream);
+        (void)hipStreamSynchronize(p.streams[(&st - p.stages) % kPoolStreams]);
         seen = done[0] == st.serial && done[1] == st.serial;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -380,7 +381,7 @@ void *pool_block(ScanPool &p, size_t bytes) {
 // (p.mu held, p's device current)  block + staging slot + the one launch
 int pool_create_scan(ScanPool &p, ym_scan *s, const double *ranges, size_t total, unsigned char **base_out) {
     if (!p.ready) {
-        HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        for (int i = 0; i < kPoolStreams; i++) HIP_TRY(hipStreamCreateWithFlags(&p.streams[i], hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.stage_host), kStageBytes * kScanStages, hipHostMallocMapped));
         unsigned char *dev = nullptr;
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p.stage_host, 0));
@@ -416,7 +417,7 @@ int pool_create_scan(ScanPool &p, ym_scan *s, const double *ranges, size_t total
     sa.ranges_out = s->d_ranges;
     sa.done = reinterpret_cast<uint32_t *>(st.dev + kStageInfoOffset + 16);
     sa.serial = st.serial;
-    hipLaunchKernelGGL(ym::structure_kernel<512>, dim3(2), dim3(512), YM_PREP_LDS_BYTES(s->n), p.stream, sa);
+    hipLaunchKernelGGL(ym::structure_kernel<512>, dim3(2), dim3(512), YM_PREP_LDS_BYTES(s->n), p.streams[(&st - p.stages) % kPoolStreams], sa);
     if (hipGetLastError() != hipSuccess) { // the plain way
         if (hipMemcpy(s->d_ranges, ranges, sizeof(double) * s->n, hipMemcpyHostToDevice) != hipSuccess) {
             p.free_blocks[bytes].push_back(base);
