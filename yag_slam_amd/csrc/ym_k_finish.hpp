@@ -246,7 +246,8 @@ template <int NT>
 __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const double *resp, const double *bm,
                                                        int n_blocks, const double pose[3], double mean[3], int *status,
                                                        double *scratch /* >= 80 */, int *s_list /* NT */, int *s_tmp /* NT */,
-                                                       int *s_nlist, double2 *s_trig /* L.nt */) {
+                                                       int *s_nlist, double2 *s_trig /* L.nt */,
+                                                       const double *first_round = nullptr /* [4]: bm[tid + u * NT] or -1, loaded by the caller */) {
     const int tid = threadIdx.x;
     const int nh = L.nx * L.ny * L.nt;
     const double start_angle = pose[2] - L.angle_off;
@@ -254,7 +255,7 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
     double lb = -1.0;
     double v0[4]; // (the first round of block maxima is in flight while the table is computed)
 #pragma unroll
-    for (int u = 0; u < 4; u++) v0[u] = (tid + u * NT) < n_blocks ? bm[tid + u * NT] : -1.0;
+    for (int u = 0; u < 4; u++) v0[u] = first_round ? first_round[u] : (tid + u * NT) < n_blocks ? bm[tid + u * NT] : -1.0;
     tie_trig_table<NT>(L, start_angle, s_trig);
 #pragma unroll
     for (int u = 0; u < 4; u++) lb = v0[u] > lb ? v0[u] : lb;
@@ -387,6 +388,12 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     const int b = xcd_item_of_block_2d(k); // the blocks of an item share its grid patch: keep them on one XCD
     const int tid = threadIdx.x, lane = tid & 63;
     YM_STAMP(a, 12);
+    // the block maxima leave together with the item's state: the "no readings" test on the state would otherwise put a
+    // memory round trip of its own in front of them
+    const double *bm = a.blockmax + (size_t)b * a.n_blocks;
+    double bm0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bm0[u] = (tid + u * NT) < a.n_blocks ? bm[tid + u * NT] : -1.0;
     YmItemState &st = a.states[b];
     const int nq = st.nq;
     if (nq == 0) return;
@@ -394,9 +401,8 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     const double off_x = st.off_x, off_y = st.off_y;
     double mean[3];
     int status = 0;
-    const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride,
-                                                 a.blockmax + (size_t)b * a.n_blocks, a.n_blocks, pose, mean, &status,
-                                                 scratch, s_list, s_tmp, &s_nlist, s_trig);
+    const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride, bm, a.n_blocks, pose, mean, &status,
+                                                 scratch, s_list, s_tmp, &s_nlist, s_trig, bm0);
     if (k == (a.refine ? a.lf.nt : 0)) { // extra block: coarse result + positional covariance for final_kernel
         double cov[9];
         positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
@@ -502,6 +508,8 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
     const int b = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63;
     YM_STAMP(a, 16);
+    // (the first fine sums leave together with the item's state, not a round trip after it)
+    const uint32_t f0 = (a.refine && tid < a.lf.nx * a.lf.ny * a.lf.nt) ? a.fsums[(size_t)b * a.fsums_stride + tid] : 0u;
     YmItemState &st = a.states[b];
     const int nq = st.nq;
     if (nq == 0) {
@@ -540,7 +548,6 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
         const double start_x = -L.off_x, start_y = -L.off_y, start_angle = ct - L.angle_off;
         const uint32_t *fs = a.fsums + (size_t)b * a.fsums_stride;
         double lb = -1.0;
-        uint32_t f0 = tid < nh ? fs[tid] : 0u; // (in flight while the tie table is computed)
         tie_trig_table<NT>(L, start_angle, s_trig);
         for (int h = tid; h < nh; h += NT) {
             const int k = h / nxy, c = h - k * nxy, iy = c / nx, ix = c - iy * nx;
