@@ -739,6 +739,7 @@ __device__ __forceinline__ int select_insert(unsigned *keys, unsigned bmask, int
 template <int NB>
 __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     constexpr int NT = 1024, KMAX = 16, NW = (NB - 1) / 4;
+    constexpr int PMAX = 12; // points per thread: the host sends at most 12 288 readings here (3 * capacity >= 4 * readings, capacity <= 2^14)
     constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
     constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
     extern __shared__ unsigned sel_lds[];
@@ -749,17 +750,29 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     unsigned *minidx = sel_lds + cap;
     unsigned char *status = reinterpret_cast<unsigned char *>(sel_lds + 2 * cap); // 0 undecided, 1 effective, 2 out
     YM_STAMP(a, 24);
-    for (unsigned i = tid; i < cap; i += NT) { keys[i] = 0u; minidx[i] = 0xffffffffu; status[i] = 0; }
-    __syncthreads();
+    // The thread's points: all loaded at once and kept for step (3), with the slots step (1) finds for them.  (The one block
+    // of an item is a latency chain: a load per loop trip -- which the stores of step (3) into the same array keep the
+    // compiler from moving -- cost steps (1) and (3) a memory round trip per point, 14 + 58 of the kernel's 118 us.)
     int2 *cells = a.cells + (size_t)b * a.max_base * a.max_n;
     const int total = a.max_base * a.max_n;
+    int2 mine[PMAX];
+    unsigned short slot_of[PMAX];
+#pragma unroll
+    for (int q = 0; q < PMAX; q++) {
+        const int e = tid + q * NT;
+        mine[q] = e < total ? cells[e] : make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    }
+    for (unsigned i = tid; i < cap; i += NT) { keys[i] = 0u; minidx[i] = 0xffffffffu; status[i] = 0; }
+    __syncthreads();
     YM_STAMP(a, 25);
     // (1) cell -> earliest point index
-    for (int e = tid; e < total; e += NT) {
-        const int2 c = cells[e];
-        if (c.x == YM_CELL_NONE) continue;
-        const int slot = select_insert(keys, bmask, shift, select_key(c.x, c.y));
-        atomicMin(&minidx[slot], (unsigned)e);
+#pragma unroll
+    for (int q = 0; q < PMAX; q++) {
+        slot_of[q] = 0;
+        if (mine[q].x == YM_CELL_NONE) continue;
+        const int slot = select_insert(keys, bmask, shift, select_key(mine[q].x, mine[q].y));
+        slot_of[q] = (unsigned short)slot;
+        atomicMin(&minidx[slot], (unsigned)(tid + q * NT));
     }
     __syncthreads();
     YM_STAMP(a, 26);
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
         if (any) und |= 1u << k;
         else status[s] = 1;
     }
-    YM_STAMP(a, 27);
+    YM_STAMP(a, 3);
     // (2b) asynchronous relaxation, no barriers: every wave keeps re-reading the state of the earlier
     // neighbours of its undecided cells.  A decision is final and is taken only from final states
     // (a stale "undecided" read merely delays it), and all 16 waves of the block are resident, so
@@ -828,15 +841,15 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
         }
     }
     __syncthreads();
-    YM_STAMP(a, 28);
+    YM_STAMP(a, 30);
     // (3) keep only the earliest point of every effective cell
-    for (int e = tid; e < total; e += NT) {
-        const int2 c = cells[e];
-        if (c.x == YM_CELL_NONE) continue;
-        const int t = select_find(keys, bmask, shift, select_key(c.x, c.y));
-        if (!(t >= 0 && status[t] == 1 && minidx[t] == (unsigned)e)) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+#pragma unroll
+    for (int q = 0; q < PMAX; q++) {
+        if (mine[q].x == YM_CELL_NONE) continue;
+        const int e = tid + q * NT, t = slot_of[q];
+        if (!(status[t] == 1 && minidx[t] == (unsigned)e)) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
     }
-    YM_STAMP(a, 29);
+    YM_STAMP(a, 31);
 }
 
 // ---- the same rule for chains too long for one CU's LDS (more than 12 288 readings): hash, earliest-point index, neighbour
