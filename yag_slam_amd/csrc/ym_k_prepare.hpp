@@ -738,7 +738,7 @@ __device__ __forceinline__ int select_insert(unsigned *keys, unsigned bmask, int
 // NB = 5 for z2max = 1 (plus-shaped disc), 9 for z2max = 2
 template <int NB>
 __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
-    constexpr int NT = 1024, KMAX = 16, NW = (NB - 1) / 4;
+    constexpr int NT = 1024, NW = (NB - 1) / 4;
     constexpr int PMAX = 12; // points per thread: the host sends at most 12 288 readings here (3 * capacity >= 4 * readings, capacity <= 2^14)
     constexpr int DX[9] = {0, 1, -1, 0, 0, 1, 1, -1, -1};
     constexpr int DY[9] = {0, 0, 0, 1, -1, 1, -1, 1, -1};
@@ -757,10 +757,15 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     const int total = a.max_base * a.max_n;
     int2 mine[PMAX];
     unsigned short slot_of[PMAX];
+    // A thread takes `per` CONSECUTIVE points and, in steps (2a) / (2b), decides the cells whose earliest point is one of
+    // them, in that order: the earlier neighbours of a cell are mostly the cells of the beams just before it, so a wall's
+    // chain of dependent decisions resolves inside one thread in one sweep instead of hopping from thread to thread once
+    // per sweep (the relaxation took 53 of the kernel's 111 us while a thread owned hash SLOTS).
+    const int per = (total + NT - 1) / NT, e0 = tid * per;
 #pragma unroll
     for (int q = 0; q < PMAX; q++) {
-        const int e = tid + q * NT;
-        mine[q] = e < total ? cells[e] : make_int2(YM_CELL_NONE, YM_CELL_NONE);
+        const int e = e0 + q;
+        mine[q] = (q < per && e < total) ? cells[e] : make_int2(YM_CELL_NONE, YM_CELL_NONE);
     }
     for (unsigned i = tid; i < cap; i += NT) { keys[i] = 0u; minidx[i] = 0xffffffffu; status[i] = 0; }
     __syncthreads();
@@ -772,24 +777,22 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
         if (mine[q].x == YM_CELL_NONE) continue;
         const int slot = select_insert(keys, bmask, shift, select_key(mine[q].x, mine[q].y));
         slot_of[q] = (unsigned short)slot;
-        atomicMin(&minidx[slot], (unsigned)(tid + q * NT));
+        atomicMin(&minidx[slot], (unsigned)(e0 + q));
     }
     __syncthreads();
     YM_STAMP(a, 26);
-    // (2a) per owned slot (tid + k*NT): the slots of the neighbour cells that hold an EARLIER point,
-    // packed as 16-bit slot numbers (0xffff = none).  A cell with no earlier neighbour is effective.
-    unsigned long long nb[KMAX][NW];
+    // (2a) per owned cell (= owned point that is the earliest of its cell): the slots of the neighbour cells that hold an
+    // EARLIER point, packed as 16-bit slot numbers (0xffff = none).  A cell with no earlier neighbour is effective.
+    unsigned long long nb[PMAX][NW];
     unsigned und = 0;
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
+    for (int k = 0; k < PMAX; k++) {
 #pragma unroll
         for (int w = 0; w < NW; w++) nb[k][w] = ~0ull;
-        const unsigned s = tid + k * NT;
-        if (s >= cap) continue;
-        const unsigned key = keys[s];
-        if (key == 0u) continue;
-        const unsigned me = minidx[s];
-        const int x = (int)(key & 0xffffu) - 32768, y = (int)(key >> 16) - 32768;
+        if (mine[k].x == YM_CELL_NONE) continue;
+        const unsigned s = slot_of[k], me = (unsigned)(e0 + k);
+        if (minidx[s] != me) continue; // a later point of its cell: never effective, nothing to decide
+        const int x = mine[k].x, y = mine[k].y;
         bool any = false;
 #pragma unroll
         for (int n = 1; n < NB; n++) {
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     unsigned char *vst = status;
     unsigned wmask = 0;
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) wmask |= __ballot((und >> k) & 1u) ? (1u << k) : 0u;
+    for (int k = 0; k < PMAX; k++) wmask |= __ballot((und >> k) & 1u) ? (1u << k) : 0u;
     while (wmask) {
         unsigned m = wmask;
         while (m) {
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
                         pending |= stt == 0;
                     }
                 }
-                const unsigned s = tid + k * NT;
+                const unsigned s = slot_of[k];
                 if (knocked) vst[s] = 2;
                 else if (!pending) vst[s] = 1;
                 else still = true;
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
 #pragma unroll
     for (int q = 0; q < PMAX; q++) {
         if (mine[q].x == YM_CELL_NONE) continue;
-        const int e = tid + q * NT, t = slot_of[q];
+        const int e = e0 + q, t = slot_of[q];
         if (!(status[t] == 1 && minidx[t] == (unsigned)e)) cells[e] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
     }
     YM_STAMP(a, 31);
