@@ -721,6 +721,18 @@ __device__ __forceinline__ int select_find(const unsigned *keys, unsigned bmask,
         bk = (bk + 1u) & bmask;
     }
 }
+// the same search, continued at bucket bk
+__device__ __forceinline__ int select_find_from(const unsigned *keys, unsigned bmask, unsigned bk, unsigned key) {
+    for (;;) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + 4 * bk);
+        if (q.x == key) return (int)(4 * bk);
+        if (q.y == key) return (int)(4 * bk + 1);
+        if (q.z == key) return (int)(4 * bk + 2);
+        if (q.w == key) return (int)(4 * bk + 3);
+        if (q.w == 0u) return -1;
+        bk = (bk + 1u) & bmask;
+    }
+}
 // slot of `key`, inserting it if absent
 __device__ __forceinline__ int select_insert(unsigned *keys, unsigned bmask, int shift, unsigned key) {
     unsigned bk = (key * 2654435761u) >> shift;
@@ -794,9 +806,22 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
         if (minidx[s] != me) continue; // a later point of its cell: never effective, nothing to decide
         const int x = mine[k].x, y = mine[k].y;
         bool any = false;
+        // the first probe of every neighbour is issued before any is looked at (the probes are latency, not bandwidth)
+        unsigned nkey[NB], nbk[NB];
+        uint4 nq[NB];
 #pragma unroll
         for (int n = 1; n < NB; n++) {
-            const int t = select_find(keys, bmask, shift, select_key(x + DX[n], y + DY[n]));
+            nkey[n] = select_key(x + DX[n], y + DY[n]);
+            nbk[n] = (nkey[n] * 2654435761u) >> shift;
+            nq[n] = *reinterpret_cast<const uint4 *>(keys + 4 * nbk[n]);
+        }
+#pragma unroll
+        for (int n = 1; n < NB; n++) {
+            const uint4 q4 = nq[n];
+            const unsigned key = nkey[n];
+            int t = q4.x == key ? (int)(4 * nbk[n]) : q4.y == key ? (int)(4 * nbk[n] + 1) : q4.z == key ? (int)(4 * nbk[n] + 2)
+                    : q4.w == key ? (int)(4 * nbk[n] + 3) : q4.w == 0u ? -1 : -2;
+            if (t == -2) t = select_find_from(keys, bmask, (nbk[n] + 1u) & bmask, key); // (a full bucket without the key: go on)
             if (t >= 0 && minidx[t] < me) {
                 any = true;
                 const int j = n - 1;
