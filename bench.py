@@ -641,22 +641,31 @@ def main():
 
         def leg_cold():
             # every chain re-posed before every enqueue: the point cache misses on every base scan (points_kernel projects
-            # them again), the descriptor is new.  512 chains: the pose writes are Python + ctypes calls, ~0.5 us each
-            n = min(512, args.batch)
+            # them again), the descriptor is new, no plan is replayed.  The pose writes are ONE ym_scans_set_poses call per
+            # enqueue (what a graph optimisation does to every vertex, graph_slam.py:263-272); round 3 made one ctypes call
+            # per scan and spent 1.7 ms of Python on 5120 of them against 0.85 ms of GPU.
+            import ctypes as C_
+            n = min(LB, args.batch)
             b1 = m.make_batch(query, chains[:n])
             flat = [s_ for ch in chains[:n] for s_ in ch]
-            poses = [(s_.corrected_pose.x, s_.corrected_pose.y, s_.corrected_pose.euler[-1]) for s_ in flat]
-            hs = [s_.native(local_rank) for s_ in flat]
-            setp = m._lib.ym_scan_set_pose
-            import ctypes as C_
+            poses = np.array([(s_.corrected_pose.x, s_.corrected_pose.y, s_.corrected_pose.euler[-1]) for s_ in flat], dtype=np.float64)
+            hs = (C_.c_void_p * len(flat))(*[s_.native(local_rank) for s_ in flat])
+            setp = m._lib.ym_scans_set_poses
+            dp = C_.POINTER(C_.c_double)
+            moved = [np.ascontiguousarray(poses + np.array([1e-4 * k, 0.0, 0.0])) for k in (1, 2)]
             m.profile(True)
             reps, host = 12, 0.0
+            for i in range(2):  # (the slots meet the batch once, untimed)
+                setp(hs, moved[i % 2].ctypes.data_as(dp), len(flat))
+                b1.run_async(True, True, slot=i % 8)
+            for sl in range(2):
+                b1.wait(sl, per_chain=False)
+            torch.cuda.synchronize()
+            m.profile_read(2)
             t1 = time.perf_counter()
             for i in range(reps):
-                d = 1e-4 * (1 + i % 2)
                 th = time.perf_counter()
-                for h_, p_ in zip(hs, poses):
-                    setp(h_, C_.c_double(p_[0] + d), C_.c_double(p_[1]), C_.c_double(p_[2]))
+                setp(hs, moved[i % 2].ctypes.data_as(dp), len(flat))
                 host += time.perf_counter() - th
                 if i >= 8:
                     b1.wait(i % 8, per_chain=False)
@@ -667,11 +676,12 @@ def main():
             sec = (time.perf_counter() - t1) / reps
             cms, cn = m.profile_read(2)
             m.profile(False)
-            for h_, p_ in zip(hs, poses):  # the chains go back to where the other legs expect them
-                setp(h_, C_.c_double(p_[0]), C_.c_double(p_[1]), C_.c_double(p_[2]))
-            return {"chains_per_enqueue": n, "gpu_us_per_enqueue": cms / max(cn, 1) * 1e3, "hypotheses_per_s_gpu": hyp_per_match * n / (cms / max(cn, 1) * 1e-3),
-                    "wall_us_per_enqueue": sec * 1e6, "host_pose_writes_us_per_enqueue": host / reps * 1e6,
-                    "what": "every base scan re-posed before every enqueue (point cache misses on all of them)"}
+            setp(hs, poses.ctypes.data_as(dp), len(flat))  # the chains go back to where the other legs expect them
+            return {"chains_per_enqueue": n, "scans_reposed_per_enqueue": len(flat), "gpu_us_per_enqueue": cms / max(cn, 1) * 1e3,
+                    "hypotheses_per_s_gpu": hyp_per_match * n / (cms / max(cn, 1) * 1e-3),
+                    "wall_us_per_enqueue": sec * 1e6, "hypotheses_per_s": hyp_per_match * n / sec,
+                    "host_pose_writes_us_per_enqueue": host / reps * 1e6,
+                    "what": "every base scan re-posed (one ym_scans_set_poses call) before every enqueue: point cache misses on all of them, no plan replay"}
 
         if rank == 0 and not args.no_production_legs:
             sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold)]

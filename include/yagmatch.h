@@ -120,6 +120,10 @@ int ym_synchronize(ym_matcher *m);
  * at the same time). */
 ym_scan *ym_scan_create(int device, const ym_scan_desc *desc);
 int ym_scan_set_pose(ym_scan *s, double x, double y, double heading);
+/* n poses (x, y, heading) written to n scans in one call -- what the reference does scan by scan after every graph
+ * optimisation (/root/reference/yag_slam/graph_slam.py:263-272: `vtx.obj.corrected_pose = ...` for EVERY vertex, one pybind11
+ * write each, /root/reference/yag_slam/models.py:67-75).  All or nothing: a null entry fails the call before any pose is written. */
+int ym_scans_set_poses(ym_scan *const *scans, const double *xyz, int n);
 int ym_scan_get_pose(const ym_scan *s, double pose[3]);
 int ym_scan_size(const ym_scan *s);
 /* 1: the scan's trigger-chain structure, computed once at creation in the sensor frame, holds at every pose (no distance

@@ -200,6 +200,16 @@ def test_device_chained_sequence_recovers_from_faults():
             assert max(abs(pa.x - pb.x), abs(pa.y - pb.y), abs(pa.euler[-1] - pb.euler[-1])) <= 1e-9, (name, i)
         if name == "jump":
             assert max(r.meta["expansions"] for r in dev_out[1:]) >= 1
+        if name == "shrunk":
+            # On a matcher's first chained step every tile of the fresh window is launched, far more than the (shrunk)
+            # rectangle the step may stamp; the fault has to come from THAT rectangle, or stamps outside it stay in the
+            # window for good (nothing marks their tiles dirty).  One more match on the same window memory against the
+            # same match on a fresh matcher: byte-identical windows.
+            probe, fresh = dev_scans[n - 1].copy(), ScanMatcher()
+            a, b = dm.match_scan(probe, dev.running_scans, True, True), fresh.match_scan(probe, dev.running_scans, True, True)
+            assert a.response == b.response and a.covariance == b.covariance
+            (ga, ia), (gb, ib) = dm.debug_grid(), fresh.debug_grid()
+            assert ga.shape == gb.shape and np.array_equal(ga, gb)
 
 
 def test_cfg4_loop_batch_4096_distinct_chains_against_oracle():

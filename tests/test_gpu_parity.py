@@ -462,6 +462,54 @@ def test_c_abi_error_behaviour():
     assert L.ym_debug_grid_info(m._m, 5, C.byref(info)) == -1
 
 
+def test_bulk_pose_write_equals_the_per_scan_writes():
+    """ym_scans_set_poses / models.set_corrected_poses (graph_slam.py:263-272: every vertex re-posed after an optimisation):
+    the same poses on the device twins and the same match as one ym_scan_set_pose per scan; a resident batch enqueued again
+    sees the move (its plan is not replayed); a null entry fails the call before anything is written."""
+    import ctypes as C
+    from yag_slam_amd import _capi, synth
+    from yag_slam_amd.models import set_corrected_poses
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    L = _capi.lib()
+    m = ScanMatcher()
+    q, base = synth.single_match_scans()
+    q2, base2 = synth.single_match_scans()
+    for s in (q, q2, *base, *base2):
+        s.native(0)
+    rng = np.random.default_rng(5)
+    moved = np.array([(s.corrected_pose.x + rng.normal(0, 0.02), s.corrected_pose.y + rng.normal(0, 0.02),
+                       s.corrected_pose.euler[-1] + rng.normal(0, 0.01)) for s in base])
+    for s, p in zip(base, moved):                       # one write per scan
+        s.corrected_pose = Transform(p[0], p[1], 0.0, p[2])
+    batch = m.make_batch(q2, [base2, base2[:5]])
+    batch.run_async(True, True)
+    before = batch.wait()[0]
+    set_corrected_poses(base2, moved)                   # one call
+    pose = (C.c_double * 3)()
+    for s, p in zip(base2, moved):
+        assert L.ym_scan_get_pose(s._native, pose) == 0 and tuple(pose) == tuple(p)
+        cp = s.corrected_pose
+        assert (cp.x, cp.y, cp.euler[-1]) == tuple(p)
+    a, b = m.match_scan(q, base, True, True), m.match_scan(q2, base2, True, True)
+    assert a.response == b.response and a.covariance == b.covariance
+    assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+    batch.run_async(True, True)
+    after = batch.wait()[0]
+    assert after[0].response == a.response and before[0].response != after[0].response
+    # Transforms instead of an array; scans without a twin are only written on the Python side
+    plain = synth.single_match_scans()[1][:3]
+    set_corrected_poses(plain + base2[:2], [Transform(1.0 + i, 2.0, 0.0, 0.1) for i in range(5)])
+    assert plain[2].corrected_pose.x == 3.0 and plain[0]._native is None
+    assert L.ym_scan_get_pose(base2[1]._native, pose) == 0 and tuple(pose) == (5.0, 2.0, 0.1)
+    # all or nothing
+    hs = (C.c_void_p * 3)(base2[0]._native, None, base2[2]._native)
+    xyz = (C.c_double * 9)(*([9.0] * 9))
+    assert L.ym_scans_set_poses(hs, xyz, 3) == -1
+    assert L.ym_scan_get_pose(base2[0]._native, pose) == 0 and tuple(pose) == (4.0, 2.0, 0.1)
+    assert L.ym_scans_set_poses(None, None, 0) == 0
+
+
 def _random_case(seed):
     """seeded random scene, sensor, poses and matcher config -> (cfg, query, base scans, penalty, fine)"""
     from yag_slam_amd import synth

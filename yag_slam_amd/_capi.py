@@ -15,7 +15,7 @@ SEM = {"karto": 0, "yagpy": 1}
 
 EXPORTS = (
     "ym_version", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
-    "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scan_get_pose",
+    "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scans_set_poses", "ym_scan_get_pose",
     "ym_scan_size", "ym_scan_structure_trusted", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_map_sequence", "ym_process_scan", "ym_sequence_stats", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
     "ym_batch_run_async", "ym_batch_wait", "ym_debug_grid_info",
@@ -148,6 +148,7 @@ def lib():
     L.ym_scan_create.restype = vp
     L.ym_scan_create.argtypes = [C.c_int, C.POINTER(YmScanDesc)]
     L.ym_scan_set_pose.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    L.ym_scans_set_poses.argtypes = [C.POINTER(vp), dp, C.c_int]
     L.ym_scan_get_pose.argtypes = [vp, dp]
     L.ym_scan_size.argtypes = [vp]
     L.ym_scan_destroy.argtypes = [vp]

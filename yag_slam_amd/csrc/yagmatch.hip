@@ -274,7 +274,7 @@ struct ym_scan {
     // written by structure_kernel into the scan's staging slot and read when the scan is first used (scan_resolve)
     mutable int32_t cnp[2] = {0, 0};
     mutable bool gov_ok[2] = {false, false};
-    mutable struct ScanStage *stage = nullptr; // != null: the upload + structure launch of ym_scan_create is not known to be complete yet
+    mutable std::atomic<struct ScanStage *> stage{nullptr}; // != null: the upload + structure launch of ym_scan_create is not known to be complete yet
     size_t block_bytes = 0;                 // != 0: d_ranges is a block of this size of the device's scan pool (0: its own hipMalloc)
     int n;
     double min_angle, max_angle, angle_inc, min_range, max_range, range_threshold;
@@ -395,9 +395,28 @@ int pool_create_scan(ScanPool &p, ym_scan *s, const double *ranges, size_t total
     const size_t bytes = align_up(total, 1024);
     unsigned char *base = static_cast<unsigned char *>(pool_block(p, bytes));
     if (!base) return set_err(YM_ERR_HIP, "cannot allocate device ranges");
-    ScanStage &st = p.stages[p.next_stage++ % kScanStages];
+    // a staging slot no synchronous match of another thread is reading (staged_query; readers change under p.mu only upwards,
+    // so a slot seen free here stays free): never WAIT for a reader with the mutex held -- its thread may need the mutex
+    // (scan_resolve) before it lets go
+    ScanStage *free_stage = nullptr;
+    for (int tries = 0; tries < kScanStages && !free_stage; tries++) {
+        ScanStage &c = p.stages[p.next_stage++ % kScanStages];
+        if (c.readers.load(std::memory_order_acquire) == 0) free_stage = &c;
+    }
+    if (!free_stage) { // (64 matches in flight on freshly created scans: upload the plain way, the matchers compute the chain per pose)
+        if (hipMemcpy(base, ranges, sizeof(double) * s->n, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            p.free_blocks[bytes].push_back(base);
+            return set_err(YM_ERR_HIP, "cannot upload ranges");
+        }
+        s->d_ranges = reinterpret_cast<double *>(base);
+        s->block_bytes = bytes;
+        s->gov_ok[0] = s->gov_ok[1] = false;
+        *base_out = base;
+        return YM_OK;
+    }
+    ScanStage &st = *free_stage;
     stage_wait(p, st); // (the slot's previous user, 64 creations ago)
-    while (st.readers.load(std::memory_order_acquire) > 0) __builtin_ia32_pause(); // (another thread's match is reading it)
     std::memcpy(st.host, ranges, sizeof(double) * s->n);
     st.serial = ++p.serial ? p.serial : ++p.serial;
     s->d_ranges = reinterpret_cast<double *>(base);
@@ -1386,14 +1405,16 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.ltx = std::max(0, launch[2] - launch[0] + 1);
     P.lty = std::max(0, launch[3] - launch[1] + 1);
     if (call.chain_step) {
-        // what prepare_kernel checks every kept cell against: a cell whose smear would reach a tile this call does not launch
-        // (the window's own edge is no limit) is a fault of the step
+        // what prepare_kernel checks every kept cell against: a cell whose smear would reach a tile outside `want` (the
+        // window's own edge is no limit) is a fault of the step.  `want`, not `launch`: the launch also covers the tiles that
+        // may still hold an earlier call's stamps (and, on a window's first call, every tile), but item_dirty above says that
+        // after this call only `want` can hold non-zero bytes -- a stamp in launch \ want would never be cleared again.
         const int h = g.half_kernel;
-        P.cell_box[0] = launch[0] <= 0 ? INT32_MIN : launch[0] * YM_TILE_W + h;
-        P.cell_box[1] = launch[1] <= 0 ? INT32_MIN : launch[1] * P.tile_h + h;
-        P.cell_box[2] = launch[2] >= tiles_x - 1 ? INT32_MAX : (launch[2] + 1) * YM_TILE_W - 1 - h;
-        P.cell_box[3] = launch[3] >= tiles_y - 1 ? INT32_MAX : (launch[3] + 1) * P.tile_h - 1 - h;
-        if (P.ltx <= 0 || P.lty <= 0) { P.cell_box[0] = P.cell_box[1] = INT32_MAX; P.cell_box[2] = P.cell_box[3] = INT32_MIN; } // nothing launched
+        P.cell_box[0] = want[0] <= 0 ? INT32_MIN : want[0] * YM_TILE_W + h;
+        P.cell_box[1] = want[1] <= 0 ? INT32_MIN : want[1] * P.tile_h + h;
+        P.cell_box[2] = want[2] >= tiles_x - 1 ? INT32_MAX : (want[2] + 1) * YM_TILE_W - 1 - h;
+        P.cell_box[3] = want[3] >= tiles_y - 1 ? INT32_MAX : (want[3] + 1) * P.tile_h - 1 - h;
+        if (want[2] < want[0] || want[3] < want[1]) { P.cell_box[0] = P.cell_box[1] = INT32_MAX; P.cell_box[2] = P.cell_box[3] = INT32_MIN; } // nothing may be stamped
     }
     P.tile_cap = std::max(1, P.ltx * P.lty);
     // a work list pays for its extra launch once the items are many
@@ -1862,6 +1883,10 @@ int launch_call(ym_matcher *m, Slot &slot) {
     const uint64_t before = m->call_counter;
     const int rc = launch_call_body(m, slot);
     if (rc != YM_OK) {
+        // a call abandoned after its pair lists were forked onto the second stream: whatever is queued there (bin_kernel
+        // writes the shared list buffers) is ordered before the next call's work on the main stream
+        if (m->side_stream && m->ev_join && hipEventRecord(m->ev_join, m->side_stream) == hipSuccess)
+            (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
         if (m->call_counter != before)
             for (ym_matcher::CacheEntry &ce : m->cache_entries)
                 if (ce.stale_in_call == m->call_counter) ce.pose[0] = ce.pose[1] = ce.pose[2] = std::nan("");
@@ -2281,6 +2306,19 @@ int ym_scan_set_pose(ym_scan *s, double x, double y, double heading) {
     return YM_OK;
 }
 
+int ym_scans_set_poses(ym_scan *const *scans, const double *xyz, int n) {
+    if (n < 0 || (n > 0 && (!scans || !xyz))) return set_err(YM_ERR_INVALID, "null argument");
+    for (int i = 0; i < n; i++)
+        if (!scans[i]) return set_err(YM_ERR_INVALID, "null scan %d", i); // (nothing is written unless every scan can be)
+    if (n > 0) g_pose_epoch.fetch_add(1, std::memory_order_relaxed);
+    for (int i = 0; i < n; i++) {
+        ym_scan *s = scans[i];
+        s->pose[0] = xyz[3 * (size_t)i]; s->pose[1] = xyz[3 * (size_t)i + 1]; s->pose[2] = xyz[3 * (size_t)i + 2];
+        world_bbox(s->lbox, s->pose, s->wbox);
+    }
+    return YM_OK;
+}
+
 int ym_scan_get_pose(const ym_scan *s, double pose[3]) {
     if (!s || !pose) return set_err(YM_ERR_INVALID, "null argument");
     pose[0] = s->pose[0]; pose[1] = s->pose[1]; pose[2] = s->pose[2];
@@ -2451,13 +2489,19 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
     HIP_TRY(hipMemsetAsync(m->seq_fault.p, 0, sizeof(int32_t), m->stream));
     Slot &slot = m->slots[kAsyncSlots];
     if (slot.in_flight) return set_err(YM_ERR_BUSY, "the matcher's synchronous slot holds a call in flight");
-    int enqueued = 0;
+    // the poses the caller set: the dead-reckoned priors below overwrite them, and the scans a fault (or an error) leaves
+    // unmatched get them back -- only matched scans are touched, as the header says
+    std::vector<double> caller_pose(3 * (size_t)n_seg);
+    for (int k = 0; k < n_seg; k++)
+        for (int c = 0; c < 3; c++) caller_pose[3 * (size_t)k + c] = scans[lo + k]->pose[c];
+    int enqueued = 0, posed = 0;
     for (int i = lo; i < hi; i++, enqueued++) {
         double inv[3], diff[3], prior[3], next_diff[3] = {0, 0, 0};
         tf_inverse(odom + 3 * (size_t)(i - 1), inv);
         tf_compose(inv, odom + 3 * (size_t)i, diff);
         tf_compose(scans[i - 1]->pose, diff, prior); // (scan i - 1: its true pose for i == lo, else what the odometry predicts)
         if ((rc = ym_scan_set_pose(scans[i], prior[0], prior[1], prior[2]))) break;
+        posed = i - lo + 1;
         if (i + 1 < hi) {
             tf_inverse(odom + 3 * (size_t)i, inv);
             tf_compose(inv, odom + 3 * (size_t)(i + 1), next_diff);
@@ -2483,11 +2527,16 @@ static int sequence_segment_chained(ym_matcher *m, ym_scan *const *scans, const 
             break;
         }
     }
+    auto restore_from = [&](int k0) {
+        for (int k = k0; k < posed; k++)
+            (void)ym_scan_set_pose(scans[lo + k], caller_pose[3 * (size_t)k], caller_pose[3 * (size_t)k + 1], caller_pose[3 * (size_t)k + 2]);
+    };
     int32_t fault = 0;
     hipError_t herr = hipMemcpyAsync(&fault, m->seq_fault.p, sizeof fault, hipMemcpyDeviceToHost, m->stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(m->stream);
-    if (herr != hipSuccess) return set_err(YM_ERR_HIP, "%s", hipGetErrorString(herr));
+    if (herr != hipSuccess) { restore_from(0); return set_err(YM_ERR_HIP, "%s", hipGetErrorString(herr)); }
     const int good = std::min(enqueued, fault > 0 ? fault - lo : enqueued);
+    restore_from(good);
     const YmItemState *hs = reinterpret_cast<const YmItemState *>(m->seq_results.p);
     for (int k = 0; k < good; k++) {
         const int i = lo + k;

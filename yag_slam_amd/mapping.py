@@ -7,6 +7,7 @@ chain of the last `scan_buffer_len` scans (default 10, graph_slam.py:47,336-337)
 optimiser, no loop closure here -- this only drives the matcher the way yag-slam does, with every
 scan resident on the device (one upload per new scan, poses written through).
 """
+from .models import set_corrected_poses
 from .transform import Transform
 
 
@@ -241,8 +242,8 @@ class LoopClosingMapper(SequentialMapper):
         """graph_slam.py:262-272; a no-op without an optimizer except for the spatial index refresh"""
         if self.opt is not None:
             self.opt.compute(100, 1.0e-4, True, 1.0e-9, 50)
-            for node, s in zip(self.opt.nodes, self.scans):
-                s.corrected_pose = Transform(node.x, node.y, 0.0, node.yaw)
+            n = min(len(self.opt.nodes), len(self.scans))  # (zip's length, as graph_slam.py:268)
+            set_corrected_poses(self.scans[:n], [Transform(node.x, node.y, 0.0, node.yaw) for node in self.opt.nodes[:n]])
         self.index.rebuild(self.scans)
 
     def process_scan(self, scan):

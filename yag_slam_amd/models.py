@@ -25,6 +25,32 @@ def point_readings(ranges, x, y, t, min_angle, angle_increment, range_threshold)
     return x + r[idx] * np.cos(ang), y + r[idx] * np.sin(ang)
 
 
+def set_corrected_poses(scans, poses):
+    """`scan.corrected_pose = pose` for many scans at once: what `GraphSlam.run_opt` does vertex by vertex after every
+    optimisation (/root/reference/yag_slam/graph_slam.py:263-272, one pybind11 write per scan through models.py:67-75).
+    poses: Transforms, or an (n, 3) array of (x, y, heading).  The Python side is updated scan by scan; the device twins
+    get ONE ym_scans_set_poses call (one pose-epoch bump instead of n ctypes calls)."""
+    scans = list(scans)
+    if isinstance(poses, np.ndarray):
+        xyz = np.ascontiguousarray(poses, dtype=np.float64).reshape(len(scans), 3)
+        tfs = [Transform(float(p[0]), float(p[1]), 0.0, float(p[2])) for p in xyz]
+    else:
+        tfs = list(poses)
+        if len(tfs) != len(scans):
+            raise ValueError("set_corrected_poses: %d scans, %d poses" % (len(scans), len(tfs)))
+        xyz = np.array([(float(p.x), float(p.y), float(p.euler[-1])) for p in tfs], dtype=np.float64).reshape(len(scans), 3)
+    resident = [i for i, s in enumerate(scans) if getattr(s, "_native", None) is not None]
+    if resident:
+        handles = (C.c_void_p * len(resident))(*[scans[i]._native for i in resident])
+        sub = xyz if len(resident) == len(scans) else np.ascontiguousarray(xyz[resident])
+        _capi.check(_capi.lib().ym_scans_set_poses(handles, sub.ctypes.data_as(C.POINTER(C.c_double)), len(resident)))
+    for s, tf in zip(scans, tfs):
+        if isinstance(s, LocalizedRangeScan):
+            s._corrected_pose = tf      # (the twin is already written)
+        else:
+            s.corrected_pose = tf       # any other scan type: its own setter
+
+
 class LocalizedRangeScan:
     def __init__(self, ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold,
                  x, y, t):

@@ -498,8 +498,10 @@ class MatchBatch(object):
 
     def push_poses(self):
         """Write the scans' current corrected poses through to their device twins."""
-        for s in [self.query] + self._flat:
-            self.m._push_pose(s)
+        scans = [self.query] + self._flat
+        hs = self.m._handles(scans)
+        xyz = np.array([_pose_of(s) for s in scans], dtype=np.float64).reshape(len(scans), 3)
+        _capi.check(self.m._lib.ym_scans_set_poses((C.c_void_p * len(hs))(*hs), xyz.ctypes.data_as(C.POINTER(C.c_double)), len(hs)))
 
     def run_async(self, penalty=False, do_fine=False, slot=0, chain_id_base=0, dev_best_out=None):
         _capi.check(self.m._lib.ym_batch_run_async(self.m._m, self._h, int(bool(penalty)), int(bool(do_fine)), int(slot),
