@@ -197,7 +197,8 @@ struct CallPlan {
     // batches on the default-sized lattices (up to 26 x 32): the region-staged correlate (ym_k_region.hpp)
     bool region26 = false;
     bool fuse_score = false;  // ... also scores (no score_kernel launch)
-    int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1;
+    int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1, rg_nregions = 0;
+    bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
     // always scores its sums
@@ -527,6 +528,8 @@ struct ym_matcher {
     DevBuf<uint16_t> rg_entries; // region correlate: per query slot of a call the (beam, angle) pairs sorted by region
     DevBuf<int32_t> rg_starts;
     DevBuf<uint32_t> rg_rbox;    // per query slot, region and angle block: the box its patches read of the region
+    DevBuf<uint32_t> rg_walk;    // per query slot and angle block: the walk of the wave-specialised region correlate (region_walk_kernel)
+    int n_cus = 0;               // compute units of the device
     size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
     int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
     uint64_t cache_gen = 1;      // bumped whenever the point cache changes (entries created, re-posed, dropped) or an option is set
@@ -540,6 +543,8 @@ struct ym_matcher {
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
+    int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
+    int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     // gather correlate: per query slot of a call the (beam, angle) units sorted by region, the bin table, the work
     // lists and the counters they are built with; the lane -> (row, segment) table of the lattice
@@ -913,22 +918,31 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     // walk is one long chain.
     {
         const int half_w = (g.win_w + 1) / 2;
-        P.rg_nrx = (half_w + YM_RG_W - 1) / YM_RG_W;
-        P.rg_nry = (half_w + YM_RG_H - 1) / YM_RG_H;
-        // sets of 16-bit sums per (item, angle): room for the padding of the entry lists (an item that needs more is scored
-        // by the per-cell path)
-        P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
-        P.rg_nbins = P.rg_nrx * P.rg_nry * lc.nt;
         // (measured, 21 angles: three blocks of 8 waves per CU beat blocks of 7 although the third block of an item idles 3 waves)
         P.rg_nw = m->corr_region_nw > 0 ? std::min(m->corr_region_nw, 16) : lc.nt <= 8 ? lc.nt : 8;
         if (P.rg_nw < 4 || P.rg_nw == 9 || (P.rg_nw > 11 && P.rg_nw != 16)) P.rg_nw = lc.nt <= 4 ? 4 : 8;
         P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
+        // the wave-specialised form: blocks of 8, 11 or 12 gather waves (21 angles = 11 + 10) + 4 loader waves, regions of one class image
+        P.rg_ws = m->corr_region_nw == 0 && m->corr_region_form == 2; // (measured slower than the first form: opt-in, option 32 = 2)
+        if (P.rg_ws) { // (8 gather waves + 8 loader waves per block, two blocks per CU)
+            P.rg_nw = YM_WS_NG;
+            P.rg_parts = (lc.nt + YM_WS_NG - 1) / YM_WS_NG;
+        }
+        const int rg_h = P.rg_ws ? YM_WS_H : YM_RG_H;
+        P.rg_nrx = (half_w + YM_RG_W - 1) / YM_RG_W;
+        P.rg_nry = (half_w + rg_h - 1) / rg_h;
+        P.rg_nregions = P.rg_nrx * P.rg_nry;
+        // sets of 16-bit sums per (item, angle): room for the padding of the entry lists (an item that needs more is scored
+        // by the per-cell path)
+        P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
+        P.rg_nbins = P.rg_nregions * lc.nt;
         P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
                      lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         if (P.region26) {
             P.n_groups = P.rg_ng;
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
+            // (the wave-specialised form's bins are a third more and hold less each: 20 %)
             P.rg_entries_stride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)lc.nt * max_n * 11 / 10 + 63) / 64 * 64);
             P.rg_starts_stride = ((size_t)P.rg_nbins + 1 + 15) / 16 * 16;
         }
@@ -1046,7 +1060,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * YM_N_BOXES(max_n)))) return rc;
     if ((rc = m->grid.ensure((size_t)B * P.grid_stride))) return rc;
-    if ((rc = m->planes.ensure((size_t)B * P.grid_stride + std::max(YM_RG_PLANES_SLACK(g.pitch / 2), YM_GA_PLANES_SLACK(g.pitch / 2, std::max(P.ga_rows, P.ga_nry + P.ga_H), lc.ny, P.ga_P))))) return rc;
+    if ((rc = m->planes.ensure((size_t)B * P.grid_stride + std::max(std::max(YM_RG_PLANES_SLACK(g.pitch / 2), YM_WS_PLANES_SLACK(g.pitch / 2)), YM_GA_PLANES_SLACK(g.pitch / 2, std::max(P.ga_rows, P.ga_nry + P.ga_H), lc.ny, P.ga_P))))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * P.nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * P.dim_stride))) return rc;
@@ -1061,7 +1075,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
     P.resp = call.ext_resp ? call.ext_resp : m->resp.p;
     P.probs = call.ext_probs ? call.ext_probs : m->probs.p;
-    P.fuse_score = P.region26 && !m->keep_sums && m->corr_fuse_score != 2;
+    P.fuse_score = P.region26 && !P.rg_ws && !m->keep_sums && m->corr_fuse_score != 2;
     P.k_begin = call.slice ? std::max(0, call.k_begin) : 0;
     P.k_end = call.slice ? std::min(lc.nt, call.k_end) : lc.nt;
     if (call.slice && (yag || B != 1)) return set_err(YM_ERR_UNSUPPORTED, "angle-sliced matches are single Karto matches");
@@ -1192,7 +1206,8 @@ int plan_jobs(ym_matcher *m, Slot &slot, CallPlan &P, bool replay = false) {
         if (P.region26) { // the region correlate's lists: one per query slot
             if ((rc = m->rg_entries.ensure((size_t)n_q * P.rg_entries_stride))) return rc;
             if ((rc = m->rg_starts.ensure((size_t)n_q * P.rg_starts_stride))) return rc;
-            if ((rc = m->rg_rbox.ensure((size_t)n_q * P.rg_nrx * P.rg_nry * P.rg_parts))) return rc;
+            if ((rc = m->rg_rbox.ensure((size_t)n_q * P.rg_nregions * P.rg_parts))) return rc;
+            if (P.rg_ws && (rc = m->rg_walk.ensure((size_t)n_q * P.rg_parts * YM_WS_WALK_WORDS))) return rc;
         }
         if (P.region) { // the gather correlate's lists: one set per query slot
             if ((rc = m->ga_units.ensure((size_t)n_q * P.ga_units_stride))) return rc;
@@ -1590,23 +1605,29 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
     r.g = P.g; r.lat = P.lc; r.grid = m->grid.p; r.planes = m->planes.p; r.grid_stride = P.grid_stride; r.ctrig = m->ctrig.p;
     r.hypcell = m->hypcell.p; r.states = m->states.p; r.qrep = P.d_qrep; r.entries = m->rg_entries.p; r.entries_stride = P.rg_entries_stride;
     r.starts = m->rg_starts.p; r.starts_stride = P.rg_starts_stride; r.partial = m->partial.p; r.partial_stride = P.partial_stride;
-    r.rbox = m->rg_rbox.p; r.rbox_stride = (size_t)P.rg_nrx * P.rg_nry * P.rg_parts; r.nw = P.rg_nw; r.parts = P.rg_parts;
+    r.rbox = m->rg_rbox.p; r.rbox_stride = (size_t)P.rg_nregions * P.rg_parts; r.nw = P.rg_nw; r.parts = P.rg_parts;
     r.nt_stride = P.nt_stride; r.dim_stride = P.dim_stride; r.nrx = P.rg_nrx; r.nry = P.rg_nry; r.ng = P.rg_ng; r.nbins = P.rg_nbins;
-    r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = 0; r.stamps = P.stamps;
+    r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = m->corr_region_dbg; r.stamps = P.stamps;
     r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
     r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
+    r.rg_h = P.rg_ws ? YM_WS_H : YM_RG_H; r.rg_cls = P.rg_ws ? YM_WS_CLS : YM_RG_CLS; r.rg_zero = P.rg_ws ? YM_WS_ZERO : YM_RG_ZERO; r.pad2 = 0;
+    r.rg_w = 0; r.rg_pitch = YM_RG_PITCH; r.nregions = P.rg_nregions; r.pad3 = 0;
+    r.walk = m->rg_walk.p; r.nitems = P.B;
+    // teams of `parts` blocks per XCD: two blocks per CU, no more teams than the XCD gets items
+    r.gpx = std::max(1, std::min((2 * std::max(m->n_cus, 8) / 8) / std::max(1, P.rg_parts), (P.B + 7) / 8));
     return r;
 }
 
 // bin_kernel, once per query slot of the call: after the prepare stage (item states, hypothesis cells, angle tables)
 int enqueue_region_lists(ym_matcher *m, const CallPlan &P, hipStream_t st) {
     const ym::RegionArgs r = region_args(m, P);
-    const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nrx * P.rg_nry * P.rg_parts);
+    const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nregions * P.rg_parts);
     if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
         m->bin_lds_limit = bin_lds;
     }
     hipLaunchKernelGGL(ym::bin_kernel, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
+    if (P.rg_ws) hipLaunchKernelGGL(ym::region_walk_kernel, dim3(P.rg_parts, P.n_qslots), dim3(64), 0, st, r);
     return YM_OK;
 }
 
@@ -1644,6 +1665,11 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         else if ((rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts, P.B);
+        if (P.rg_ws) {
+            hipLaunchKernelGGL(ym::correlate_region_ws_kernel, dim3(8 * r.gpx * P.rg_parts), dim3(64 * (YM_WS_NG + YM_WS_NL)), 0, st, r);
+            hipLaunchKernelGGL(ym::region_percell_kernel, rgrid, dim3(64 * YM_WS_NG), 0, st, r);
+            return prof_end(m, ev_k);
+        }
         switch (P.rg_nw) {
         case 4: hipLaunchKernelGGL(ym::correlate_region_kernel<4>, rgrid, dim3(256), 0, st, r); break;
         case 5: hipLaunchKernelGGL(ym::correlate_region_kernel<5>, rgrid, dim3(320), 0, st, r); break;
@@ -2168,6 +2194,11 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     ym_matcher *m = new ym_matcher();
     m->cfg = *cfg;
     m->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+        m->n_cus = cus > 0 ? cus : 256;
+    }
     m->own_stream = nullptr;
     if (build_geometry(m) != YM_OK) { delete m; return nullptr; }
     DevGuard guard(device);
@@ -2202,7 +2233,7 @@ void ym_destroy(ym_matcher *m) {
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->tile_hit_start.release(); m->sel_scratch.release();
-    m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
+    m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
@@ -3182,6 +3213,8 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
+    else if (option == 32) m->corr_region_form = value;
+    else if (option == 33) m->corr_region_dbg = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;
@@ -3209,6 +3242,7 @@ int ym_debug_stamps(ym_matcher *m, int enable, uint64_t *out, int32_t count) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (out && count > 0)
         HIP_TRY(hipMemcpy(out, m->stamps.p, sizeof(uint64_t) * std::min(count, 32), hipMemcpyDeviceToHost));
+    if (enable && !m->stamps_on) HIP_TRY(hipMemset(m->stamps.p, 0, 32 * sizeof(unsigned long long))); // (some slots are counters)
     m->stamps_on = enable != 0;
     return YM_OK;
 }

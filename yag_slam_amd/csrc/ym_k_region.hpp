@@ -22,6 +22,23 @@
 
 namespace ym {
 
+// development build (-DYM_RG_PROF=1): every wave of correlate_region_kernel adds the shader clocks it spends per phase to
+// stamps[8 + phase] (0 setup, 1 issue of the next region's loads, 2 gather, 3 barrier after the gather, 4 staging stores,
+// 5 barrier after them, 6 scoring); scripts/dev/region_phases.py
+#ifndef YM_RG_PROF
+#define YM_RG_PROF 0
+#endif
+#if YM_RG_PROF
+#if YM_RG_PROF == 2 // phase 1 in three parts: 7 the next region's box and segment (LDS), 8 its entry list (one global load), 1 the staging loads; 2 gather
+#define YM_RG_PH(i) do { if ((i) == 7 || (i) == 8 || (i) == 1 || (i) == 2 || (i) == 5) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); \
+    if ((i) != 5) ph[(i) == 7 ? 0 : (i) == 8 ? 1 : (i) == 1 ? 2 : 3] += t_ - pt; pt = t_; } } while (0)
+#else
+#define YM_RG_PH(i) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); if ((i) >= 2 && (i) <= 5) ph[(i) - 2] += t_ - pt; pt = t_; } while (0)
+#endif
+#else
+#define YM_RG_PH(i) do { } while (0)
+#endif
+
 #define YM_RG_W 64                            // region width and height in class bytes (128 x 160 window cells): what three
 #define YM_RG_H 80                            // blocks per CU leave room for in LDS
 #define YM_RG_PITCH 100                       // LDS bytes per staged row: 25 dwords, odd -> 26 rows on 26 distinct banks
@@ -80,6 +97,15 @@ struct RegionArgs {
     double *probs;           // [B][ny*nx] max over theta per (x, y); zeroed by the prepare stage
     size_t probs_stride;
     int32_t n_blocks, pad;
+    // the region geometry the lists are built for (the two correlate kernels stage regions of different heights): class rows a
+    // region owns, LDS bytes from one class image to the next, LDS offset of the all-zero patch the padding entries point at
+    int32_t rg_h, rg_cls, rg_zero, pad2;
+    // wave-specialised form (rg_w != 0): a region is ONE class image, rg_w class bytes x rg_h class rows, staged at a row
+    // pitch of rg_pitch bytes; region index = (ry * nrx + rx) * 4 + class; nregions = 4 * nrx * nry (else nrx * nry)
+    int32_t rg_w, rg_pitch, nregions, pad3;
+    // wave-specialised form: the walks (region_walk_kernel: [Q][parts][YM_WS_WALK_WORDS]), items of the call, block teams per XCD
+    uint32_t *walk;
+    int32_t nitems, gpx;
     unsigned long long *stamps;
 };
 
@@ -92,13 +118,24 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
     const int X = cx0 + cell.x, Y = cy0 + cell.y;
     if (X < 0 || Y < 0) return false;
     const unsigned xc = (unsigned)X >> 1, yc = (unsigned)Y >> 1;
-    const unsigned rx = xc / (unsigned)YM_RG_W, ry = yc / (unsigned)YM_RG_H;
+    const unsigned cls = (unsigned)((X & 1) | ((Y & 1) << 1));
+    if (a.rg_w) { // one class image per region
+        const unsigned rx = xc / (unsigned)a.rg_w, ry = yc / (unsigned)a.rg_h;
+        if ((int)rx >= a.nrx || (int)ry >= a.nry) return false;
+        region = (int)((ry * (unsigned)a.nrx + rx) * 4u + cls);
+        bin = region * a.lat.nt + k;
+        er = yc - ry * (unsigned)a.rg_h;
+        ex = xc - rx * (unsigned)a.rg_w;
+        entry = er * (unsigned)a.rg_pitch + ex;
+        return true;
+    }
+    const unsigned rx = xc / (unsigned)YM_RG_W, ry = yc / (unsigned)a.rg_h;
     if ((int)rx >= a.nrx || (int)ry >= a.nry) return false;
     region = (int)(ry * (unsigned)a.nrx + rx);
     bin = region * a.lat.nt + k;
-    er = yc - ry * YM_RG_H;
+    er = yc - ry * (unsigned)a.rg_h;
     ex = xc - rx * YM_RG_W;
-    entry = (unsigned)(((X & 1) | ((Y & 1) << 1)) * YM_RG_CLS) + er * YM_RG_PITCH + ex;
+    entry = cls * (unsigned)a.rg_cls + er * YM_RG_PITCH + ex;
     return true;
 }
 
@@ -120,7 +157,7 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(regions_used + 1);             // [nbins] four 16-bit counters (one per
                                                                                          // misalignment), later the runs' first positions
     unsigned short *ent = reinterpret_cast<unsigned short *>(cnt + a.nbins);             // [entries_stride]
-    const int nboxes = a.nrx * a.nry * a.parts;
+    const int nboxes = a.nregions * a.parts;
     unsigned (*box)[4] = reinterpret_cast<unsigned (*)[4]>(bin_smem + ((reinterpret_cast<unsigned char *>(ent + a.entries_stride) - bin_smem) + 15) / 16 * 16); // [nboxes] rmin, rmax, xmin, xmax
     const int qs = blockIdx.x, b = a.qrep[qs], tid = threadIdx.x, lane = tid & 63;
     const YmItemState &st = a.states[b];
@@ -233,10 +270,10 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
                 unsigned fill[4];
                 for (int r = 0; r < 4; r++) { // run r: its entries from pos on (placed below), then the padding
                     fill[r] = (unsigned)pos;
-                    if (fits && (c[r] & 1)) ent[pos + c[r]] = (unsigned short)(YM_RG_ZERO + r);
+                    if (fits && (c[r] & 1)) ent[pos + c[r]] = (unsigned short)(a.rg_zero + r);
                     pos += (c[r] + 1) & ~1;
                 }
-                if (fits && ((pos - run) & 3)) { ent[pos] = (unsigned short)YM_RG_ZERO; ent[pos + 1] = (unsigned short)YM_RG_ZERO; }
+                if (fits && ((pos - run) & 3)) { ent[pos] = (unsigned short)a.rg_zero; ent[pos + 1] = (unsigned short)a.rg_zero; }
                 pos = run + ((pos - run + 3) & ~3);
                 cnt[first + j][0] = fill[0] | fill[1] << 16;
                 cnt[first + j][1] = fill[2] | fill[3] << 16;
@@ -363,7 +400,14 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         flushed++;
         in_set = 0;
     };
+#if !YM_RG_PROF
     YM_STAMP(a, 8);
+#endif
+#if YM_RG_PROF
+    uint32_t ph[4] = {0u, 0u, 0u, 0u};
+    uint32_t pt = (uint32_t)__builtin_amdgcn_s_memtime();
+    const uint32_t pt_begin = pt;
+#endif
     const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
     if (regular) {
         const int k_lo = p * NW, k_hi = min(nt, k_lo + NW);
@@ -503,6 +547,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             elist[wave][lane] = ev;
         }
         __syncthreads();
+        YM_RG_PH(0);
         for (int ri = 0; ri < nlist; ri++) {
             // two-stage pipeline: the global loads of the next region are in flight (registers) while this one is gathered
             const bool has_next = ri + 1 < nlist;
@@ -511,17 +556,24 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             if (has_next) {
                 nbx = __builtin_amdgcn_readfirstlane(rboxl[ri + 1]);
                 segment(ri + 1, n0, n2);
+                YM_RG_PH(7);
                 entries_load(n0, n2);
+                YM_RG_PH(8);
                 stage_load(rlist[ri + 1], nbx);
             }
+            YM_RG_PH(1);
             gather(s0, s2);
+            YM_RG_PH(2);
             __syncthreads(); // every wave is done with region ri
+            YM_RG_PH(3);
             if (has_next) {
                 stage_store(nbx);
                 elist[wave][lane] = ev;
             }
             s0 = n0; s2 = n2;
+            YM_RG_PH(4);
             __syncthreads();
+            YM_RG_PH(5);
         }
     } else if (kvalid && job) {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path over the window
@@ -547,7 +599,17 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             flush();
         }
     }
+#if !YM_RG_PROF
     YM_STAMP(a, 9);
+#endif
+#if YM_RG_PROF
+    auto prof_out = [&]() {
+        if (a.stamps && lane == 0) {
+            for (int i = 0; i < 4; i++) atomicAdd(a.stamps + 10 + i, (unsigned long long)ph[i]);
+            atomicAdd(a.stamps + 8, (unsigned long long)(pt - pt_begin)); // the wave's whole life
+        }
+    };
+#endif
     if (!a.fuse_score) {
         if (!kvalid) return;
         while (flushed < ng) flush(); // the set being filled, then empty ones
@@ -606,6 +668,323 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     __syncthreads();
     for (int i = tid; i < nxy; i += NT)
         if (pmax[i]) atomicMax(reinterpret_cast<unsigned long long *>(a.probs) + (size_t)b * a.probs_stride + i, pmax[i]);
+#if YM_RG_PROF
+    YM_RG_PH(6);
+    prof_out();
+#endif
+}
+
+// ================================================================== the wave-specialised form (round 4)
+// Phase clocks of correlate_region_kernel (YM_RG_PROF, scripts/dev/region_phases.py, 4096 items): a wave gathers for a
+// quarter of its life.  The rest: 37 % in the issue of the next region's staging loads -- every global_load_dwordx4 of the
+// burst a block fires after its barrier queues behind the others at the CU's one address unit, ~600 clocks each --, 21 % at
+// the barrier after the gather, 15 % in the staging stores and the barrier after them, the block's set-up and scoring.
+// On average 1.5 of a SIMD's six waves are gathering, and the gather loop alone (scripts/exp/rg_proto.hip) reaches its
+// issue rate only from two per SIMD on.  Here the two jobs belong to different waves, and a block does not end with its item:
+//   waves 0 .. NG - 1      GATHER: wave w owns coarse angle p * NG + w of the block's current item, walks the item's regions,
+//                          waits until a region's buffer is FULL, gathers its patches, says DONE, scores its angle, goes on
+//                          to the next item.  No staging, no barrier.
+//   waves NG .. NG + 7     LOAD: two groups of four (one wave per class image); group g fills buffer g, i.e. every other
+//                          region of the stream: loads in registers, waits until every gatherer is DONE with the buffer's
+//                          previous region, stores, says FULL.  They are the ones that wait for memory, and they run ahead
+//                          into the next item while the gatherers finish this one: the pipeline never drains.
+// Two region buffers per block, counters in LDS instead of barriers (full[b] / done[b] only grow; a region's number in the
+// block's stream says what to wait for).  Two blocks of 16 waves per CU, each with its own sequence of (item, angle block)
+// units: the blocks that share an item run on one XCD at the same time (the item's planes in one L2).  What a unit's walk
+// needs -- the regions with work, their boxes, every angle's segment of the entry list -- depends on the QUERY alone and
+// comes from region_walk_kernel, once per query of the call.  Regions own YM_WS_H class rows (two buffers in 80 KB).
+// (Tried and dropped: regions of ONE class image, 256 x 74 class bytes at a pitch of 324 -- rows of 288 contiguous bytes for the
+//  loaders, less margin per owned byte.  A wall's bounding box fills such a region, the walk has 64 rounds of 16 patches per
+//  wave instead of 27 of 43, and a round costs a wave one memory round trip whatever it gathers: 4140 us against 3281.
+//  One loader group with two register sets per wave: a destination register the compiler also uses as a temporary makes it
+//  wait for every load in flight.)
+#define YM_WS_H 56
+#define YM_WS_ROWS (YM_WS_H + 26)
+#define YM_WS_CLS (YM_RG_PITCH * YM_WS_ROWS)
+#define YM_WS_ZERO (4 * YM_WS_CLS)                      // every buffer is followed by its own all-zero patch
+#define YM_WS_ZERO_BYTES (25 * YM_RG_PITCH + 32)        // (the last lane row reads 16 bytes from byte 13 on of patch row 25)
+#define YM_WS_BUF ((YM_WS_ZERO + YM_WS_ZERO_BYTES + 15) / 16 * 16)
+#define YM_WS_NG 8                                      // gather waves (= angles) per block
+#define YM_WS_NL 8                                      // loader waves: two groups of one per class image; group g fills buffer g
+#define YM_WS_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_WS_ROWS + 2 * YM_WS_H + 22) * (size_t)(half_pitch) + 256)
+// a unit's walk (region_walk_kernel): [0] regions with work, [16 + i] region, [16 + MAX + i] box, [16 + 2 MAX + w MAX + i] first
+// entry | end << 16 of gather wave w
+#define YM_WS_WALK_WORDS (16 + (2 + YM_WS_NG) * YM_RG_MAX_REGIONS)
+static_assert(YM_WS_ZERO + YM_WS_ZERO_BYTES < 65536, "entries are 16-bit LDS offsets");
+
+// grid (parts, Q), one wave: the walk of angle block p of query slot q
+__global__ __launch_bounds__(64) void region_walk_kernel(RegionArgs a) {
+    __shared__ int rl[YM_RG_MAX_REGIONS];
+    const int p = blockIdx.x, qs = blockIdx.y, lane = threadIdx.x;
+    const int nt = a.lat.nt, nx = a.lat.nx, ny = a.lat.ny;
+    const int32_t *__restrict__ starts = a.starts + (size_t)qs * a.starts_stride;
+    uint32_t *wk = a.walk + ((size_t)qs * a.parts + p) * YM_WS_WALK_WORDS;
+    if (starts[a.nbins] < 0) { if (lane == 0) wk[0] = 0u; return; } // (no list: the per-cell path)
+    const int k_lo = p * a.nw, k_hi = min(nt, k_lo + a.nw);
+    const int nreg = a.nregions;
+    int n = 0;
+    for (int R0 = 0; R0 < nreg; R0 += 64) {
+        const int R = R0 + lane;
+        const bool has = R < nreg && starts[(size_t)R * nt + k_lo] != starts[(size_t)R * nt + k_hi];
+        const unsigned long long mask = __ballot(has);
+        const int at = n + __popcll(mask & ((1ull << lane) - 1ull));
+        if (has && at < YM_RG_MAX_REGIONS) rl[at] = R;
+        n += __popcll(mask);
+    }
+    n = min(n, YM_RG_MAX_REGIONS); // (bin_kernel refuses a list with more regions in use)
+    __syncthreads();
+    if (lane == 0) wk[0] = (uint32_t)n;
+    const uint32_t *rb = a.rbox + (size_t)qs * a.rbox_stride;
+    const uint32_t reach = (uint32_t)(nx > YM_RG_G ? 15 + YM_RG_G : 15);
+    for (int i = lane; i < n; i += 64) {
+        const int R = rl[i];
+        wk[16 + i] = (uint32_t)R;
+        // what the block's patches read of the region: rows rmin .. rmax + ny - 1, bytes (xmin & ~3) .. xmax + 15 (+ 13 for the
+        // second half of a lattice row)
+        const uint32_t v = rb[(size_t)R * a.parts + p];
+        const uint32_t r0 = v & 0xffu, r1 = min((uint32_t)(YM_WS_ROWS - 1), ((v >> 8) & 0xffu) + (uint32_t)ny - 1u);
+        const uint32_t s0 = ((v >> 16) & 0xfcu) >> 4, s1 = min((uint32_t)(YM_RG_SEGS - 1), ((v >> 24) + reach) >> 4);
+        wk[16 + YM_RG_MAX_REGIONS + i] = r0 | r1 << 8 | s0 << 16 | s1 << 24;
+        for (int w = 0; w < a.nw; w++) {
+            const int k = k_lo + w;
+            wk[16 + (2 + w) * YM_RG_MAX_REGIONS + i] = k < nt ? ((uint32_t)starts[(size_t)R * nt + k] & 0xffffu) | (uint32_t)starts[(size_t)R * nt + k + 1] << 16 : 0u;
+        }
+    }
+}
+
+// grid (parts, B), YM_WS_NG waves: the items the wave-specialised kernel leaves out -- hypothesis cells that are not an exact
+// lattice (possible only through fp rounding), or a query whose lists did not fit -- scored cell by cell over the window.  A
+// block of any other item returns at once.
+__global__ __launch_bounds__(64 * YM_WS_NG) void region_percell_kernel(RegionArgs a) {
+    const int p = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const YmItemState &st = a.states[b];
+    const int32_t *starts = a.starts + (size_t)st.qslot * a.starts_stride;
+    if (st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0) return;
+    const int nt = a.lat.nt, nx = a.lat.nx, ny = a.lat.ny, ng = a.ng;
+    const int k = p * YM_WS_NG + wave;
+    const int row = lane & 31, half = lane >> 5;
+    if (k >= nt) return;
+    const bool job = row < ny && half * YM_RG_G < nx;
+    const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+    const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
+    const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    const int32_t *cy = cx + a.dim_stride;
+    const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+    const int nq = st.nq;
+    for (int gs = 0; gs < ng; gs++) { // set gs = the beams [gs * FLUSH, (gs + 1) * FLUSH)
+        uint32_t acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0u;
+        if (job)
+            for (int j = 0; j < YM_RG_G; j++) {
+                const int ix = half * YM_RG_G + j;
+                if (ix >= nx) break;
+                const int base = cy[row] * lin_pitch(a.g) + cx[ix];
+                unsigned sum = 0;
+                const int i1 = min(nq, (gs + 1) * YM_RG_FLUSH);
+                for (int i = gs * YM_RG_FLUSH; i < i1; i++)
+                    sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
+                acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
+                if ((j & 3) == 2) acc[2 * (j >> 2) + 1] += sum << 8; // (what the sum of dword >> 8 holds of byte 2)
+            }
+        rg_odd(acc);
+        store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)gs * nt + k) * 64 + lane) * 16, acc);
+    }
+}
+
+// grid (8 * gpx * parts): block j runs on XCD j % 8 (workgroups go round the XCDs in launch order); of the gpx * parts
+// blocks of an XCD, `parts` neighbours form a group that works through the items x + 8 (t + gpx s), s = 0, 1, ...
+__global__ __launch_bounds__(64 * (YM_WS_NG + YM_WS_NL), 8 /* two blocks of 16 waves per CU = 8 waves per SIMD */) void correlate_region_ws_kernel(RegionArgs a) {
+    constexpr int NG = YM_WS_NG;
+    constexpr int NT = 64 * (NG + YM_WS_NL);
+    constexpr int LPS = 64 / YM_RG_SEGS;                              // rows a loader wave covers at once (60 of its 64 lanes copy)
+    constexpr int PER = (YM_WS_ROWS + LPS - 1) / LPS;                 // copy tasks per loader thread
+    __shared__ __attribute__((aligned(16))) unsigned char bufs[2 * YM_WS_BUF];
+    __shared__ uint2 elist[NG][32];                   // per gather wave: its first 128 entries of the region it is about to gather
+    __shared__ uint32_t full[2], done[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool gatherer = wave < NG;
+    const int parts = a.parts, gpx = a.gpx;
+    const int xcd = (int)blockIdx.x & 7, qx = (int)blockIdx.x >> 3;
+    const int team = qx / parts, p = qx - team * parts;
+    const int nt = a.lat.nt, nx = a.lat.nx, ny = a.lat.ny, ng = a.ng;
+    const int k = p * NG + wave;
+    const bool kvalid = gatherer && k < nt;
+    const int row = lane & 31, half = lane >> 5;
+    const bool job = row < ny && half * YM_RG_G < nx;
+    const int half_pitch = a.g.pitch / 2;
+    const int plane_bytes = half_pitch * a.g.win_w;
+    const uint32_t lds0 = (uint32_t)(size_t)bufs;
+    const uint32_t lane_part = (uint32_t)((job ? row : 0) * YM_RG_PITCH + (half * YM_RG_G < nx ? half * YM_RG_G : 0));
+    // The counters: a wave that has stored (gathered) says so once, lane 0, after its own LDS operations have completed.
+    // Written out by hand: the release / acquire forms of the atomics also wait for the wave's vector-memory operations
+    // (vmcnt(0): the HIP memory model orders global memory too) -- for a loader that is the next region's loads in flight.
+    // What is needed: the LDS executes a CU's operations in order, so "my stores have completed (lgkmcnt(0)), then the
+    // add" on one side and "the load that saw the count, then my reads" on the other is enough.
+    auto signal = [&](bool is_full, int which) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            if (is_full) __hip_atomic_fetch_add(&full[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_add(&done[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto wait_for = [&](bool is_full, int which, uint32_t target) {
+        for (;;) {
+            // (one lane reads: sixteen waiting loader waves polling with all their lanes take a fifth of the LDS cycles)
+            uint32_t seen = 0u;
+            if (lane == 0)
+                seen = is_full ? __hip_atomic_load(&full[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                               : __hip_atomic_load(&done[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane(seen) - target) >= 0) break;
+            if (is_full) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
+        }
+        asm volatile("" ::: "memory");
+    };
+    for (int i = tid; i < 2 * YM_WS_ZERO_BYTES / 4; i += NT) {
+        const int which = i >= YM_WS_ZERO_BYTES / 4;
+        reinterpret_cast<uint32_t *>(bufs + which * YM_WS_BUF + YM_WS_ZERO)[i - which * (YM_WS_ZERO_BYTES / 4)] = 0u;
+    }
+    if (tid < 2) { full[tid] = 0u; done[tid] = 0u; }
+    __syncthreads(); // (the only barrier)
+    if (team >= gpx) return;
+    uint32_t g = 0u; // regions this block's stream has held so far: region g of the stream lives in buffer g & 1
+    for (int s = 0;; s++) {
+        const int b = xcd + 8 * (team + gpx * s);
+        if (b >= a.nitems) break;
+        const YmItemState &st = a.states[b];
+        const int qslot = __builtin_amdgcn_readfirstlane(st.qslot);
+        const int32_t *__restrict__ starts = a.starts + (size_t)qslot * a.starts_stride;
+        const uint32_t *__restrict__ wk = a.walk + ((size_t)qslot * parts + p) * YM_WS_WALK_WORDS;
+        const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
+        const int nlist = regular ? __builtin_amdgcn_readfirstlane((int)wk[0]) : 0;
+        if (!gatherer) {
+            // ---- LOAD: loader l belongs to group l >> 2 and stages class image l & 3 of the regions g + ri with (g + ri) & 1 = its group.
+            // Lane = one 16-byte segment of the rows r0, r0 + LPS, ...  A loader's round is one exposed memory round trip (load,
+            // wait, store); the two groups' round trips overlap, and with two blocks per CU sixteen loader waves keep 144 KB of
+            // requests in flight, what the first form's 24 waves did.
+            const uint32_t lw = (uint32_t)(wave - NG), cls = lw & 3u;
+            const int grp = (int)(lw >> 2);
+            const uint32_t seg = (uint32_t)lane % YM_RG_SEGS, r0 = (uint32_t)lane / YM_RG_SEGS;
+            const bool copier = lane < LPS * YM_RG_SEGS;
+            const uint32_t src0 = (cls & 1u) * (uint32_t)plane_bytes + (2u * r0 + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
+            const uint32_t src_step = 2u * LPS * (uint32_t)half_pitch;
+            const uint32_t dst0 = (cls * YM_WS_ROWS + r0) * YM_RG_PITCH + 16u * seg;
+            const uint8_t *__restrict__ planes = a.planes + (size_t)b * a.grid_stride;
+            unsigned char *buf = bufs + grp * YM_WS_BUF;
+            uint4 v[PER];
+            auto band_in = [&](int q, uint32_t bx) { // (wave-uniform: a band the box does not reach issues no load and no store)
+                return (uint32_t)(q * LPS) <= ((bx >> 8) & 0xffu) && (uint32_t)(q * LPS + LPS - 1) >= (bx & 0xffu);
+            };
+            // (the unit's walk in two registers per table, one region per lane: a round reads it with v_readlane instead of
+            //  waiting for a memory round trip before it can issue its loads)
+            const uint32_t rlA = lane < nlist ? wk[16 + lane] : 0u, rlB = 64 + lane < nlist ? wk[16 + 64 + lane] : 0u;
+            const uint32_t bxA = lane < nlist ? wk[16 + YM_RG_MAX_REGIONS + lane] : 0u, bxB = 64 + lane < nlist ? wk[16 + YM_RG_MAX_REGIONS + 64 + lane] : 0u;
+            for (int ri = ((g & 1u) == (uint32_t)grp) ? 0 : 1; ri < nlist; ri += 2) {
+                const uint32_t gg = g + (uint32_t)ri;
+                const uint32_t bx = ri < 64 ? __builtin_amdgcn_readlane(bxA, ri) : __builtin_amdgcn_readlane(bxB, ri - 64);
+                const int R = (int)(ri < 64 ? __builtin_amdgcn_readlane(rlA, ri) : __builtin_amdgcn_readlane(rlB, ri - 64));
+                const int RX = R % a.nrx, RY = R / a.nrx;
+                const uint8_t *src = planes + ((size_t)(2 * RY * YM_WS_H) * half_pitch + (size_t)RX * YM_RG_W);
+                const bool seg_in = copier && seg >= ((bx >> 16) & 0xffu) && seg <= (bx >> 24);
+#pragma unroll
+                for (int q = 0; q < PER; q++)
+                    if (band_in(q, bx) && !(a.pad & 1)) v[q] = *reinterpret_cast<const uint4 *>(src + (seg_in ? src0 + (uint32_t)q * src_step : 0u));
+                if (gg >= 2u) wait_for(false, grp, (uint32_t)NG * (gg >> 1)); // the buffer's previous region: every gatherer is done with it
+#pragma unroll
+                for (int q = 0; q < PER; q++) {
+                    uint32_t *d = reinterpret_cast<uint32_t *>(buf + dst0 + (uint32_t)(q * LPS * YM_RG_PITCH));
+                    // (the last band reaches past the class image: rows beyond it belong to the next image)
+                    const bool row_in = (q + 1) * LPS <= YM_WS_ROWS || r0 + (uint32_t)(q * LPS) < (uint32_t)YM_WS_ROWS;
+                    if (band_in(q, bx) && seg_in && row_in && !(a.pad & 1)) { d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w; }
+                }
+                signal(true, grp);
+            }
+            g += (uint32_t)nlist;
+            continue;
+        }
+        // ---- GATHER
+        uint32_t acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0u;
+        int in_set = 0, flushed = 0;
+        auto flush = [&]() {
+            if (flushed < ng) {
+                rg_odd(acc);
+                store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)flushed * nt + k) * 64 + lane) * 16, acc);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = 0u;
+            flushed++;
+            in_set = 0;
+        };
+        if (regular) {
+            const uint2 *__restrict__ entries4 = reinterpret_cast<const uint2 *>(a.entries + (size_t)qslot * a.entries_stride);
+            const uint32_t *__restrict__ wseg = wk + 16 + (2 + wave) * YM_RG_MAX_REGIONS;
+            auto gather = [&](uint32_t lane_off, int lo, int hi) { // entries [lo, hi)
+                const int lds_hi = min(hi, lo + 128);
+                if (lo < lds_hi) {
+                    const uint2 *el = elist[wave];
+                    const int n4 = (lds_hi - lo) >> 2;
+                    // two quads per trip, each read one quad ahead into its own pair of registers
+                    uint2 e0 = el[0], e1 = el[min(1, n4 - 1)];
+                    int c = 0;
+                    for (; c + 1 < n4; c += 2) {
+                        rg_gather4(acc, lane_off, e0);
+                        e0 = el[min(c + 2, n4 - 1)];
+                        in_set += 4;
+                        if (in_set == YM_RG_FLUSH) flush();
+                        rg_gather4(acc, lane_off, e1);
+                        e1 = el[min(c + 3, n4 - 1)];
+                        in_set += 4;
+                        if (in_set == YM_RG_FLUSH) flush();
+                    }
+                    if (c < n4) {
+                        rg_gather4(acc, lane_off, e0);
+                        in_set += 4;
+                        if (in_set == YM_RG_FLUSH) flush();
+                    }
+                }
+                for (int c = lds_hi; c < hi; c += 4) { // (a very long segment)
+                    rg_gather4(acc, lane_off, entries4[c >> 2]);
+                    in_set += 4;
+                    if (in_set == YM_RG_FLUSH) flush();
+                }
+            };
+            // (the wave's segments of the unit's regions, one region per lane: v_readlane per round, not a memory round trip)
+            const uint32_t sgA = (kvalid && lane < nlist) ? wseg[lane] : 0u, sgB = (kvalid && 64 + lane < nlist) ? wseg[64 + lane] : 0u;
+            auto seg_of = [&](int ri) { return ri < 64 ? __builtin_amdgcn_readlane(sgA, ri) : __builtin_amdgcn_readlane(sgB, ri - 64); };
+            int s0 = 0, s2 = 0;
+            if (nlist > 0) {
+                const uint32_t sg = seg_of(0);
+                s0 = (int)(sg & 0xffffu); s2 = (int)(sg >> 16);
+                uint2 ev = make_uint2(0u, 0u);
+                if (s0 + 4 * lane < s2 && lane < 32) ev = entries4[(s0 >> 2) + lane];
+                if (lane < 32) elist[wave][lane] = ev; // (the wave's own list: no other wave reads it)
+            }
+            for (int ri = 0; ri < nlist; ri++) {
+                const uint32_t gg = g + (uint32_t)ri;
+                int n0 = 0, n2 = 0;
+                uint2 ev = make_uint2(0u, 0u);
+                if (ri + 1 < nlist) { // the next region's entries travel while this one is gathered
+                    const uint32_t sg = seg_of(ri + 1);
+                    n0 = (int)(sg & 0xffffu); n2 = (int)(sg >> 16);
+                    if (n0 + 4 * lane < n2 && lane < 32) ev = entries4[(n0 >> 2) + lane];
+                }
+                wait_for(true, (int)(gg & 1u), (uint32_t)(YM_WS_NL / 2) * ((gg >> 1) + 1u));
+                if (!(a.pad & 2)) gather(lds0 + (gg & 1u) * (uint32_t)YM_WS_BUF + lane_part, s0, s2);
+                if (ri + 1 < nlist && lane < 32) elist[wave][lane] = ev;
+                signal(false, (int)(gg & 1u)); // (the reads of this region and the store above have completed)
+                s0 = n0; s2 = n2;
+            }
+            g += (uint32_t)nlist;
+        } else continue; // (an item without a lattice or a list: region_percell_kernel)
+        if (!kvalid) continue;
+        // the sums leave as sets of 16-bit partials; score_kernel turns them into responses (scoring here, in the wave that
+        // holds the sums, saves that kernel's 85 us per 4096 items and costs this one 100 spilled registers)
+        while (flushed < ng) flush(); // the set being filled, then empty ones
+    }
 }
 
 } // namespace ym

@@ -6,6 +6,7 @@ attribute bag yag-slam serialises (graph_slam.py:82-83).  All numerics run in li
 the MI355X; this file only marshals scans and results across the ctypes boundary.
 """
 import ctypes as C
+import os
 import struct
 from collections import namedtuple
 
@@ -132,6 +133,9 @@ class ScanMatcher(object):
         self._m = self._lib.ym_create(C.byref(self._cfg), self.device)
         if not self._m:
             raise _capi.YmError(-1, _capi.last_error())
+        for kv in filter(None, os.environ.get("YM_DEBUG_OPTIONS", "").split(",")):  # development: "32=1,33=2" -> ym_debug_option
+            k, v = kv.split("=")
+            self.debug_option(int(k), int(v))
 
     def close(self):
         if getattr(self, "_m", None):
