@@ -198,6 +198,7 @@ struct CallPlan {
     bool region26 = false;
     bool fuse_score = false;  // ... also scores (no score_kernel launch)
     int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1, rg_nregions = 0;
+    int rg_rsplit = 1;  // blocks that share the regions of an (item, angle block) on small batches
     bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
@@ -543,6 +544,7 @@ struct ym_matcher {
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
+    int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
@@ -939,7 +941,14 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
                      lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         if (P.region26) {
-            P.n_groups = P.rg_ng;
+            // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
+            // kernel 121 -> 65 us with four, the enqueue 236 -> 205 us; 128 chains 317 -> 295 with two; scripts/dev/rsplit_time.py)
+            P.rg_rsplit = 1;
+            if (!P.rg_ws && m->corr_region_rsplit != 1) {
+                const int blocks = B * P.rg_parts;
+                P.rg_rsplit = m->corr_region_rsplit > 1 ? m->corr_region_rsplit : std::max(1, std::min(8, (3 * m->n_cus) / std::max(1, blocks)));
+            }
+            P.n_groups = P.rg_ng * P.rg_rsplit;
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
             // (the wave-specialised form's bins are a third more and hold less each: 20 %)
@@ -1049,7 +1058,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.dim_stride = std::max(lc.nx, lc.ny);
     P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
-    P.partial_stride = P.region26 ? (size_t)P.rg_ng * lc.nt * 64 * 16 : P.region ? (size_t)P.ga_ng * lc.nt * P.ga_np * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
+    P.partial_stride = P.region26 ? (size_t)P.rg_ng * P.rg_rsplit * lc.nt * 64 * 16 : P.region ? (size_t)P.ga_ng * lc.nt * P.ga_np * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
     P.cell_blocks = (lc.nx * lc.ny + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
     P.score_blocks = P.cell_blocks * lc.nt; // block maxima per (angle, block of cells)
 
@@ -1075,7 +1084,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
     P.resp = call.ext_resp ? call.ext_resp : m->resp.p;
     P.probs = call.ext_probs ? call.ext_probs : m->probs.p;
-    P.fuse_score = P.region26 && !P.rg_ws && !m->keep_sums && m->corr_fuse_score != 2;
+    P.fuse_score = P.region26 && !P.rg_ws && P.rg_rsplit == 1 && !m->keep_sums && m->corr_fuse_score != 2;
     P.k_begin = call.slice ? std::max(0, call.k_begin) : 0;
     P.k_end = call.slice ? std::min(lc.nt, call.k_end) : lc.nt;
     if (call.slice && (yag || B != 1)) return set_err(YM_ERR_UNSUPPORTED, "angle-sliced matches are single Karto matches");
@@ -1612,7 +1621,7 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
     r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
     r.rg_h = P.rg_ws ? YM_WS_H : YM_RG_H; r.rg_cls = P.rg_ws ? YM_WS_CLS : YM_RG_CLS; r.rg_zero = P.rg_ws ? YM_WS_ZERO : YM_RG_ZERO; r.pad2 = 0;
     r.rg_w = 0; r.rg_pitch = YM_RG_PITCH; r.nregions = P.rg_nregions; r.pad3 = 0;
-    r.walk = m->rg_walk.p; r.nitems = P.B;
+    r.walk = m->rg_walk.p; r.nitems = P.B; r.rsplit = P.rg_rsplit; r.pad4 = 0;
     // teams of `parts` blocks per XCD: two blocks per CU, no more teams than the XCD gets items
     r.gpx = std::max(1, std::min((2 * std::max(m->n_cus, 8) / 8) / std::max(1, P.rg_parts), (P.B + 7) / 8));
     return r;
@@ -1664,7 +1673,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         if (P.lists_on_side_stream) HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
         else if ((rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
-        const dim3 rgrid(P.rg_parts, P.B);
+        const dim3 rgrid(P.rg_parts * P.rg_rsplit, P.B);
         if (P.rg_ws) {
             hipLaunchKernelGGL(ym::correlate_region_ws_kernel, dim3(8 * r.gpx * P.rg_parts), dim3(64 * (YM_WS_NG + YM_WS_NL)), 0, st, r);
             hipLaunchKernelGGL(ym::region_percell_kernel, rgrid, dim3(64 * YM_WS_NG), 0, st, r);
@@ -1772,8 +1781,8 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     if (P.region || P.fuse_score) return; // the LDS correlates score their sums themselves
     // (a thread of score_kernel walks all angles of its cell: fine when the batch fills the chip, 36 us on 8 items, where
     //  one thread per hypothesis takes 5)
-    //  (score_kernel also is the one that reads the region correlate's lane-ordered sums)
-    if (P.B >= 64 || P.region26) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
+    //  (a region correlate whose regions were dealt out to several blocks -- a small batch -- leaves its sets to this stage too)
+    if (P.B >= 256 || (P.B >= 64 && !P.region26)) hipLaunchKernelGGL(ym::score_kernel, dim3(P.cell_blocks, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
     else if (P.k_end > P.k_begin)
         hipLaunchKernelGGL(ym::score_hyp_kernel, dim3(P.cell_blocks, P.k_end - P.k_begin, P.B), dim3(YM_SCORE_THREADS), 0, st, a);
 }
@@ -3215,6 +3224,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 21) m->corr_fuse_score = value;
     else if (option == 32) m->corr_region_form = value;
     else if (option == 33) m->corr_region_dbg = value;
+    else if (option == 34) m->corr_region_rsplit = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;

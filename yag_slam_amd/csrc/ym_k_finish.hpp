@@ -113,8 +113,11 @@ __global__ __launch_bounds__(YM_SCORE_THREADS) void score_hyp_kernel(ScoreArgs a
     YM_STAMP(a, 10);
     if (c < nxy) {
         const int iy = c / nx, ix = c - iy * nx;
-        const uint16_t *p = a.partial + (size_t)b * a.partial_stride + ((size_t)k * ny + iy) * a.nx_pad + ix;
-        const size_t cstride = (size_t)nt * ny * a.nx_pad;
+        // (lane_layout: the region correlate's sets, [set][angle][lane = 32 * (ix / 13) + iy][ix % 13 of 16])
+        const size_t kstride = a.lane_layout ? (size_t)64 * 16 : (size_t)ny * a.nx_pad;
+        const uint16_t *p = a.partial + (size_t)b * a.partial_stride + (size_t)k * kstride +
+                            (a.lane_layout ? (size_t)((32 * (ix / 13) + iy) * 16 + ix % 13) : (size_t)iy * a.nx_pad + ix);
+        const size_t cstride = (size_t)nt * kstride;
         unsigned sum = 0;
 #pragma unroll 8
         for (int c2 = 0; c2 < a.n_chunks; c2++) sum += p[(size_t)c2 * cstride];

@@ -106,6 +106,7 @@ struct RegionArgs {
     // wave-specialised form: the walks (region_walk_kernel: [Q][parts][YM_WS_WALK_WORDS]), items of the call, block teams per XCD
     uint32_t *walk;
     int32_t nitems, gpx;
+    int32_t rsplit, pad4;    // correlate_region_kernel: blocks that share the regions of an (item, angle block); <= 1: one
     unsigned long long *stamps;
 };
 
@@ -366,8 +367,13 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][2]; // per wave and listed region: its first entry and the end
     __shared__ uint2 elist[NW][64];                   // per wave: its first 256 entries of the region being gathered
     __shared__ int rcount;
+    // Small batches (fewer blocks than the chip holds): the listed regions of an (item, angle block) are dealt out to rsplit
+    // blocks, each with its own sets of partial sums -- a block's region walk is a chain of ~20 stage / gather rounds, 118 us
+    // whatever the batch, and only more blocks shorten it (score_kernel adds the sets; no fused scoring then).
     int p;
     const int b = xcd_item_of_block_2d(p);
+    const int rsplit = a.rsplit > 1 ? a.rsplit : 1, rsi = p / a.parts;
+    p -= rsi * a.parts;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const YmItemState &st = a.states[b];
     const int nt = a.lat.nt, nx = a.lat.nx, ny = a.lat.ny, ng = a.ng;
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     auto flush = [&]() {
         if (flushed < ng) {
             rg_odd(acc);
-            store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)flushed * nt + k) * 64 + lane) * 16, acc);
+            store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)(rsi * ng + flushed) * nt + k) * 64 + lane) * 16, acc);
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[j] = 0u;
@@ -420,10 +426,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 const int R = R0 + lane;
                 const bool has = R < nreg && starts[(size_t)R * nt + k_lo] != starts[(size_t)R * nt + k_hi];
                 const unsigned long long mask = __ballot(has);
-                if (has) rlist[n + __popcll(mask & ((1ull << lane) - 1ull))] = R;
+                const int at = n + __popcll(mask & ((1ull << lane) - 1ull)); // (its place among the regions with work)
+                if (has && at % rsplit == rsi) rlist[at / rsplit] = R;
                 n += __popcll(mask);
             }
-            if (lane == 0) rcount = n;
+            if (lane == 0) rcount = n > rsi ? (n - rsi + rsplit - 1) / rsplit : 0;
         }
         __syncthreads();
         const int nlist = rcount;
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             __syncthreads();
             YM_RG_PH(5);
         }
-    } else if (kvalid && job) {
+    } else if (kvalid && job && rsi == 0) {
         // hypothesis cells are not an exact lattice (possible only through fp rounding): per-cell path over the window
         const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
         const unsigned limit = (unsigned)(a.g.pitch * a.g.win_w);
