@@ -101,6 +101,50 @@ def profile_json(name):
         return None
 
 
+def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlate_body", cus=256):
+    """`roofline` block of `kernel` as it ran in `workload`: its counters per launch from profiles/counters.json (rocprofv3 --pmc
+    passes of that workload, scripts/profile_pmc.sh) over the kernel duration `kernel_s` (seconds; measured live where the
+    caller can, else the profiled run's) against the measured peaks of profiles/issue_peaks.json.  bound = the resource with
+    the highest utilisation.  None when the tree holds no counters for the kernel."""
+    ctr, peaks = profile_json("counters.json"), profile_json("issue_peaks.json")
+    try:
+        k = ctr["workloads"][workload]["kernels"][kernel]
+    except (KeyError, TypeError):
+        return None
+    live = kernel_s is not None
+    if kernel_s is None:
+        kernel_s = k.get("us", 0.0) * 1e-6
+    if not kernel_s or not peaks:
+        return None
+    clocks = kernel_s * 2.4e9 * cus  # (cus: the CUs the launch can occupy -- 1 for a one-block kernel)
+    vp = peaks.get(valu_peak_key, {}).get("peak_per_cu_clk") or peaks["generic"]["slow_class_per_cu_clk"]
+    res = {}
+    if k.get("SQ_INSTS_VALU"):
+        res["valu_issue"] = {"achieved": k["SQ_INSTS_VALU"] / clocks, "peak": vp, "unit": "wave-instructions per CU and clock",
+                             "peak_source": "profiles/issue_peaks.json: " + valu_peak_key}
+    if k.get("SQ_LDS_IDX_ACTIVE"):
+        res["lds"] = {"achieved": k["SQ_LDS_IDX_ACTIVE"] / clocks, "peak": 1.0, "unit": "LDS busy cycles per CU and clock"}
+    if k.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        res["vector_l1"] = {"achieved": k["TCP_TOTAL_CACHE_ACCESSES_sum"] / clocks, "peak": 1.0, "unit": "cache-line visits per CU and clock"}
+    hbm_bytes = (k.get("FETCH_SIZE", 0.0) * 2.0 + k.get("WRITE_SIZE", 0.0)) * 1024.0  # (KiB; gfx950 counts half of a wide read stream)
+    if hbm_bytes:
+        res["hbm"] = {"achieved": hbm_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "read_bytes": k.get("FETCH_SIZE", 0.0) * 2048.0,
+                      "written_bytes": k.get("WRITE_SIZE", 0.0) * 1024.0}
+    for r_ in res.values():
+        r_["frac"] = r_["achieved"] / r_["peak"]
+    if not res:
+        return None
+    bound = max(res, key=lambda k_: res[k_]["frac"])
+    wc = k.get("SQ_WAVE_CYCLES", 0.0)
+    return {"bound": bound, "kernel": kernel, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
+            "frac": res[bound]["frac"], "traffic": hbm_bytes or None, "hbm_frac": res["hbm"]["frac"] if "hbm" in res else None,
+            "resources": res, "kernel_us": kernel_s * 1e6, "kernel_us_is": "measured in this run" if live else "the profiled run's",
+            "wave_time": {"waiting_at_waitcnt_or_barrier": k.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": k.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                          "issuing": k.get("SQ_ACTIVE_INST_ANY", 0.0) / wc} if wc else None,
+            "l2_hit_rate": k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if k.get("TCC_HIT_sum") else None,
+            "replayed_from": "profiles/counters.json (%s, workload %s: %s)" % (ctr.get("tag"), workload, ctr["workloads"][workload]["command"])}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -294,6 +338,21 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     # call for each: 2-4 ms, next to 5 ms of GPU); second pass: every slot replays its plan (0.13 ms of host per enqueue)
     dt_first = timed_pass()
     dt = timed_pass()
+    # the dominant kernel of this config (the gather correlate) against its counters: duration measured here (HIP events on
+    # the matcher's stream around the correlate stage, lists excluded), counters replayed from profiles/counters.json
+    roof = None
+    if rank == 0:
+        loop_m.profile(True)
+        timed_pass()
+        corr_ms, corr_n = loop_m.profile_read(0)
+        loop_m.profile_read(1); loop_m.profile_read(2)
+        loop_m.profile(False)
+        if corr_n:
+            roof = replayed_roofline("cfg4", "ym::gather_kernel<1, 2, 4>", corr_ms / corr_n * 1e-3)
+            if roof is not None:
+                nbeams = 1081
+                roof["algorithmic_bytes_per_launch"] = float(hi - lo) * 41 * 41 * 21 * nbeams  # one byte per valid beam and hypothesis
+                roof["algorithmic_GBps"] = roof["algorithmic_bytes_per_launch"] / (corr_ms / corr_n * 1e-3) / 1e9
     t = torch.tensor([dt, float(hyp_local)], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = t.clone()
@@ -311,7 +370,7 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     return {"chains": args.cfg4_chains, "chains_per_gpu": hi - lo, "lattice": "41x41x21", "scaling": "strong",
             "ms_per_query": dt * 1e3, "ms_per_query_first_use_of_the_slots": dt_first * 1e3, "one_shot_ms_incl_results": one_shot * 1e3,
             "chain_matches_per_s": args.cfg4_chains / dt, "hypotheses_per_s": hyp_total / dt,
-            "hypotheses": hyp_total, "winner": winner,
+            "hypotheses": hyp_total, "winner": winner, "roofline": roof,
             "collective": "all_gather of one 64-byte best record per rank" if world > 1 else "none"}
 
 
@@ -344,6 +403,12 @@ def leg_cfg5(device, query, chain, rank, world, torch, dist):
                "hypotheses_per_match": r.meta["hypotheses"], "us_per_match": dt * 1e6, "scan_matches_per_s": 1.0 / dt,
                "hypotheses_per_s": r.meta["hypotheses"] / dt, "correlate_kernel_us": corr_s * 1e6,
                "correlate_algorithmic_GBps": alg / corr_s / 1e9, "correlate_frac_of_hbm_peak": alg / corr_s / 1e9 / HBM_PEAK_GBS}
+        # the two kernels that are most of this match: the direct correlate (duration measured here) and the one-block
+        # select step of the order-dependent smear (duration from the profiled run), against their counters
+        out["roofline"] = replayed_roofline("cfg5", "ym::correlate_kernel<2, 16, 1>", corr_s, "generic")
+        out["roofline_select"] = replayed_roofline("cfg5", "ym::select_kernel<5>", None, "generic", cus=1)
+        if out["roofline_select"]:
+            out["roofline_select"]["note"] = "one block on one CU (a chain of dependent decisions): fractions are of that CU; no resource is the bound, the latency of its LDS round trips is"
     if world > 1:
         sp = ymdist.AngleSplitMatcher(m, rank, world)
         g = sp.match_scan(query, chain, True, True)
@@ -557,42 +622,22 @@ def main():
             "timed_seconds": dt,
             "collective": "all_gather of %d 64-byte best records per rank per step" % E if world > 1 else "none",
         }
-        traffic = profile_json("traffic_correlate.json")
-        issue = profile_json("issue_correlate.json")
         region = LB >= 8 and args.corr_region != 1
         kernel = "ym::correlate_region_kernel<8>" if region else "ym::correlate_kernel<2, 16, 4>"
-        if traffic and (traffic.get("kernel") != kernel or int(traffic.get("batch", 0)) != LB):
-            traffic = None
-        if issue and (issue.get("kernel") != kernel or int(issue.get("batch", 0)) != LB):
-            issue = None
         step_alg = hyp_step * nq  # coarse + fine lattice points x one byte per valid beam
-        # utilisation of every resource the counters cover, over THIS run's kernel duration (2.4 GHz, 256 CUs)
-        clocks = corr_s * 2.4e9 * 256
-        res = {}
-        if issue:
-            res["valu_issue"] = {"achieved": issue["valu"]["per_launch"] / clocks, "peak": issue["valu"]["peak_per_cu_clk"],
-                                 "unit": "wave-instructions per CU and clock", "peak_source": issue["valu"]["peak_source"]}
-            res["lds"] = {"achieved": issue["lds"]["cycles_per_launch"] / clocks, "peak": 1.0, "unit": "LDS busy cycles per CU and clock"}
-        if traffic:
-            res["hbm"] = {"achieved": traffic["hbm_bytes_per_launch"] / corr_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        for r_ in res.values():
-            r_["frac"] = r_["achieved"] / r_["peak"]
-        bound = max(res, key=lambda k_: res[k_]["frac"]) if res else "hbm"
-        top = res.get(bound, {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
-        line["roofline"] = {
-            "bound": bound, "kernel": kernel, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-            "hbm_frac": res["hbm"]["frac"] if "hbm" in res else None,
-            "resources": res,
-            "replayed_from": ("counters of profiles/issue_correlate.json + profiles/traffic_correlate.json (%s); only kernel_us is "
-                              "measured in this run" % (issue or traffic or {}).get("source", "-")) if res else None,
-            "kernel_us": corr_s * 1e6, "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
+        rl = replayed_roofline("cfg2x", kernel, corr_s) if LB == 4096 else None
+        if rl is None:
+            rl = {"bound": "hbm", "kernel": kernel, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                  "kernel_us": corr_s * 1e6, "replayed_from": None}
+        rl.update({
+            "call_us_gpu": call_ms / max(call_n, 1) * 1e3,
             # one grid byte per valid beam and hypothesis, against the HBM peak.  Not a roofline fraction:
             # the bytes are gathered from LDS, where a staged byte is read ~19 times
             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBS,
             # the whole step against the same figure: every kernel of the call, launch gaps and host work included
             "algorithmic_frac_step": step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        }
+        })
+        line["roofline"] = rl
         line["config"]["point_cache"] = dict(zip(("hits", "misses"), m.cache_stats()))
 
         # ---- what production would see of this workload (same run, after the timed region of the metric)
