@@ -14,7 +14,7 @@ chains = []
 for c in range(B):
     rng = np.random.default_rng(100000 + c)
     chains.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
-for form, dbg, what in ((0, 0, "first form (every wave stages and gathers)"), (2, 0, "wave-specialised"), (2, 1, "... loaders move nothing"),
+for form, dbg, what in ((1, 0, "first form (every wave stages and gathers)"), (3, 0, "one block per item, sums in LDS"), (2, 0, "wave-specialised"), (2, 1, "... loaders move nothing"),
                         (2, 2, "... gatherers gather nothing"), (2, 3, "... neither")):
     m = ScanMatcher({"use_response_expansion": False})
     m.debug_option(32, form)

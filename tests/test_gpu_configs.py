@@ -379,7 +379,7 @@ def test_cfg2_batch_512_distinct_chains_region_correlate_against_direct_and_orac
     m = ScanMatcher()
     per, best = m.match_scan_batch(q, chains, True, True)
     assert len(per) == n_chains and all(tuple(p.meta["coarse_dims"]) == (26, 26, 21) for p in per)
-    for opt, mode in ((14, 1), (14, 4), (32, 2)):  # the direct kernel; the general gather correlate; the region correlate's wave-specialised form
+    for opt, mode in ((14, 1), (14, 4), (32, 2), (32, 3)):  # the direct kernel; the general gather correlate; the region correlate's wave-specialised and one-block-per-item forms
         md = ScanMatcher()
         md.debug_option(opt, mode)
         perd, bestd = md.match_scan_batch(q, chains, True, True)

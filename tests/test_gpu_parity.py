@@ -1030,18 +1030,22 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
                     assert np.array_equal(vols[mode][0][i], vols[1][0][i]), (mode, i)
                 same(vols[mode], vols[1])
             assert vols[0][0][0].any()
-            # the region correlate's wave-specialised form (option 32 = 2: gather waves + loader waves, persistent blocks)
-            m = ScanMatcher(cfg)
-            m.debug_option(12, 1)
-            m.debug_option(32, 2)
-            per, best = m.match_scan_batch(nquery, chains, True, True)
-            ws_form = ([m.debug_sums(0, item=i, dims=per[0].meta["coarse_dims"]) for i in range(len(chains))], per, best)
-            for i in range(len(chains)):
-                assert np.array_equal(ws_form[0][i], vols[1][0][i]), i
-            same(ws_form, vols[1])
+            # the region correlate's other forms: wave-specialised (option 32 = 2: gather waves + loader waves, persistent blocks) and
+            # one block per item with the item's sums in LDS (= 3: what large batches take), with the lists that fit and without
+            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3)):
+                m = ScanMatcher(cfg)
+                m.debug_option(12, 1)
+                m.debug_option(32, form)
+                if irregular:
+                    m.debug_option(14, irregular)
+                per, best = m.match_scan_batch(nquery, chains, True, True)
+                other = ([m.debug_sums(0, item=i, dims=per[0].meta["coarse_dims"]) for i in range(len(chains))], per, best)
+                for i in range(len(chains)):
+                    assert np.array_equal(other[0][i], vols[1][0][i]), (form, irregular, i)
+                same(other, vols[1])
             # without the kept sums (the production form: the region correlate scores its sums itself; option 21 = 2 leaves
             # that to the score kernel), through either kernel
-            for opts in ({}, {21: 2}, {14: 4}, {32: 2}, {32: 2, 21: 2}):
+            for opts in ({}, {21: 2}, {14: 4}, {32: 2}, {32: 2, 21: 2}, {32: 3}, {32: 3, 21: 2}, {32: 3, 14: 2}):
                 m = ScanMatcher(cfg)
                 for k, v in opts.items():
                     m.debug_option(k, v)

@@ -199,6 +199,7 @@ struct CallPlan {
     bool fuse_score = false;  // ... also scores (no score_kernel launch)
     int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1, rg_nregions = 0;
     int rg_rsplit = 1;  // blocks that share the regions of an (item, angle block) on small batches
+    bool rg_item = false; // correlate_item_kernel: one block of 16 waves per item, the item's sums in LDS
     bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
@@ -544,6 +545,8 @@ struct ym_matcher {
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
     bool poll_completion = true; // single matches: the host polls a pinned word instead of waiting for the stream event
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
+    int item_min_batch = 1 << 30; // batches from this many items on take correlate_item_kernel
+    bool item_lds_set = false;
     int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
@@ -944,10 +947,13 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
             // kernel 121 -> 65 us with four, the enqueue 236 -> 205 us; 128 chains 317 -> 295 with two; scripts/dev/rsplit_time.py)
             P.rg_rsplit = 1;
-            if (!P.rg_ws && m->corr_region_rsplit != 1) {
+            if (!P.rg_ws && m->corr_region_rsplit != 1 && m->corr_region_form != 3) {
                 const int blocks = B * P.rg_parts;
                 P.rg_rsplit = m->corr_region_rsplit > 1 ? m->corr_region_rsplit : std::max(1, std::min(8, (3 * m->n_cus) / std::max(1, blocks)));
             }
+            // batches that fill the chip with one block per item: correlate_item_kernel (option 32: 1 = never, 3 = always)
+            P.rg_item = !P.rg_ws && P.rg_rsplit == 1 && lc.nt <= YM_IT_MAX_NT && m->corr_region_form != 1 &&
+                        (m->corr_region_form == 3 || B >= m->item_min_batch);
             P.n_groups = P.rg_ng * P.rg_rsplit;
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
@@ -1619,7 +1625,8 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
     r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.pad = m->corr_region_dbg; r.stamps = P.stamps;
     r.fuse_score = P.fuse_score ? 1 : 0; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
     r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
-    r.rg_h = P.rg_ws ? YM_WS_H : YM_RG_H; r.rg_cls = P.rg_ws ? YM_WS_CLS : YM_RG_CLS; r.rg_zero = P.rg_ws ? YM_WS_ZERO : YM_RG_ZERO; r.pad2 = 0;
+    r.rg_h = P.rg_ws ? YM_WS_H : YM_RG_H; r.rg_cls = P.rg_ws ? YM_WS_CLS : P.rg_item ? YM_IT_CLS : YM_RG_CLS;
+    r.rg_zero = P.rg_ws ? YM_WS_ZERO : P.rg_item ? YM_IT_ZERO : YM_RG_ZERO; r.pad2 = 0;
     r.rg_w = 0; r.rg_pitch = YM_RG_PITCH; r.nregions = P.rg_nregions; r.pad3 = 0;
     r.walk = m->rg_walk.p; r.nitems = P.B; r.rsplit = P.rg_rsplit; r.pad4 = 0;
     // teams of `parts` blocks per XCD: two blocks per CU, no more teams than the XCD gets items
@@ -1674,6 +1681,15 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         else if ((rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts * P.rg_rsplit, P.B);
+        if (P.rg_item) {
+            const size_t lds = YM_IT_ACC_BYTES(P.lc.nt);
+            if (!m->item_lds_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::correlate_item_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)YM_IT_ACC_BYTES(YM_IT_MAX_NT)));
+                m->item_lds_set = true;
+            }
+            hipLaunchKernelGGL(ym::correlate_item_kernel, dim3(P.B), dim3(64 * YM_IT_NW), lds, st, r);
+            return prof_end(m, ev_k);
+        }
         if (P.rg_ws) {
             hipLaunchKernelGGL(ym::correlate_region_ws_kernel, dim3(8 * r.gpx * P.rg_parts), dim3(64 * (YM_WS_NG + YM_WS_NL)), 0, st, r);
             hipLaunchKernelGGL(ym::region_percell_kernel, rgrid, dim3(64 * YM_WS_NG), 0, st, r);
@@ -3225,6 +3241,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 32) m->corr_region_form = value;
     else if (option == 33) m->corr_region_dbg = value;
     else if (option == 34) m->corr_region_rsplit = value;
+    else if (option == 35) m->item_min_batch = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;
