@@ -197,6 +197,56 @@ def test_sequential_mapper_process_scans_falls_back_to_the_per_scan_loop():
     assert [s.num for s in b.running_scans] == list(range(4, 14)) and len(b.results) == 13
 
 
+def test_sequential_mapper_process_scans_keeps_what_was_matched_when_the_sequence_fails():
+    # map_sequence raises at a scan Karto aborts on (or on a library error): the scans matched before it are done on both
+    # sides, and the mapper's state is what the per-scan loop would have left when it raised there; scans that are not our
+    # LocalizedRangeScan take the per-scan loop although the matcher has a map_sequence
+    from collections import namedtuple
+    import pytest
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.transform import Transform
+    R = namedtuple("R", "best_pose response covariance meta")
+
+    class Seq:
+        def __init__(self, fail_at):
+            self.fail_at, self.calls = fail_at, 0
+        def match_scan(self, q, base, pen, fine):
+            self.calls += 1
+            return R(Transform(q.corrected_pose.x, q.corrected_pose.y, 0, q.corrected_pose.euler[-1]), 1.0, None, {"n": len(base)})
+        def map_sequence(self, seq, start, buffer_len, pen, fine, device_chain):
+            done = []
+            for i in range(start, len(seq)):
+                if i == self.fail_at:
+                    self.sequence_done = done
+                    raise RuntimeError("Mapper FATAL ERROR (scan %d)" % i)
+                done.append(R(seq[i].corrected_pose, 1.0, None, {"i": i}))
+            self.sequence_done = done
+            return done
+
+    def scans(n, cls=LocalizedRangeScan):
+        out = []
+        for i in range(n):
+            s = cls([1.0] * 5, -1, 1, 0.5, 0, 10, 5, 0, 0, 0)
+            s.odom_pose = Transform(0.1 * i, 0.0, 0, 0.0)
+            out.append(s)
+        return out
+    m = SequentialMapper(Seq(fail_at=9), scan_buffer_len=4)
+    ss = scans(14)
+    m.process_scans(ss[:3])
+    with pytest.raises(RuntimeError):
+        m.process_scans(ss[3:])
+    assert [r.meta["i"] for r in m.results[2:]] == [3, 4, 5, 6, 7, 8] and len(m.results) == 8
+    assert [s.num for s in m.running_scans] == [5, 6, 7, 8]
+
+    class Duck:  # (not our scan type: only the attributes process_scan touches)
+        def __init__(self, i):
+            self.odom_pose, self.corrected_pose, self.num = Transform(0.1 * i, 0.0, 0, 0.0), Transform(0, 0, 0, 0), 0
+    m2 = SequentialMapper(Seq(fail_at=-1))
+    out = m2.process_scans([Duck(i) for i in range(5)])
+    assert out[0] is None and len(out) == 5 and m2.seq_matcher.calls == 4 and not hasattr(m2.seq_matcher, "sequence_done")
+
+
 def _light_scan(num, pose):
     from yag_slam_amd.transform import Transform
 

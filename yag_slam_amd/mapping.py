@@ -7,7 +7,7 @@ chain of the last `scan_buffer_len` scans (default 10, graph_slam.py:47,336-337)
 optimiser, no loop closure here -- this only drives the matcher the way yag-slam does, with every
 scan resident on the device (one upload per new scan, poses written through).
 """
-from .models import set_corrected_poses
+from .models import LocalizedRangeScan, set_corrected_poses
 from .transform import Transform
 
 
@@ -52,13 +52,22 @@ class SequentialMapper(object):
         if not scans:
             return out
         native = getattr(self.seq_matcher, "map_sequence", None)
-        if native is None:
+        resident = all(isinstance(s, LocalizedRangeScan) for s in self.running_scans + scans)
+        if native is None or not resident:  # (any matcher plugin, any scan type: scan by scan, as process_scan does)
             return out + [self.process_scan(s) for s in scans]
         start = len(self.running_scans)
         seq = self.running_scans + scans
         for k in range(start, len(seq)):
             seq[k].num = seq[k - 1].num + 1
-        res = native(seq, start, self.scan_buffer_len, True, True, device_chain)
+        try:
+            res = native(seq, start, self.scan_buffer_len, True, True, device_chain)
+        except Exception:
+            # the scans matched before the failing one are done (poses final on both sides): the mapper's state is what
+            # the per-scan loop would have left when it raised at that scan
+            res = list(getattr(self.seq_matcher, "sequence_done", None) or [])
+            self.running_scans = (seq[:start + len(res)])[-self.scan_buffer_len:]
+            self.results.extend(res)
+            raise
         self.running_scans = seq[-self.scan_buffer_len:]
         self.results.extend(res)
         return out + res

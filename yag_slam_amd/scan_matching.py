@@ -203,13 +203,16 @@ class ScanMatcher(object):
             odom[i, 0], odom[i, 1], odom[i, 2] = p.x, p.y, p.euler[-1]
         per = (_capi.YmResult * max(1, n))()
         done = C.c_int32(0)
-        _capi.check(self._lib.ym_map_sequence(self._m, handles, odom.ctypes.data_as(C.POINTER(C.c_double)), n, int(start),
-                                              int(buffer_len), int(bool(penalty)), int(bool(do_fine)), int(bool(device_chain)),
-                                              per, C.byref(done)))
+        rc = self._lib.ym_map_sequence(self._m, handles, odom.ctypes.data_as(C.POINTER(C.c_double)), n, int(start),
+                                       int(buffer_len), int(bool(penalty)), int(bool(do_fine)), int(bool(device_chain)),
+                                       per, C.byref(done))
         first = max(int(start), 1)
         res = _results(per)[first:done.value] if done.value > first else []
         for s, r in zip(scans[first:done.value], res):
             s._corrected_pose = r.best_pose  # (the device twin already has it)
+        self.sequence_done = res  # (the scans matched before an error: SequentialMapper.process_scans commits them)
+        if rc:  # (a library error: the scans matched so far keep their results, Python and device twins agree)
+            _capi.check(rc)
         if done.value < n:
             bad = scans[done.value]
             pose = (C.c_double * 3)()
