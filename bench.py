@@ -54,7 +54,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16384, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--launch-batch", type=int, default=4096, help="matches per enqueue (workspace size)")
-    ap.add_argument("--lanes", type=int, default=1, help="matchers (stream + workspace each) the enqueues of a step alternate over")
+    ap.add_argument("--lanes", type=int, default=2, help="matchers (stream + workspace each) the enqueues of a step alternate over: with two, "
+                    "the small kernels at the end of one enqueue run beside the large ones of the next (-3.5 %% step time)")
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-production-legs", action="store_true",
@@ -528,7 +529,7 @@ def main():
         used = [[None] * nslots for _ in lanes]  # per lane: which batch object a slot's call belongs to
         counter = [0] * NL
 
-        def step(i):
+        def step(i, one_at_a_time=False):
             b = i % nbuf
             if works[b] is not None:
                 works[b].wait()  # its gathered records are about to be overwritten
@@ -542,6 +543,9 @@ def main():
                 batches[e].run_async(True, True, slot=s, chain_id_base=rank * args.batch + e * LB,
                                      dev_best_out=records[b, e].data_ptr())
                 used[ln][s] = batches[e]
+                if one_at_a_time:  # (the profiling pass: a kernel's duration means something only while nothing runs beside it)
+                    batches[e].wait(s, per_chain=False)
+                    used[ln][s] = None
             if dist is not None:
                 # cross-rank arg-max payload: E 64-byte records per rank.  Asynchronous: RCCL's stream waits for this
                 # step's records (on every lane's stream), the launch streams go straight on to the next step
@@ -596,7 +600,7 @@ def main():
         for lm in lanes:
             lm.profile(True)
         for i in range(min(args.steps, 4)):
-            step(i)
+            step(i, one_at_a_time=NL > 1)
         drain()
         corr_ms = corr_n = call_ms = call_n = 0
         for lm in lanes:

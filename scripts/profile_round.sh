@@ -6,7 +6,7 @@
 tag=${1:-r03p}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o ${tag} -- python3 bench.py --no-cpu-baseline --no-production-legs > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o ${tag} -- python3 bench.py --lanes 1 --no-cpu-baseline --no-production-legs > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_single -o ${tag} -- python3 scripts/quick_time.py > $out/${tag}_single.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stress -o ${tag} -- python3 scripts/stress_time.py > $out/${tag}_stress.log 2>&1
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err

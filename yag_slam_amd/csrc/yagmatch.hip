@@ -547,6 +547,7 @@ struct ym_matcher {
     int corr_region_nw = 0;  // development: waves (= angles) per region-correlate block
     int item_min_batch = 1 << 30; // batches from this many items on take correlate_item_kernel
     bool item_lds_set = false;
+    int raster_planes_only = 0; // timing experiment (option 36): the raster does not write the row-major window
     int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
@@ -1556,7 +1557,7 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.tile_list = P.use_tile_list ? m->tile_list.p : nullptr; a.tile_count = m->tile_count.p; a.tile_cap = P.tile_cap;
     a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
-    a.tile_zero = m->tile_zero.p;
+    a.tile_zero = m->tile_zero.p; a.planes_only = m->raster_planes_only; a.pad = 0;
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
     a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.hit_start = m->tile_hit_start.p; a.hit_cap = P.hit_cap; a.lty = P.lty;
     int rc;
@@ -3242,6 +3243,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 33) m->corr_region_dbg = value;
     else if (option == 34) m->corr_region_rsplit = value;
     else if (option == 35) m->item_min_batch = value;
+    else if (option == 36) m->raster_planes_only = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;

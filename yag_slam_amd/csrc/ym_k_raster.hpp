@@ -28,6 +28,7 @@ struct RasterArgs {
     int32_t hit_cap, lty;
     const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
     int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
+    int32_t planes_only, pad;  // timing experiment: 1 = the row-major window is not written
     unsigned long long *stamps;
 };
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     auto store8 = [&](int y, uint32_t p0, uint32_t p1) {
         if (ty0 + y < a.g.win_w) {
             const uint32_t row = (uint32_t)(ty0 + y), col = (uint32_t)(tx0 + x8);
-            *reinterpret_cast<uint2 *>(grid + (row * (uint32_t)a.g.pitch + col)) = make_uint2(p0, p1);
+            if (!a.planes_only) *reinterpret_cast<uint2 *>(grid + (row * (uint32_t)a.g.pitch + col)) = make_uint2(p0, p1);
             uint8_t *pl = planes + (row * (uint32_t)(a.g.pitch / 2) + col / 2u);
             *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
             *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
