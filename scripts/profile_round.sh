@@ -10,5 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o ${t
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_single -o ${tag} -- python3 scripts/quick_time.py > $out/${tag}_single.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stress -o ${tag} -- python3 scripts/stress_time.py > $out/${tag}_stress.log 2>&1
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+find $out -path "*${tag}_*" -name "*kernel_trace.csv" -delete   # (only the per-kernel statistics travel)
 find $out -name "*${tag}*" -size +20M -delete
 ls $out | grep ${tag}

@@ -14,7 +14,8 @@ CU, CLOCK_HZ = 256, 2.4e9
 
 def kernel_means(tag, name):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True):
+    for f in (glob.glob(os.path.join(REPO, "gpurun_out", "%s_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True) +
+              glob.glob(os.path.join(REPO, "gpurun_out", "%s_cfg2x_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if "ym::" in k:
@@ -93,13 +94,13 @@ def main():
         dur = stats.get(k)
         if dur and "region" in k and iv:
             clk = dur * 1e-9 * CLOCK_HZ
+            peaks = json.load(open(os.path.join(REPO, "profiles", "issue_peaks.json")))["region_correlate_body"]
             json.dump({"kernel": k, "batch": batch, "kernel_us_under_rocprof": dur * 1e-3,
-                       "valu": {"counter": "SQ_INSTS_VALU", "per_launch": iv, "per_cu_clk": iv / (CU * clk), "peak_per_cu_clk": 0.96,
-                                "frac": iv / (CU * clk) / 0.96,
-                                "peak_source": "MEASURED for this kernel's instruction mix (v_add / v_alignbyte / v_and / v_perm / v_add3 / "
-                                               "v_add): 0.961 wave-instructions per CU and clock at 8 waves per SIMD, "
-                                               "scripts/exp/valu_issue.hip, profiles/r03_issue_rates.md (1.0 for v_perm-class, "
-                                               "2.0 for v_and-class instructions alone)"},
+                       "valu": {"counter": "SQ_INSTS_VALU", "per_launch": iv, "per_cu_clk": iv / (CU * clk),
+                                "peak_per_cu_clk": peaks["peak_per_cu_clk"], "frac": iv / (CU * clk) / peaks["peak_per_cu_clk"],
+                                "peak_source": "profiles/issue_peaks.json (round 4): " + peaks["what"],
+                                "other_measurements_of_the_peak": peaks["other_measurements"],
+                                "frac_against_round_3_peak_0.96": iv / (CU * clk) / 0.96},
                        "waves": sq2.get(k),
                        "lds": {"counter": "SQ_LDS_IDX_ACTIVE", "cycles_per_launch": la, "bank_conflict_cycles": lc,
                                "frac": la / (CU * clk), "peak_source": "LDS busy cycles / (256 CUs x kernel clocks)"},
