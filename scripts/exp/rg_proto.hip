@@ -57,6 +57,40 @@ __device__ __forceinline__ void rg_odd(uint32_t (&acc)[8]) {
     for (int j = 0; j < 4; j++) acc[2 * j + 1] -= (acc[2 * j] >> 16) << 8;
 }
 
+// variant 2: one v_perm_b32 per 16-bit pair of hypotheses does the byte funnel AND the widening (selector byte 0x0c = zero):
+// even = (B[rr], 0, B[rr + 2], 0), odd = (B[rr + 1], 0, B[rr + 3], 0) of the eight bytes s[j + 1] : s[j]; no v_alignbyte, no v_and,
+// no v_lshrrev, clean 16-bit fields in the odd accumulators too (no rg_odd at the end)
+__device__ __forceinline__ void rg_perm_pair(const rg_u32x2 &pa, const rg_u32x2 &qa, const rg_u32x2 &pb, const rg_u32x2 &qb, uint32_t rr,
+                                             uint32_t (&e)[4], uint32_t (&o)[4]) {
+    const uint32_t s0 = pa.x + pb.x, s1 = pa.y + pb.y, s2 = qa.x + qb.x, s3 = qa.y + qb.y;
+    const uint32_t selE = rr * 0x00010001u + 0x0c020c00u, selO = selE + 0x00010001u;
+    e[0] = __builtin_amdgcn_perm(s1, s0, selE); o[0] = __builtin_amdgcn_perm(s1, s0, selO);
+    e[1] = __builtin_amdgcn_perm(s2, s1, selE); o[1] = __builtin_amdgcn_perm(s2, s1, selO);
+    e[2] = __builtin_amdgcn_perm(s3, s2, selE); o[2] = __builtin_amdgcn_perm(s3, s2, selO);
+    e[3] = __builtin_amdgcn_perm(0u, s3, selE);
+}
+__device__ __forceinline__ void rg_gather4_perm(uint32_t (&acc)[8], uint32_t lane_off, uint2 ee) {
+    const uint32_t ad0 = lane_off + (ee.x & 0xffffu), ad1 = lane_off + (ee.x >> 16), ad2 = lane_off + (ee.y & 0xffffu), ad3 = lane_off + (ee.y >> 16);
+    rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %4, %10 offset1:1\n\tds_read2_b32 %5, %10 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %6, %11 offset1:1\n\tds_read2_b32 %7, %11 offset0:2 offset1:3\n\t"
+                 "s_waitcnt lgkmcnt(4)"
+                 : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
+                 : "v"(ad0 & ~3u), "v"(ad1 & ~3u), "v"(ad2 & ~3u), "v"(ad3 & ~3u)
+                 : "memory");
+    uint32_t e[2][4], o[2][4];
+    rg_perm_pair(p0, q0, p1, q1, ad0 & 3u, e[0], o[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p2), "+v"(q2), "+v"(p3), "+v"(q3) : : "memory");
+    rg_perm_pair(p2, q2, p3, q3, ad2 & 3u, e[1], o[1]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        acc[2 * j] = acc[2 * j] + e[0][j] + e[1][j];
+        if (j < 3) acc[2 * j + 1] = acc[2 * j + 1] + o[0][j] + o[1][j];
+    }
+}
+
 struct Args {
     const uint16_t *entries; // [waves in the grid][Q]: LDS offsets of patch origins, sorted by misalignment in runs of even length
     const uint16_t *runs;    // [waves in the grid][4]: first PAIR of the runs with misalignment 1, 2, 3 and the pair count
@@ -90,7 +124,28 @@ __global__ __launch_bounds__(64 * NW) void proto(Args a) {
     const int row = lane & 31, half = lane >> 5;
     const bool job = row < 26;
     const uint32_t lds0 = (uint32_t)(size_t)region;
-    if (VAR == 0) {
+    if (VAR == 2) {
+        const uint32_t lane_off = lds0 + (uint32_t)((job ? row : 0) * RG_PITCH + half * RG_G);
+        uint32_t acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0u;
+        for (int r = 0; r < a.R; r++) {
+            const uint2 *el = elist[wave];
+            const int n4 = Q >> 2;
+            uint2 e0 = el[0], e1 = el[min(1, n4 - 1)];
+            int c = 0;
+            for (; c + 1 < n4; c += 2) {
+                rg_gather4_perm(acc, lane_off, e0);
+                e0 = el[min(c + 2, n4 - 1)];
+                rg_gather4_perm(acc, lane_off, e1);
+                e1 = el[min(c + 3, n4 - 1)];
+            }
+            if (c < n4) rg_gather4_perm(acc, lane_off, e0);
+            if (a.barrier) __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < RG_G; j++) a.out[((size_t)gw * 64 + lane) * RG_G + j] = (acc[2 * (j >> 2) + (j & 1)] >> (16 * ((j >> 1) & 1))) & 0xffffu;
+    } else if (VAR == 0) {
         const uint32_t lane_off = lds0 + (uint32_t)((job ? row : 0) * RG_PITCH + half * RG_G);
         uint32_t acc[8];
 #pragma unroll
@@ -222,22 +277,22 @@ int main(int argc, char **argv) {
         }
         runs[(size_t)w * 4 + 3] = (uint16_t)pairs;
     }
-    uint16_t *d_ent, *d_runs; uint32_t *d_out[2];
+    uint16_t *d_ent, *d_runs; uint32_t *d_out[3];
     hipMalloc(&d_ent, ent.size() * 2); hipMalloc(&d_runs, runs.size() * 2);
     hipMemcpy(d_ent, ent.data(), ent.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(d_runs, runs.data(), runs.size() * 2, hipMemcpyHostToDevice);
     const size_t out_n = (size_t)nwaves * 64 * RG_G;
-    for (int v = 0; v < 2; v++) { hipMalloc(&d_out[v], out_n * 4); hipMemset(d_out[v], 0, out_n * 4); }
-    std::vector<uint32_t> h[2];
+    for (int v = 0; v < 3; v++) { hipMalloc(&d_out[v], out_n * 4); hipMemset(d_out[v], 0, out_n * 4); }
+    std::vector<uint32_t> h[3];
     printf("# %s, %d CUs, %d blocks of %d waves, Q = %d patches per wave and round, R = %d rounds\n", prop.gcnArchName, cus, blocks, NW, Q, R);
     printf("%-48s %10s %12s %14s\n", "variant", "blocks/CU", "us", "CU clk/patch");
     const size_t base_lds = ((RG_LDS_BYTES + 15) & ~15) + NW * 64 * 8;
-    for (int var = 0; var < 2; var++)
+    for (int var = 0; var < 3; var++)
         for (int per_cu : {3, 2})
             for (int barrier : {0, 1}) {
                 Args a{d_ent, d_runs, d_out[var], Q, R, barrier, 0};
                 const size_t lds = std::max(base_lds, (size_t)(160 * 1024 / per_cu - 1024)) ;
-                auto k = var == 0 ? proto<8, 0> : proto<8, 1>;
+                auto k = var == 0 ? proto<8, 0> : var == 1 ? proto<8, 1> : proto<8, 2>;
                 hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
@@ -250,24 +305,25 @@ int main(int argc, char **argv) {
                 hipEventElapsedTime(&ms, e0, e1);
                 const double patches = (double)nwaves * Q * R;
                 printf("%-48s %10d %12.1f %14.2f\n", var == 0 ? (barrier ? "kernel's loop, barrier per round" : "kernel's loop") :
+                       var == 2 ? (barrier ? "perm funnel + widen, barrier per round" : "perm funnel + widen") :
                        (barrier ? "misalignment sets, barrier per round" : "misalignment sets"), per_cu, ms * 1e3, ms * 1e-3 * 2.4e9 * cus / patches);
                 hipEventDestroy(e0); hipEventDestroy(e1);
             }
-    for (int var = 0; var < 2; var++) { // one round: the 16-bit sums hold Q patches
+    for (int var = 0; var < 3; var++) { // one round: the 16-bit sums hold Q patches
         Args a{d_ent, d_runs, d_out[var], Q, 1, 0, 0};
-        auto k = var == 0 ? proto<8, 0> : proto<8, 1>;
+        auto k = var == 0 ? proto<8, 0> : var == 1 ? proto<8, 1> : proto<8, 2>;
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * NW), base_lds, 0, a);
     }
     hipDeviceSynchronize();
-    for (int v = 0; v < 2; v++) { h[v].resize(out_n); hipMemcpy(h[v].data(), d_out[v], out_n * 4, hipMemcpyDeviceToHost); }
+    for (int v = 0; v < 3; v++) { h[v].resize(out_n); hipMemcpy(h[v].data(), d_out[v], out_n * 4, hipMemcpyDeviceToHost); }
     size_t bad = 0;
     for (size_t i = 0; i < out_n; i++) {
         const int lane = (int)((i / RG_G) % 64);
         if ((lane & 31) >= 26) continue;
         // (R rounds of the same patches: the 16-bit sums wrap the same way in both variants only while they do not overflow --
         //  compare modulo 2^16)
-        if ((h[0][i] & 0xffffu) != (h[1][i] & 0xffffu)) { if (bad < 5) printf("  differ at %zu: %u vs %u\n", i, h[0][i], h[1][i]); bad++; }
+        if ((h[0][i] & 0xffffu) != (h[1][i] & 0xffffu) || (h[0][i] & 0xffffu) != (h[2][i] & 0xffffu)) { if (bad < 5) printf("  differ at %zu: %u vs %u vs %u\n", i, h[0][i], h[1][i], h[2][i]); bad++; }
     }
-    printf("# sums of the two variants differ in %zu of %zu places\n", bad, out_n);
+    printf("# sums of the three variants differ in %zu of %zu places\n", bad, out_n);
     return 0;
 }

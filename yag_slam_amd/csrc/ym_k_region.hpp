@@ -307,18 +307,27 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
 typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
 // Four patches (their LDS origins: four 16-bit entries, the same in every lane -- a broadcast read of the wave's entry list)
 // into the packed 16-bit sums (acc[2j]: hypotheses 4j, 4j + 2; acc[2j + 1]: 4j + 1, 4j + 3).  Patches 2i and 2i + 1 share their misalignment (bin_kernel): grid
-// bytes are at most 100, so their RAW dwords add without carries and one funnel serves both; the two funnelled pair sums
-// are split into even / odd bytes and added with one v_add3 each.
-__device__ __forceinline__ void rg_funnel_pair(const rg_u32x2 &pa, const rg_u32x2 &qa, const rg_u32x2 &pb, const rg_u32x2 &qb, uint32_t rr,
-                                               uint32_t (&x)[4]) {
+// bytes are at most 100, so their RAW dwords add without carries and one funnel serves both.
+// Round 4: the funnel and the widening are ONE v_perm_b32 per pair of hypotheses -- selector (rr, 0x0c, rr + 2, 0x0c) picks bytes
+// rr and rr + 2 of the eight bytes s[j + 1] : s[j] into the low bytes of the two 16-bit fields and zeroes the rest (0x0c = the
+// constant 0), (rr + 1, 0x0c, rr + 3, 0x0c) the odd ones: 14 v_perm per pair of patches instead of 8 v_alignbyte + 8 v_and +
+// 6 v_lshrrev, and the odd sums are clean 16-bit fields like the even ones.  The loop alone: 11.5 -> 10.1 CU clocks per patch
+// (scripts/exp/rg_proto.hip variant 2, profiles/r04_rg_proto.txt).
+__device__ __forceinline__ void rg_perm_pair(const rg_u32x2 &pa, const rg_u32x2 &qa, const rg_u32x2 &pb, const rg_u32x2 &qb, uint32_t rr,
+                                             uint32_t (&e)[4], uint32_t (&o)[4]) {
     const uint32_t s0 = pa.x + pb.x, s1 = pa.y + pb.y, s2 = qa.x + qb.x, s3 = qa.y + qb.y; // raw dwords of two patches: bytes <= 200
-    x[0] = __builtin_amdgcn_alignbyte(s1, s0, rr);
-    x[1] = __builtin_amdgcn_alignbyte(s2, s1, rr);
-    x[2] = __builtin_amdgcn_alignbyte(s3, s2, rr);
-    x[3] = __builtin_amdgcn_alignbyte(0u, s3, rr); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
+    const uint32_t selE = rr * 0x00010001u + 0x0c020c00u, selO = selE + 0x00010001u;
+    e[0] = __builtin_amdgcn_perm(s1, s0, selE); o[0] = __builtin_amdgcn_perm(s1, s0, selO);
+    e[1] = __builtin_amdgcn_perm(s2, s1, selE); o[1] = __builtin_amdgcn_perm(s2, s1, selO);
+    e[2] = __builtin_amdgcn_perm(s3, s2, selE); o[2] = __builtin_amdgcn_perm(s3, s2, selO);
+    e[3] = __builtin_amdgcn_perm(0u, s3, selE); // byte 12 (the 13th hypothesis) is at most byte 15 of the four dwords
+    o[3] = 0u;                                  // (acc[7] would hold hypotheses 13 and 15 of the lane: there are only 13)
 }
 // All eight reads of the four patches are issued at once; the first pair is funnelled while the second pair's reads are
 // still in flight (LDS reads return in order: lgkmcnt(4) = the first four are back).
+// The registers an asm statement that only ISSUES a read names as outputs are not written when the statement ends, and
+// the compiler is free to copy them right there (seen: wrong sums): every such register is either waited for inside
+// the issuing statement or passes through the statement that waits for it ("+v") before anything else touches it.
 __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint2 ee /* four 16-bit origins, wave-uniform */) {
     const uint32_t ad0 = lane_off + (ee.x & 0xffffu), ad1 = lane_off + (ee.x >> 16), ad2 = lane_off + (ee.y & 0xffffu), ad3 = lane_off + (ee.y >> 16);
     rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
@@ -330,27 +339,22 @@ __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off
                  : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
                  : "v"(ad0 & ~3u), "v"(ad1 & ~3u), "v"(ad2 & ~3u), "v"(ad3 & ~3u)
                  : "memory");
-    uint32_t x[2][4];
-    rg_funnel_pair(p0, q0, p1, q1, ad0 & 3u, x[0]);
+    uint32_t e[2][4], o[2][4];
+    rg_perm_pair(p0, q0, p1, q1, ad0 & 3u, e[0], o[0]);
     // (the second pair's registers are written by the LDS until here: they pass through this statement and nothing else)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p2), "+v"(q2), "+v"(p3), "+v"(q3) : : "memory");
-    rg_funnel_pair(p2, q2, p3, q3, ad2 & 3u, x[1]);
+    rg_perm_pair(p2, q2, p3, q3, ad2 & 3u, e[1], o[1]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        acc[2 * j] = acc[2 * j] + (x[0][j] & 0x00FF00FFu) + (x[1][j] & 0x00FF00FFu);
-        // odd bytes: the running sum of (dword >> 8) = sum(4j + 1) + 2^8 sum(4j + 2) + 2^16 sum(4j + 3), separated by rg_odd()
-        // when the sums leave the registers (v_lshrrev issues at twice the rate of the v_perm that would pick the two odd
-        // bytes: profiles/r03_issue_rates.md; 652 patches of at most 100 keep the sum below 2^32)
-        if (j < 3) // (acc[7] would hold hypotheses 13 and 15 of the lane: there are only 13)
-            acc[2 * j + 1] = acc[2 * j + 1] + (x[0][j] >> 8) + (x[1][j] >> 8);
+        acc[2 * j] = acc[2 * j] + e[0][j] + e[1][j];
+        if (j < 3) acc[2 * j + 1] = acc[2 * j + 1] + o[0][j] + o[1][j];
     }
 }
 
-// acc[2j + 1] as rg_gather4 keeps it -> hypotheses 4j + 1 (low 16 bits) and 4j + 3
-__device__ __forceinline__ void rg_odd(uint32_t (&acc)[8]) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[2 * j + 1] -= (acc[2 * j] >> 16) << 8;
-}
+// (until round 4 the odd accumulators held the running sum of dword >> 8 and were separated here; v_perm hands them over as
+//  clean 16-bit fields, so this is the identity -- kept as the one place that says what layout the sums leave the loop in:
+//  acc[2j] = hypotheses 4j | 4j + 2 << 16, acc[2j + 1] = 4j + 1 | 4j + 3 << 16)
+__device__ __forceinline__ void rg_odd(uint32_t (&)[8]) {}
 
 // grid (P, B): block (p, item) = NW waves, wave w owns coarse angle p * NW + w.  Lane = 13 x-adjacent hypotheses of one
 // lattice row: row = lane & 31, half = lane >> 5 (nx <= 26, ny <= 32: checked on the host).
@@ -601,7 +605,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 for (int i = g * YM_RG_FLUSH; i < i1; i++)
                     sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
                 acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
-                if ((j & 3) == 2) acc[2 * (j >> 2) + 1] += sum << 8; // (what the sum of dword >> 8 holds of byte 2)
             }
             flush();
         }
@@ -794,7 +797,6 @@ __global__ __launch_bounds__(64 * YM_WS_NG) void region_percell_kernel(RegionArg
                 for (int i = gs * YM_RG_FLUSH; i < i1; i++)
                     sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
                 acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
-                if ((j & 3) == 2) acc[2 * (j >> 2) + 1] += sum << 8; // (what the sum of dword >> 8 holds of byte 2)
             }
         rg_odd(acc);
         store_partial16(a.partial + (size_t)b * a.partial_stride + (((size_t)gs * nt + k) * 64 + lane) * 16, acc);
