@@ -229,7 +229,6 @@ struct CallPlan {
     int cell_box[4] = {INT32_MIN, INT32_MIN, INT32_MAX, INT32_MAX}; // chained steps: window cells whose smear stays inside the launched tiles
     bool use_tile_list = false;
     bool use_tile_hits = false;
-    int hit_cap = 0;
     unsigned long long *stamps = nullptr;
     // batches: heavy work once per distinct scan (points_kernel), then the light cells_kernel
     bool split_prepare = false;
@@ -587,11 +586,10 @@ struct ym_matcher {
     int cache_off = 0;                     // development: 1 = never cache (every call projects every scan)
     int64_t cache_hits = 0, cache_misses = 0;
     DevBuf<unsigned> sel_scratch; // select on long chains: hash, states and neighbour lists in global memory
-    DevBuf<uint16_t> tile_list; // raster work list per item
+    DevBuf<uint32_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
     DevBuf<int32_t> tile_max;        // [1] longest raster work list of the call
-    DevBuf<uint16_t> tile_hits;      // per tile of the raster's rectangle: the chunk boxes that reach it
-    DevBuf<int32_t> tile_hit_start;
+    DevBuf<uint16_t> tile_hits;      // per entry of the work list: the chunks that reach its tile (YM_TILE_HITS slots)
     int32_t *tile_max_host = nullptr; // pinned: the raster kernel leaves that number here, the next call sizes its grid by it
     int finish_form = 0; // development: 1 = fine_kernel + final_kernel even on batches, 2 = finish_kernel always
     int corr_chunks = 0; // development: force the number of beam chunks of the correlate kernel
@@ -605,7 +603,7 @@ struct ym_matcher {
     int corr_region_cap = 0;   // tests: units per LDS buffer (a multiple of 64; small values force chunked regions)
     int corr_region_lds = 0;   // development / tests: LDS bytes a gather block may use (small values force many regions)
     int raster_gx = 0;      // tests: raster blocks per item (0 = by the previous call's longest work list)
-    int raster_hits_per_tile = 0; // tests: room in the per-tile hit lists (0 = 32 per tile, -1 = no lists)
+    int raster_hits_per_tile = 0; // tests: hit slots per entry of the raster's work list (0 = YM_TILE_HITS, -1 = no hit lists)
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
@@ -1456,14 +1454,12 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
         if ((rc = m->tile_list.ensure((size_t)B * P.tile_cap))) return rc;
         if ((rc = m->tile_count.ensure(B))) return rc;
         if ((rc = m->tile_max.ensure(1))) return rc;
-        // hit lists per tile (32 per tile on average is four times what the bench scans need; an item that needs more
-        // is scanned by the raster blocks themselves)
-        P.use_tile_hits = P.max_base * YM_N_BOXES(P.max_n) < 65536 && P.tile_cap <= 8192;
-        P.hit_cap = (m->raster_hits_per_tile > 0 ? m->raster_hits_per_tile : 32 * P.tile_h / YM_TILE_H) * P.tile_cap;
+        // hit slots per list entry (YM_TILE_HITS = 64 is four times what the bench scans need of a tall tile; the block of a
+        // tile more chunks reach walks the item's boxes itself): a chunk is named by its first cell's index, 16 bits
+        P.use_tile_hits = (long long)P.max_base * P.max_n < 65536 && P.tile_cap <= 8192;
         if (m->raster_hits_per_tile < 0) P.use_tile_hits = false;
         if (P.use_tile_hits) {
-            if ((rc = m->tile_hits.ensure((size_t)B * P.hit_cap))) return rc;
-            if ((rc = m->tile_hit_start.ensure((size_t)B * (P.tile_cap + 1)))) return rc;
+            if ((rc = m->tile_hits.ensure((size_t)B * P.tile_cap * YM_TILE_HITS))) return rc;
         }
         if (!m->tile_max_host) {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->tile_max_host), sizeof(int32_t), hipHostMallocDefault));
@@ -1544,13 +1540,14 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
         ym::TilesArgs t;
         t.bbox = m->bbox.p; t.tile_list = m->tile_list.p; t.tile_count = m->tile_count.p; t.tile_zero = m->tile_zero.p;
         t.tile_max = m->tile_max.p;
-        t.hits = P.use_tile_hits ? m->tile_hits.p : nullptr; t.hit_start = m->tile_hit_start.p; t.hit_cap = P.hit_cap; t.tile_h = P.tile_h;
+        t.hits = P.use_tile_hits ? m->tile_hits.p : nullptr; t.tile_h = P.tile_h;
+        t.hit_limit = m->raster_hits_per_tile > 0 ? std::min(m->raster_hits_per_tile, YM_TILE_HITS) : YM_TILE_HITS;
         (void)hipMemsetAsync(m->tile_max.p, 0, sizeof(int32_t), st);
         t.max_n = P.max_n; t.max_base = P.max_base; t.half_kernel = g.half_kernel;
         t.tiles_x = P.tiles_x; t.tiles_y = P.tiles_y; t.tile_cap = P.tile_cap;
         for (int k = 0; k < 4; k++) t.launch[k] = P.launch[k];
         hipLaunchKernelGGL(ym::tiles_kernel, dim3(P.B), dim3(YM_TILES_THREADS),
-                           (size_t)4 * ((P.tiles_x * P.tiles_y + 31) / 32) + (P.use_tile_hits ? (size_t)4 * P.tile_cap : 0), st, t);
+                           (size_t)4 * ((P.tiles_x * P.tiles_y + 31) / 32) + (P.use_tile_hits ? (size_t)8 * P.tile_cap : 0), st, t);
     }
     ym::RasterArgs a;
     a.tiles_x = P.tiles_x; a.tiles_y = P.tiles_y; a.tile_x0 = P.launch[0]; a.tile_y0 = P.launch[1]; a.ltx = P.ltx;
@@ -1559,7 +1556,7 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
     a.tile_zero = m->tile_zero.p; a.planes_only = m->raster_planes_only; a.pad = 0;
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
-    a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.hit_start = m->tile_hit_start.p; a.hit_cap = P.hit_cap; a.lty = P.lty;
+    a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.lty = P.lty; a.pad0 = 0;
     int rc;
     hipEvent_t ev_k = nullptr;
     if ((rc = prof_begin(m, 1, &ev_k))) return rc;
@@ -1572,15 +1569,15 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
         a.first_overflow = gx;
         if (P.use_tile_list) {
             if (P.tile_h == YM_TILE_H_TALL) {
-                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H_TALL>), dim3(gx, P.B), dim3(128), 0, st, a);
-                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H_TALL>), dim3(4, P.B), dim3(128), 0, st, a);
+                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H_TALL, true>), dim3(gx, P.B), dim3(128), 0, st, a);
+                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H_TALL, true>), dim3(4, P.B), dim3(128), 0, st, a);
             } else {
-                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H>), dim3(gx, P.B), dim3(128), 0, st, a);
-                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H>), dim3(4, P.B), dim3(128), 0, st, a);
+                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H, true>), dim3(gx, P.B), dim3(128), 0, st, a);
+                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H, true>), dim3(4, P.B), dim3(128), 0, st, a);
             }
         } else {
-            if (P.tile_h == YM_TILE_H_TALL) hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H_TALL>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
+            if (P.tile_h == YM_TILE_H_TALL) hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H_TALL, false>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H, false>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
         }
     }
     return prof_end(m, ev_k);
@@ -2258,7 +2255,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->tile_hit_start.release(); m->sel_scratch.release();
+    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release();
     m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();

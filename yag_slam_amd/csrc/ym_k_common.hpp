@@ -187,5 +187,6 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 #define YM_TILE_W 64
 #define YM_TILE_H 32      // raster tile: 64 x 32 cells -- or 64 x 64 (YM_TILE_H_TALL) on large batches with large windows, chosen per call
 #define YM_TILE_H_TALL 64
+#define YM_TILE_HITS 64    // hit slots per entry of the raster's work list: the chunks that reach the entry's tile (four times what the bench scans need of a tall tile)
 
 }  // namespace ym

@@ -580,7 +580,8 @@ __global__ __launch_bounds__(256) void cells_kernel(PrepareArgs a) {
 #define YM_TILES_THREADS 256
 struct TilesArgs {
     const int4 *bbox;        // [B][max_base][YM_N_BOXES(max_n)]
-    uint16_t *tile_list;     // [B][tile_cap] tile index (tiy * tiles_x + tix), | 0x8000 = only needs clearing
+    uint32_t *tile_list;     // [B][tile_cap] tile index (tiy * tiles_x + tix), | 0x8000 = only needs clearing, | hits << 16 (0xffff =
+                             // more than YM_TILE_HITS: the raster block walks the item's boxes)
     int32_t *tile_count;     // [B]
     int32_t *tile_max;       // longest list of the call (zeroed by the host before the launch)
     const uint8_t *tile_zero;// [B][tiles_y][tiles_x] 1 = the tile's memory is known to hold zeros
@@ -588,23 +589,24 @@ struct TilesArgs {
     int32_t tiles_x, tiles_y, tile_cap;
     int32_t launch[4];       // tile rectangle (x0, y0, x1, y1) the raster covers in this call
     // per tile of that rectangle the chunk boxes that reach it, so that a raster block does not scan every box of the item:
-    uint16_t *hits;          // [B][hit_cap] box indices, tile after tile; null = no lists (the raster scans)
-    int32_t *hit_start;      // [B][tile_cap + 1] first hit of sub-grid tile i; [0] = -1: the lists did not fit hit_cap
-    int32_t hit_cap;
+    // per LIST ENTRY the chunks that reach its tile, so that a raster block neither scans every box of the item nor looks
+    // anything up before it can load them (their address depends on the entry's position alone):
+    uint16_t *hits;          // [B][tile_cap][YM_TILE_HITS] index of the chunk's first cell in the item's cells; null = no lists (the raster walks the boxes)
     int32_t tile_h;          // rows per tile in this call (YM_TILE_H or YM_TILE_H_TALL)
+    int32_t hit_limit;       // hit slots in use, <= YM_TILE_HITS (tests lower it)
 };
-// grid (B), dynamic LDS = 4 * ceil(tiles_x * tiles_y / 32) bytes (+ 4 bytes per tile of the rectangle with hit lists)
+// grid (B), dynamic LDS = 4 * ceil(tiles_x * tiles_y / 32) bytes (+ 8 bytes per tile of the rectangle with hit lists)
 __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
     extern __shared__ unsigned tile_bits[];
     __shared__ int s_n;
-    __shared__ int s_wave_tot[YM_TILES_THREADS / 64];
     constexpr int NT = YM_TILES_THREADS;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ntiles = a.tiles_x * a.tiles_y, nwords = (ntiles + 31) / 32;
     const int h = a.half_kernel;
     const int lx0 = a.launch[0], ly0 = a.launch[1], lx1 = a.launch[2], ly1 = a.launch[3];
     const int ltx = lx1 - lx0 + 1, lty = ly1 - ly0 + 1, nsub = ltx * lty;
-    int *cnt = reinterpret_cast<int *>(tile_bits + nwords); // [nsub] hits per tile of the rectangle, then fill positions
+    int *cnt = reinterpret_cast<int *>(tile_bits + nwords); // [nsub] hits per tile of the rectangle
+    int *fill = cnt + nsub;                                 // [nsub] list position << 16 | hit slots filled
     for (int i = tid; i < nwords; i += NT) tile_bits[i] = 0u;
     if (a.hits)
         for (int i = tid; i < nsub; i += NT) cnt[i] = 0;
@@ -627,11 +629,16 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
     }
     __syncthreads();
     const uint8_t *tz = a.tile_zero + (size_t)b * ntiles;
-    uint16_t *list = a.tile_list + (size_t)b * a.tile_cap;
+    uint32_t *list = a.tile_list + (size_t)b * a.tile_cap;
     for (int i = tid; i < nsub; i += NT) {
         const int ty = ly0 + i / ltx, tx = lx0 + i % ltx, t = ty * a.tiles_x + tx;
         const bool hit = (tile_bits[t >> 5] >> (t & 31)) & 1u;
-        if (hit || tz[t] == 0) list[atomicAdd(&s_n, 1)] = (uint16_t)(t | (hit ? 0 : 0x8000));
+        if (hit || tz[t] == 0) {
+            const int at = atomicAdd(&s_n, 1);
+            const uint32_t nh = !a.hits ? 0xffffu : cnt[i] > a.hit_limit ? 0xffffu : (uint32_t)cnt[i];
+            list[at] = (uint32_t)(t | (hit ? 0 : 0x8000)) | nh << 16;
+            if (a.hits) fill[i] = at << 16;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -639,44 +646,23 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
         if (s_n > *reinterpret_cast<volatile int32_t *>(a.tile_max)) atomicMax(a.tile_max, s_n); // (few blocks raise it)
     }
     if (!a.hits) return;
-    // the hit lists: exclusive scan of the counts (thread t owns tiles [t * per, (t + 1) * per)), then every box again
-    int32_t *hstart = a.hit_start + (size_t)b * (a.tile_cap + 1);
-    const int per = (nsub + NT - 1) / NT, first = tid * per;
-    int local = 0;
-    for (int j = 0; j < per; j++) if (first + j < nsub) local += cnt[first + j];
-    int incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if ((tid & 63) >= d) incl += v;
-    }
-    if ((tid & 63) == 63) s_wave_tot[tid >> 6] = incl;
-    __syncthreads();
-    int base = 0, all = 0;
-    for (int w = 0; w < NT / 64; w++) {
-        if (w < (tid >> 6)) base += s_wave_tot[w];
-        all += s_wave_tot[w];
-    }
-    const bool fits = all <= a.hit_cap;
-    int run = base + incl - local;
-    for (int j = 0; j < per; j++)
-        if (first + j < nsub) {
-            const int c = cnt[first + j];
-            cnt[first + j] = run;
-            hstart[first + j] = fits ? run : -1;
-            run += c;
-        }
-    if (tid == 0) hstart[nsub] = fits ? all : -1;
-    if (!fits) return; // (block-uniform: the raster scans the boxes of this item itself)
-    __syncthreads();
-    uint16_t *hits = a.hits + (size_t)b * a.hit_cap;
+    // the hit slots: every box again, to the entries of the tiles it reaches (in any order: the raster ORs bits)
+    uint16_t *hits = a.hits + (size_t)b * a.tile_cap * YM_TILE_HITS;
+    const int n_cchunks = YM_N_BOXES(a.max_n);
     for (int c = tid; c < n_boxes; c += NT) {
         const int4 bb = bbox[c];
         if (bb.x > bb.z) continue;
+        const int slot = c / n_cchunks;
+        const uint16_t first_cell = (uint16_t)(slot * a.max_n + (c - slot * n_cchunks) * YM_BOX_CELLS); // (the host: max_base * max_n < 65536)
         const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
         const int ty0 = max(ly0, max(bb.y - h, 0) / a.tile_h), ty1 = min(ly1, (bb.w + h) / a.tile_h);
         for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) hits[atomicAdd(&cnt[(ty - ly0) * ltx + (tx - lx0)], 1)] = (uint16_t)c;
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int i = (ty - ly0) * ltx + (tx - lx0);
+                if (cnt[i] > a.hit_limit) continue;
+                const int old = atomicAdd(&fill[i], 1);
+                hits[(size_t)(old >> 16) * YM_TILE_HITS + (old & 0xffff)] = first_cell;
+            }
     }
 }
 

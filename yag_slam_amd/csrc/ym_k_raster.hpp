@@ -19,13 +19,14 @@ struct RasterArgs {
     int32_t tiles_x, tiles_y; // full tiling of the window
     int32_t tile_x0, tile_y0; // first tile of the launched sub-grid (tiles outside it are known to be zero)
     int32_t ltx;              // tile columns of the launched sub-grid
-    const uint16_t *tile_list; // [B][tile_cap] work list built by tiles_kernel, or null: one block per sub-grid tile
+    const uint32_t *tile_list; // [B][tile_cap] work list built by tiles_kernel (tile | 0x8000 = clear only | hits << 16, 0xffff = more
+                               // than the tile's hit slots hold), or null: one block per sub-grid tile
     const int32_t *tile_count; // [B]
     int32_t tile_cap;
     int32_t first_overflow;    // OVERFLOW launch: the first list entry the main launch's grid did not reach
-    const uint16_t *hits;      // [B][hit_cap] per sub-grid tile the chunk boxes that reach it (tiles_kernel), or null
-    const int32_t *hit_start;  // [B][tile_cap + 1]; [0] = -1: this item has no lists
-    int32_t hit_cap, lty;
+    const uint16_t *hits;      // [B][tile_cap][YM_TILE_HITS] per LIST ENTRY the chunks that reach its tile, as the index of the chunk's
+                               // first cell in the item's cells (tiles_kernel), or null: the blocks walk the item's boxes
+    int32_t lty, pad0;
     const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
     int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
     int32_t planes_only, pad;  // timing experiment: 1 = the row-major window is not written
@@ -44,10 +45,15 @@ struct RasterArgs {
 // blocks per CU -- the tiles with work are latency-bound, so a batch gains (raster 160 -> 140 us on 256 items)
 // TH = 32 rows per tile, or 64: half the blocks, a sixth less halo (4096 items: raster 1.63 -> 1.44 ms), but longer
 // blocks -- a single match loses 6 us, the loop lattice's small windows 3 % --, so the host picks per call.
-template <int NT, bool OVERFLOW, int TH>
+// LISTED (batches, tiles_kernel ran): block x of an item takes entry x of the item's work list.  What a block needs to start --
+// its entry and the first 32 of the tile's hit slots -- sits at addresses that depend on (item, x) alone, so ONE memory round
+// trip brings it all, the second one the cells (round 4; before: list entry -> the tile's hit_start pair -> its hits -> LDS ->
+// cells, four dependent round trips, and the raster was bound by exactly that chain times the 11 blocks a CU held: its two
+// passes are 9 % of its time).  No hit staging in LDS either: 10 KB per block, 15 blocks per CU.
+template <int NT, bool OVERFLOW, int TH, bool LISTED>
 __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     constexpr int TW = YM_TILE_W, HM = YM_MAX_KERNEL_HALF;
-    constexpr int MAXHITS = 256 * TH / 32;             // chunk boxes a block lists for its tile before it walks all boxes
+    constexpr int MAXHITS = LISTED ? 1 : 256 * TH / 32; // chunk boxes an unlisted block lists for its tile before it walks all boxes
     constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
     constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
     __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
@@ -61,8 +67,8 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     // grid (x, B).  With a work list (batches) block i takes entry i of its item's list; without one (a few items: one
     // more launch would cost more than it saves) block i is tile i of the sub-grid and finds out by itself whether any
     // chunk box reaches it.
-    const bool listed = a.tile_list != nullptr;
-    auto one_tile = [&](unsigned entry, int bi) { // (bi = b; opaque to the optimiser in the list loop, see below)
+    // (hq[u]: hit slot tid / 16 + u * (NT / 16) of the entry, loaded by the caller together with the entry)
+    auto one_tile = [&](unsigned entry, int bi, const uint16_t *hl, const unsigned (&hq)[4]) { // (bi = b; opaque to the optimiser in the list loop, see below)
     const int tile = (int)(entry & 0x7fffu);
     const int h = a.g.half_kernel;
     const int OW = TW + 2 * h, OH = TH + 2 * h;
@@ -100,18 +106,13 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         if (tid == 0) *tz = 1;
         return;
     }
-    // with hit lists (batches) the chunks that reach this tile are known: no scan of the item's boxes
-    const int32_t *hstart = a.hits ? a.hit_start + (size_t)bi * (a.tile_cap + 1) : nullptr;
-    int h0 = 0, hn = -1;
-    if (hstart && hstart[0] >= 0) {
-        const int ti = (tiy - a.tile_y0) * a.ltx + (tix - a.tile_x0);
-        h0 = hstart[ti];
-        hn = hstart[ti + 1] - h0;
-        if (hn > MAXHITS) hn = -1; // (more than the list holds: scan)
+    // LISTED: the entry says how many chunks reach the tile; their first cells are in the entry's hit slots
+    const int hn = LISTED ? ((a.hits && (entry >> 16) != 0xffffu) ? (int)(entry >> 16) : -1) : -1; // -1: walk the boxes
+    if constexpr (!LISTED) {
+    if (tid == 0) s_nhits = 0;
     }
-    if (tid == 0) s_nhits = hn >= 0 ? hn : 0;
     int4 bb_first = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN); // this thread's first box: kept for the second pass
-    if (!listed) { // decide "no box at all" before touching LDS
+    if constexpr (!LISTED) { // decide "no box at all" before touching LDS
         int my_hits = 0;
         for (int c = tid; c < n_boxes; c += NT) {
             const int4 bb = bbox[c];
@@ -127,60 +128,48 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
             }
             return;
         }
-    } else {
-        __syncthreads();
-    }
-    // chunks whose box touches tile + halo, compacted so that the cell loads of several chunks are in flight together
-    if (hn >= 0) {
-        const uint16_t *hl = a.hits + (size_t)bi * a.hit_cap + h0;
-        for (int i = tid; i < hn; i += NT) {
-            const int c = hl[i];
-            const int slot = c / n_cchunks, first = (c - slot * n_cchunks) * YM_BOX_CELLS;
-            s_hits[i] = slot * a.max_n + first;
-            s_left[i] = a.max_n - first;
-        }
-    } else
-    for (int c = tid; c < n_boxes; c += NT) {
-        const int4 bb = (!listed && c == tid) ? bb_first : bbox[c]; // (a single match: 170 boxes, one per thread, no second load)
-        if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
-            const int at = atomicAdd(&s_nhits, 1);
-            if (at < MAXHITS) { // the chunk's first cell and how many it holds (the division once per hit, not per cell)
-                const int slot = c / n_cchunks, first = (c - slot * n_cchunks) * YM_BOX_CELLS;
-                s_hits[at] = slot * a.max_n + first;
-                s_left[at] = a.max_n - first;
+        // chunks whose box touches tile + halo, compacted so that the cell loads of several chunks are in flight together
+        for (int c = tid; c < n_boxes; c += NT) {
+            const int4 bb = c == tid ? bb_first : bbox[c]; // (a single match: 170 boxes, one per thread, no second load)
+            if (bb.x <= hi_x && bb.z >= lo_x && bb.y <= hi_y && bb.w >= lo_y) {
+                const int at = atomicAdd(&s_nhits, 1);
+                if (at < MAXHITS) { // the chunk's first cell and how many it holds (the division once per hit, not per cell)
+                    const int slot = c / n_cchunks, first = (c - slot * n_cchunks) * YM_BOX_CELLS;
+                    s_hits[at] = slot * a.max_n + first;
+                    s_left[at] = a.max_n - first;
+                }
             }
+        }
+    }
+    // LISTED: the cells of the first NT * 4 work items (hit slot, cell of the chunk) leave now, before the LDS tables are cleared
+    const int2 *cells = a.cells + (size_t)bi * a.max_base * a.max_n;
+    const int n_cells = a.max_base * a.max_n;
+    int2 cc0[4];
+    if constexpr (LISTED) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int hi = tid / YM_BOX_CELLS + u * (NT / YM_BOX_CELLS);
+            // (a chunk's 16 cells may run past its scan's last reading into the next scan's first ones: the same item's occupied
+            //  cells, stamped again -- harmless; past the item's last cell they would be another item's)
+            const int ci = (int)hq[u] + (tid % YM_BOX_CELLS);
+            cc0[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+            if (hi < hn && ci < n_cells) cc0[u] = cells[ci];
         }
     }
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
     if (tid < (TW / 8) * 4) (&colany[0][0])[tid] = 0u;
     for (int i = tid; i <= 2 * h * h + 1; i += NT) lut[i] = i <= 2 * h * h ? a.lut[i] : (unsigned char)0;
     __syncthreads();
-    const int nhits = s_nhits;
-    const int2 *cells = a.cells + (size_t)bi * a.max_base * a.max_n;
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
-    if (nhits <= MAXHITS) {
-        // work item = (hit chunk, cell of the chunk); 4 items per thread in flight
-        const int nwork = nhits * YM_BOX_CELLS;
-        for (int w0 = 0; w0 < nwork; w0 += 4 * NT) {
-            int2 cc[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int w = w0 + u * NT + tid;
-                cc[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
-                if (w < nwork && (w % YM_BOX_CELLS) < s_left[w / YM_BOX_CELLS]) cc[u] = cells[s_hits[w / YM_BOX_CELLS] + (w % YM_BOX_CELLS)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int lx = cc[u].x - lo_x, ly = cc[u].y - lo_y;
-                if (cc[u].x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
-                    atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
-                    any = 1;
-                }
-            }
+    auto stamp = [&](const int2 c2) {
+        const int lx = c2.x - lo_x, ly = c2.y - lo_y;
+        if (c2.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
+            atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
+            any = 1;
         }
-    } else {
-        // more hit chunks than the list holds: walk every box (rare)
+    };
+    auto walk_boxes = [&]() { // every box of the item, the cells of those that touch tile + halo
         for (int c0 = 0; c0 < n_boxes; c0 += NT) {
             const int c = c0 + tid;
             bool hit = false;
@@ -195,16 +184,54 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                 const int chunk = c0 + (tid & ~63) + bit; // wave-uniform
                 const int slot = chunk / n_cchunks, ci = chunk - slot * n_cchunks;
                 const int i = ci * YM_BOX_CELLS + (tid & 63);
-                if ((tid & 63) < YM_BOX_CELLS && i < a.max_n) {
-                    const int2 c2 = cells[(size_t)slot * a.max_n + i];
-                    const int lx = c2.x - lo_x, ly = c2.y - lo_y;
-                    if (c2.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
-                        atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
-                        any = 1;
-                    }
-                }
+                if ((tid & 63) < YM_BOX_CELLS && i < a.max_n) stamp(cells[(size_t)slot * a.max_n + i]);
             }
         }
+    };
+    int nhits = 0;
+    if constexpr (LISTED) {
+        nhits = hn;
+        if (hn >= 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) stamp(cc0[u]);
+            // (a tile more than NT / 4 chunks reach: the remaining hit slots, then their cells -- two more round trips)
+            for (int h0 = NT / 4; h0 < hn; h0 += NT / 4) {
+                int2 cc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int hi = h0 + tid / YM_BOX_CELLS + u * (NT / YM_BOX_CELLS);
+                    cc[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+                    if (hi < hn) {
+                        const int ci = (int)hl[hi] + (tid % YM_BOX_CELLS);
+                        if (ci < n_cells) cc[u] = cells[ci];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) stamp(cc[u]);
+            }
+        } else {
+            walk_boxes();
+        }
+    } else {
+    nhits = s_nhits;
+    if (nhits <= MAXHITS) {
+        // work item = (hit chunk, cell of the chunk); 4 items per thread in flight
+        const int nwork = nhits * YM_BOX_CELLS;
+        for (int w0 = 0; w0 < nwork; w0 += 4 * NT) {
+            int2 cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = w0 + u * NT + tid;
+                cc[u] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+                if (w < nwork && (w % YM_BOX_CELLS) < s_left[w / YM_BOX_CELLS]) cc[u] = cells[s_hits[w / YM_BOX_CELLS] + (w % YM_BOX_CELLS)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) stamp(cc[u]);
+        }
+    } else {
+        // more hit chunks than the list holds: walk every box (rare)
+        walk_boxes();
+    }
     }
     any = __syncthreads_or(any);
     YM_STAMP(a, 5);
@@ -336,19 +363,37 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     }
     YM_STAMP(a, 7);
     }; // one_tile
-    if (listed) {
+    if constexpr (LISTED) {
         // The grid's x size is a guess (the longest list of the previous call + 1/8, yagmatch.hip): launching one block per
         // tile of the sub-grid cost 80 us per 1024 items in blocks that only found the list exhausted.  Block x takes entry
         // x; what a longer list holds beyond the grid is done by the OVERFLOW instantiation, a second launch of a few blocks
         // per item that walk the rest (its loop keeps every per-item constant in registers: 106 SGPRs, 9 spilled -- not
         // something the one-tile-per-block kernel should pay for).
-        const int count = a.tile_count[b];
+        // An entry and its first hit slots are loaded together with the item's count, whatever the count says (the list
+        // has tile_cap >= gridDim.x slots per item): one round trip, not two.
+        const uint32_t *list = a.tile_list + (size_t)b * a.tile_cap;
+        const uint16_t *hits = a.hits ? a.hits + (size_t)b * a.tile_cap * YM_TILE_HITS : nullptr;
+        auto load_entry = [&](int e, unsigned &entry, const uint16_t *&hl, unsigned (&hq)[4]) {
+            entry = list[e];
+            hl = hits ? hits + (size_t)e * YM_TILE_HITS : nullptr;
+#pragma unroll
+            for (int u = 0; u < 4; u++) hq[u] = hl ? (unsigned)hl[tid / YM_BOX_CELLS + u * (NT / YM_BOX_CELLS)] : 0u;
+        };
+        static_assert(NT / 4 <= YM_TILE_HITS, "the first round of hit slots must exist");
         if (!OVERFLOW) {
+            unsigned entry, hq[4];
+            const uint16_t *hl;
+            load_entry((int)blockIdx.x, entry, hl, hq);
+            const int count = a.tile_count[b];
             if (blockIdx.x == 0 && b == 0 && tid == 0 && a.tile_max_host) *a.tile_max_host = *a.tile_max;
-            if ((int)blockIdx.x < count) one_tile(a.tile_list[(size_t)b * a.tile_cap + blockIdx.x], b);
+            if ((int)blockIdx.x < count) one_tile(entry, b, hl, hq);
         } else {
+            const int count = a.tile_count[b];
             for (int e = a.first_overflow + (int)blockIdx.x; e < count; e += (int)gridDim.x) {
-                one_tile(a.tile_list[(size_t)b * a.tile_cap + e], b);
+                unsigned entry, hq[4];
+                const uint16_t *hl;
+                load_entry(e, entry, hl, hq);
+                one_tile(entry, b, hl, hq);
                 __syncthreads(); // (the LDS tables are reused)
             }
         }
@@ -356,7 +401,8 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         const int sy = (int)blockIdx.x / a.ltx, sx = (int)blockIdx.x - sy * a.ltx;
         // rotate the tile column by the row: a sub-grid width that is a multiple of 8 would otherwise pin every
         // tile column (i.e. every wall) to one XCD
-        one_tile((unsigned)((a.tile_y0 + sy) * a.tiles_x + a.tile_x0 + (sx + 3 * sy + 5 * b) % a.ltx), b);
+        const unsigned hq[4] = {0u, 0u, 0u, 0u};
+        one_tile((unsigned)((a.tile_y0 + sy) * a.tiles_x + a.tile_x0 + (sx + 3 * sy + 5 * b) % a.ltx), b, nullptr, hq);
     }
 }
 
