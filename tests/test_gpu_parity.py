@@ -1100,6 +1100,43 @@ def test_raster_grid_shorter_than_the_tile_list():
             assert np.array_equal(g, r)
 
 
+@pytest.mark.parametrize("sigma_cells", [1.0, 3.0, 6.0, 7.0])
+def test_raster_row_tables_are_invisible(sigma_cells):
+    """The raster's row pass finds an 8-cell group's distances to the nearest occupied cell of its row in tables indexed by
+    seven bitmap bits at a time (kernel half widths up to 12: smear deviations up to 6 cells; beyond that by 64-bit bit scans).
+    The same windows, byte for byte, as the bit scans (debug option 37) and as the oracle's max-stamp -- single match
+    (one block per tile) and a batch of 50 (work lists, hit slots) -- for kernel halves 2, 6, 12 and 14."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans()
+    cfg = {"smear_deviation": 0.01 * sigma_cells, "use_response_expansion": False}
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    chains = [nb[:max(1, len(nb) - (c % 4))] for c in range(50)]
+    o = orc.Oracle(cfg, "karto")
+    o.match_scan(q, base, True, True)
+    og, _ = o.grid_u8()
+    seen = None
+    for scans in (0, 1, 0):
+        m = ScanMatcher(cfg)
+        m.debug_option(37, scans)
+        r = m.match_scan(nq, nb, True, True)
+        g, info = m.debug_grid()
+        per, _ = m.match_scan_batch(nq, chains, True, True)
+        gb = [m.debug_grid(item=i)[0] for i in (0, 3, 49)]
+        key = (r.response, r.covariance, tuple(p.response for p in per))
+        if seen is None:
+            seen = (key, g.copy(), [x.copy() for x in gb])
+            sub = og[info.origin_y:info.origin_y + info.height, info.origin_x:info.origin_x + info.width]
+            assert np.array_equal(g, sub), "grid window differs from the oracle's in %d cells" % int((g != sub).sum())
+            assert np.array_equal(gb[0], g)
+        else:
+            assert key == seen[0]
+            assert np.array_equal(g, seen[1])
+            for x, y in zip(gb, seen[2]):
+                assert np.array_equal(x, y)
+        m.close()
+
+
 @pytest.mark.parametrize("nx", [3, 7, 13, 16, 17, 26, 27, 32, 33, 41, 47])
 def test_region_correlate_lattice_widths(nx):
     """The gather correlate gives a lane 16 x-adjacent hypotheses of one lattice row, a wave up to 32 rows of two such

@@ -505,6 +505,8 @@ struct ym_matcher {
     DevBuf<double2> map_pts;      // match against a map: the query point set
     int z2max = 0;               // largest squared cell distance whose kernel value is 100
     DevBuf<uint8_t> ktab;
+    DevBuf<uint8_t> rowtab;   // the raster's row-pass tables (upload_lut)
+    int n_rowtab = 0;
     // workspace
     DevBuf<unsigned char> desc_dev; // batch call descriptors (single calls travel in the kernel arguments)
     DevBuf<YmItemState> states;
@@ -547,6 +549,7 @@ struct ym_matcher {
     int item_min_batch = 1 << 30; // batches from this many items on take correlate_item_kernel
     bool item_lds_set = false;
     int raster_planes_only = 0; // timing experiment (option 36): the raster does not write the row-major window
+    int raster_no_rowtab = 0;   // tests (option 37): the raster's row pass by bit scans instead of its tables
     int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
@@ -743,6 +746,28 @@ int upload_lut(ym_matcher *m) {
     int rc = m->ktab.ensure(q.size());
     if (rc) return rc;
     HIP_TRY(hipMemcpy(m->ktab.p, q.data(), q.size(), hipMemcpyHostToDevice));
+    // the raster's row pass (ym_k_raster.hpp): an 8-cell group sees the 8 + 2h bitmap bits [0, 8 + 2h) of its row, cell q
+    // sits at bit q + h.  Table j, indexed by the seven bits 7j .. 7j + 6, holds for every cell the distance to the nearest
+    // of THOSE bits that is set and at most h away (127: none); the group's distances are the byte-wise minimum over j.
+    m->n_rowtab = 0;
+    if (2 * h + 8 <= 32) {
+        const int nt = (2 * h + 8 + 6) / 7;
+        std::vector<uint8_t> t((size_t)nt * 128 * 8);
+        for (int j = 0; j < nt; j++)
+            for (int v = 0; v < 128; v++)
+                for (int c = 0; c < 8; c++) {
+                    int best = 127;
+                    for (int i = 0; i < 7; i++)
+                        if ((v >> i) & 1) {
+                            const int d = std::abs(7 * j + i - (c + h));
+                            if (d <= h && d < best) best = d;
+                        }
+                    t[((size_t)j * 128 + v) * 8 + c] = (uint8_t)best;
+                }
+        if ((rc = m->rowtab.ensure(t.size()))) return rc;
+        HIP_TRY(hipMemcpy(m->rowtab.p, t.data(), t.size(), hipMemcpyHostToDevice));
+        m->n_rowtab = nt;
+    }
     return YM_OK;
 }
 
@@ -1554,7 +1579,9 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.tile_list = P.use_tile_list ? m->tile_list.p : nullptr; a.tile_count = m->tile_count.p; a.tile_cap = P.tile_cap;
     a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
-    a.tile_zero = m->tile_zero.p; a.planes_only = m->raster_planes_only; a.pad = 0;
+    a.tile_zero = m->tile_zero.p; a.planes_only = m->raster_planes_only;
+    a.n_rowtab = m->raster_no_rowtab ? 0 : m->n_rowtab; a.rowtab = reinterpret_cast<const uint2 *>(m->rowtab.p);
+    const size_t rlds = YM_RASTER_LDS_BYTES(P.tile_h, g.half_kernel, a.n_rowtab);
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
     a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.lty = P.lty; a.pad0 = 0;
     int rc;
@@ -1569,15 +1596,15 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
         a.first_overflow = gx;
         if (P.use_tile_list) {
             if (P.tile_h == YM_TILE_H_TALL) {
-                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H_TALL, true>), dim3(gx, P.B), dim3(128), 0, st, a);
-                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H_TALL, true>), dim3(4, P.B), dim3(128), 0, st, a);
+                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H_TALL, true>), dim3(gx, P.B), dim3(128), rlds, st, a);
+                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H_TALL, true>), dim3(4, P.B), dim3(128), rlds, st, a);
             } else {
-                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H, true>), dim3(gx, P.B), dim3(128), 0, st, a);
-                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H, true>), dim3(4, P.B), dim3(128), 0, st, a);
+                hipLaunchKernelGGL((ym::raster_kernel<128, false, YM_TILE_H, true>), dim3(gx, P.B), dim3(128), rlds, st, a);
+                if (gx < P.ltx * P.lty) hipLaunchKernelGGL((ym::raster_kernel<128, true, YM_TILE_H, true>), dim3(4, P.B), dim3(128), rlds, st, a);
             }
         } else {
-            if (P.tile_h == YM_TILE_H_TALL) hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H_TALL, false>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H, false>), dim3(P.ltx * P.lty, P.B), dim3(256), 0, st, a);
+            if (P.tile_h == YM_TILE_H_TALL) hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H_TALL, false>), dim3(P.ltx * P.lty, P.B), dim3(256), rlds, st, a);
+            else hipLaunchKernelGGL((ym::raster_kernel<256, false, YM_TILE_H, false>), dim3(P.ltx * P.lty, P.B), dim3(256), rlds, st, a);
         }
     }
     return prof_end(m, ev_k);
@@ -2255,7 +2282,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release();
+    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release();
     m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
@@ -3241,6 +3268,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 34) m->corr_region_rsplit = value;
     else if (option == 35) m->item_min_batch = value;
     else if (option == 36) m->raster_planes_only = value;
+    else if (option == 37) m->raster_no_rowtab = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;

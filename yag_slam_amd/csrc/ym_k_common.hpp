@@ -187,6 +187,9 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 #define YM_TILE_W 64
 #define YM_TILE_H 32      // raster tile: 64 x 32 cells -- or 64 x 64 (YM_TILE_H_TALL) on large batches with large windows, chosen per call
 #define YM_TILE_H_TALL 64
+#define YM_RASTER_RW ((YM_TILE_W + 2 * YM_MAX_KERNEL_HALF + 63) / 64 + 1) // 64-bit words per row of the raster's occupancy bitmap
+// dynamic LDS of raster_kernel: bitmap + row distances of the tile and its halo, the row pass's tables, the smear values
+#define YM_RASTER_LDS_BYTES(th, h, ntab) ((size_t)((th) + 2 * (h)) * (YM_RASTER_RW * 8 + YM_TILE_W) + (size_t)(ntab) * 1024 + (size_t)((2 * (h) * (h) + 2 + 15) / 16 * 16))
 #define YM_TILE_HITS 64    // hit slots per entry of the raster's work list: the chunks that reach the entry's tile (four times what the bench scans need of a tall tile)
 
 }  // namespace ym

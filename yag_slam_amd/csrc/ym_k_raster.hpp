@@ -29,7 +29,11 @@ struct RasterArgs {
     int32_t lty, pad0;
     const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
     int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
-    int32_t planes_only, pad;  // timing experiment: 1 = the row-major window is not written
+    int32_t planes_only, n_rowtab; // planes_only: timing experiment, 1 = the row-major window is not written
+    // the row pass's tables (host, upload_lut; n_rowtab = ceil((8 + 2h) / 7) of them, 0 = none: h > 12): table j, indexed by the
+    // seven bitmap bits 7j .. 7j + 6 of the 8 + 2h an 8-cell group sees, holds for each of the eight cells its distance to the
+    // nearest of those bits that is set and within reach (127: none)
+    const uint2 *rowtab;
     unsigned long long *stamps;
 };
 
@@ -54,16 +58,28 @@ template <int NT, bool OVERFLOW, int TH, bool LISTED>
 __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     constexpr int TW = YM_TILE_W, HM = YM_MAX_KERNEL_HALF;
     constexpr int MAXHITS = LISTED ? 1 : 256 * TH / 32; // chunk boxes an unlisted block lists for its tile before it walks all boxes
-    constexpr int RW = (TW + 2 * HM + 63) / 64 + 1;  // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
+    constexpr int RW = YM_RASTER_RW;                   // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
     constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
-    __shared__ unsigned long long occ[(TH + 2 * HM) * RW];
-    __shared__ __attribute__((aligned(8))) unsigned char grow[(TH + 2 * HM) * TW];
-    __shared__ unsigned char lut[2 * HM * HM + 8];
+    static_assert(RW == (TW + 2 * HM + 63) / 64 + 1, "YM_RASTER_RW");
+    // dynamic LDS (YM_RASTER_LDS_BYTES: sized by the kernel half in use, not by the largest one -- 10 KB on the usual kernels,
+    // sixteen blocks per CU): occ | grow | row tables | lut
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_dyn[];
+    const int OHh = TH + 2 * a.g.half_kernel;
+    unsigned long long *occ = reinterpret_cast<unsigned long long *>(rs_dyn);                    // [OH * RW]
+    unsigned char *grow = rs_dyn + (size_t)OHh * RW * 8;                                          // [OH * TW]
+    uint2 *rtab = reinterpret_cast<uint2 *>(grow + (size_t)OHh * TW);                             // [n_rowtab * 128]
+    unsigned char *lut = reinterpret_cast<unsigned char *>(rtab + (size_t)a.n_rowtab * 128);      // [2 h h + 2]
     __shared__ unsigned colany[TW / 8][4]; // per 8-cell column group: bit ry = the row pass found a wall within reach in halo row ry
     __shared__ int s_hits[MAXHITS], s_left[MAXHITS];
     __shared__ int s_nhits;
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
+    // the row tables leave first (3 KB per block, from L2); they are put into LDS when the block's bitmap is cleared
+    constexpr int TPT = (5 * 128 + NT - 1) / NT; // table entries per thread (at most five tables)
+    uint2 tq[TPT];
+#pragma unroll
+    for (int u = 0; u < TPT; u++) tq[u] = (tid + u * NT) < a.n_rowtab * 128 ? a.rowtab[tid + u * NT] : make_uint2(0u, 0u);
+    bool tables_stored = false;
     // grid (x, B).  With a work list (batches) block i takes entry i of its item's list; without one (a few items: one
     // more launch would cost more than it saves) block i is tile i of the sub-grid and finds out by itself whether any
     // chunk box reaches it.
@@ -158,6 +174,12 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     }
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
     if (tid < (TW / 8) * 4) (&colany[0][0])[tid] = 0u;
+    if (!tables_stored) { // (once per block: the OVERFLOW blocks go through here once per tile)
+#pragma unroll
+        for (int u = 0; u < TPT; u++)
+            if ((tid + u * NT) < a.n_rowtab * 128) rtab[tid + u * NT] = tq[u];
+        tables_stored = true;
+    }
     for (int i = tid; i <= 2 * h * h + 1; i += NT) lut[i] = i <= 2 * h * h ? a.lut[i] : (unsigned char)0;
     __syncthreads();
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
@@ -252,8 +274,36 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     // row pass: nearest occupied |dx| <= h, 255 = none.  Bit x+h of a bitmap row is tile column x.
     // Work item = 8 consecutive cells of one (halo) row.  Walls are thin: most 8-cell groups see no bit within
     // reach at all and leave after one test.
-    if (2 * h + 8 <= 32) {
-        // the usual kernels (h <= 12): the 8 cells of a group see 2h + 8 <= 32 bits of the bitmap row, 32-bit bit scans
+    if (a.n_rowtab) {
+        // the usual kernels (h <= 12), round 4: the 8 + 2h bits a group sees, seven at a time, index tables that hold the eight
+        // cells' distances to the nearest set bit among those seven (127: none in reach); the group's distances are the
+        // byte-wise minimum of the n_rowtab entries -- ~36 vector instructions per group instead of ~110 for eight bit scans
+        // to the left and to the right.  Byte-wise minimum of values < 128: the borrow-free difference (a | 0x80) - b keeps
+        // bit 7 of a byte exactly where a >= b.
+        const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
+        auto bmin = [](uint32_t x, uint32_t y) {
+            const uint32_t ge = (((x | 0x80808080u) - y) >> 7) & 0x01010101u; // 1 in the bytes where x >= y
+            const uint32_t m = (ge << 8) - ge;                                  // 0xff there
+            return (y & m) | (x & ~m);
+        };
+        const int ntab = a.n_rowtab;
+        for (int i = tid; i < OH * LPR; i += NT) {
+            const int ry = i / LPR, rx = (i % LPR) * 8;
+            const int w = rx >> 6, sft = rx & 63;
+            const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
+            const unsigned sw = (unsigned)((sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask); // bits rx .. rx + 7 + 2h
+            if (sw) { // (a group without a wall in reach writes nothing: the column pass only reads flagged rows)
+                uint2 g = rtab[sw & 127u];
+                for (int j = 1; j < ntab; j++) {
+                    const uint2 t = rtab[j * 128 + ((sw >> (7 * j)) & 127u)];
+                    g.x = bmin(g.x, t.x); g.y = bmin(g.y, t.y);
+                }
+                *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = g;
+                atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
+            }
+        }
+    } else if (2 * h + 8 <= 32) {
+        // (kept for a matcher without tables) the 8 cells of a group see 2h + 8 <= 32 bits of the bitmap row, 32-bit bit scans
         const unsigned wmask = (1u << (2 * h + 1)) - 1u, lmask = (1u << h) - 1u;
         const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
         for (int i = tid; i < OH * LPR; i += NT) {
@@ -331,7 +381,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
             for (int q = 0; q < 4; q++) {
                 us2 gq;
                 __builtin_memcpy(&gq, &u[q], 4);
-                mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 (none) is larger than any real distance
+                mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 or 127 (none) is larger than any real distance
             }
         };
         if (2 * h + 1 <= 32) { // (block-uniform; the usual kernels: the tap mask is a 32-bit word, its scan half the instructions)
