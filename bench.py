@@ -488,6 +488,10 @@ def main():
         m.debug_option(14, args.corr_region)
     if args.corr_region_na:
         m.debug_option(15, args.corr_region_na)
+    # development: YM_BENCH_OPTS="option:value,..." is applied to every matcher of the metric leg (A/B runs of a debug option)
+    dev_opts = [tuple(int(x) for x in kv.split(":")) for kv in os.environ.get("YM_BENCH_OPTS", "").split(",") if kv]
+    for o_, v_ in dev_opts:
+        m.debug_option(o_, v_)
 
     def barrier():
         torch.cuda.synchronize()
@@ -516,6 +520,9 @@ def main():
         # lanes: independent matchers (own stream + workspace); enqueue e of a step goes to lane e % lanes, so the
         # small tail kernels of one enqueue overlap the next one's big ones
         lanes = [m] + [ScanMatcher(None, device=local_rank) for _ in range(max(1, args.lanes) - 1)]
+        for lm in lanes[1:]:
+            for o_, v_ in dev_opts:
+                lm.debug_option(o_, v_)
         lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in lanes[1:]]
         for lm, ls in zip(lanes[1:], lane_streams[1:]):
             lm.set_stream(ls.cuda_stream)

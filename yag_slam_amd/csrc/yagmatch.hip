@@ -551,6 +551,7 @@ struct ym_matcher {
     int raster_planes_only = 0; // timing experiment (option 36): the raster does not write the row-major window
     int raster_no_rowtab = 0;   // tests (option 37): the raster's row pass by bit scans instead of its tables
     int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
+    int corr_region_pad_lds = 0; // development (option 38): dynamic LDS bytes the region correlate is launched with and does not use (fewer blocks per CU)
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
@@ -1728,7 +1729,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         case 10: hipLaunchKernelGGL(ym::correlate_region_kernel<10>, rgrid, dim3(640), 0, st, r); break;
         case 11: hipLaunchKernelGGL(ym::correlate_region_kernel<11>, rgrid, dim3(704), 0, st, r); break;
         case 16: hipLaunchKernelGGL(ym::correlate_region_kernel<16>, rgrid, dim3(1024), 0, st, r); break;
-        default: hipLaunchKernelGGL(ym::correlate_region_kernel<8>, rgrid, dim3(512), 0, st, r); break;
+        default: hipLaunchKernelGGL(ym::correlate_region_kernel<8>, rgrid, dim3(512), (size_t)m->corr_region_pad_lds, st, r); break;
         }
         return prof_end(m, ev_k);
     }
@@ -3269,6 +3270,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 35) m->item_min_batch = value;
     else if (option == 36) m->raster_planes_only = value;
     else if (option == 37) m->raster_no_rowtab = value;
+    else if (option == 38) m->corr_region_pad_lds = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;
