@@ -143,6 +143,40 @@ DEFINE_K32(mix_indep, MIX6 MIX6 MIX6 MIX6 MIX6 MIX6 MIX6 MIX6, 48)
     "v_add3_u32 %0, %0, %4, %8\n\tv_add3_u32 %1, %1, %5, %8\n\tv_add3_u32 %2, %2, %6, %8\n\tv_add3_u32 %3, %3, %7, %8\n\t" \
     "v_add3_u32 %4, %0, %4, %9\n\tv_add3_u32 %5, %1, %5, %9\n\tv_add3_u32 %6, %2, %6, %9\n\t"
 DEFINE_K32(rg_body, BODY_RG BODY_RG, 2 * 50)
+// the same loop after the funnel and the widening became one v_perm_b32 per pair of hypotheses (ym_k_region.hpp rg_perm_pair), as
+// hipcc emits it (llvm-objdump of libyagmatch.so), loads removed: per four patches 4 add (addresses: entry in an SGPR + lane
+// offset), 4 and (-4), 2 and (3), 8 add (raw pair sums), 4 mad_u32_u24 (the two selectors of each pair), 14 perm, 7 add3,
+// 2 readfirstlane (the next quad's entries) + 1 mov = 46
+#define BODY_RGP                                                                                                           \
+    "v_add_u32 %0, %8, %0\n\tv_add_u32 %1, %8, %1\n\tv_add_u32 %2, %9, %2\n\tv_add_u32 %3, %9, %3\n\t"                 \
+    "v_and_b32 %4, -4, %0\n\tv_and_b32 %5, -4, %1\n\tv_and_b32 %6, -4, %2\n\tv_and_b32 %7, -4, %3\n\t"                 \
+    "v_and_b32 %0, 3, %0\n\tv_and_b32 %2, 3, %2\n\t"                                                                    \
+    "v_add_u32 %1, %4, %5\n\tv_add_u32 %3, %5, %6\n\tv_add_u32 %4, %6, %7\n\tv_add_u32 %5, %7, %8\n\t"                 \
+    "v_add_u32 %6, %8, %9\n\tv_add_u32 %7, %9, %10\n\tv_add_u32 %1, %1, %10\n\tv_add_u32 %3, %3, %10\n\t"              \
+    "v_mad_u32_u24 %0, %0, %8, %9\n\tv_mad_u32_u24 %2, %2, %8, %9\n\tv_mad_u32_u24 %4, %4, %8, %10\n\tv_mad_u32_u24 %6, %6, %8, %10\n\t" \
+    "v_perm_b32 %1, %3, %1, %0\n\tv_perm_b32 %3, %5, %3, %0\n\tv_perm_b32 %5, %7, %5, %0\n\tv_perm_b32 %7, %8, %7, %0\n\t" \
+    "v_perm_b32 %1, %3, %1, %2\n\tv_perm_b32 %3, %5, %3, %2\n\tv_perm_b32 %5, %7, %5, %2\n\t"                           \
+    "v_perm_b32 %1, %3, %1, %4\n\tv_perm_b32 %3, %5, %3, %4\n\tv_perm_b32 %5, %7, %5, %4\n\tv_perm_b32 %7, %9, %7, %4\n\t" \
+    "v_perm_b32 %1, %3, %1, %6\n\tv_perm_b32 %3, %5, %3, %6\n\tv_perm_b32 %5, %7, %5, %6\n\t"                           \
+    "v_add3_u32 %0, %0, %1, %8\n\tv_add3_u32 %2, %2, %3, %8\n\tv_add3_u32 %4, %4, %5, %8\n\tv_add3_u32 %6, %6, %7, %8\n\t" \
+    "v_add3_u32 %1, %1, %0, %9\n\tv_add3_u32 %3, %3, %2, %9\n\tv_add3_u32 %5, %5, %4, %9\n\t"                           \
+    "v_readfirstlane_b32 s20, %7\n\tv_readfirstlane_b32 s21, %6\n\tv_mov_b32 %7, s20\n\t"
+#define DEFINE_K32_SGPR(NAME, BODY, N)                                                                                      \
+    __global__ __launch_bounds__(1024) void k_##NAME(uint32_t *out, int iters, unsigned long long *ticks) {                \
+        uint32_t r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+        const uint32_t a = blockIdx.x + 3, b = 0x00ff00ffu, c = threadIdx.x & 3;                                           \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();                 \
+        for (int i = 0; i < iters; i++)                                                                                    \
+            asm volatile(BODY : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)             \
+                         : "v"(a), "v"(b), "v"(c) : "s20", "s21");                                                         \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();                 \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;                                \
+        if ((threadIdx.x & 63) == 0) {                                                                                     \
+            const size_t w = (size_t)(blockIdx.x * blockDim.x + threadIdx.x) / 64;                                         \
+            ticks[2 * w] = t1 - t0; ticks[2 * w + 1] = w1 - w0;                                                            \
+        }                                                                                                                  \
+    }
+DEFINE_K32_SGPR(rgp_body, BODY_RGP BODY_RGP, 2 * 46)
 
 typedef void (*kern_t)(uint32_t *, int, unsigned long long *);
 struct Entry { const char *name; kern_t k; int per_iter; };
@@ -197,6 +231,7 @@ int main(int argc, char **argv) {
         {"v_lshlrev_b64", k_lshl64, 64}, {"v_msad_u8", k_msad, 64},
         {"region mix, independent registers (6 ops)", k_mix_indep, 48},
         {"rg_gather4 body without loads (50 ops)", k_rg_body, 100},
+        {"rg_gather4 body, v_perm form (46 ops)", k_rgp_body, 92},
     };
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
