@@ -1163,6 +1163,13 @@ def test_region_correlate_lattice_widths(nx):
         vols.append([m.debug_sums(0, item=i, dims=dims) for i in range(len(chains))])
     for a, b in zip(*vols):
         assert np.array_equal(a, b)
+    # ... and the first two chains' volumes against the oracle itself (not only through the direct kernel)
+    from oracle import oracle as orc
+    for i in (0, 1):
+        o = orc.Oracle(cfg, "karto")
+        ro = o.match_scan(q, [base[j] for j in ([range(10), range(4)][i])], True, True)
+        if ro["expansions"] == 0 and per[i].meta["expansions"] == 0:
+            assert np.array_equal(vols[1][i], o.sums(0)), "gather correlate differs from the oracle at width %d, chain %d" % (nx, i)
     m = ScanMatcher(cfg)
     per, best = m.match_scan_batch(nq, chains, True, True)
     singles = [m.match_scan(nq, ch, True, True) for ch in chains]
