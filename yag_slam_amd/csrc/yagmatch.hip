@@ -506,7 +506,7 @@ struct ym_matcher {
     int z2max = 0;               // largest squared cell distance whose kernel value is 100
     DevBuf<uint8_t> ktab;
     DevBuf<uint8_t> rowtab;   // the raster's row-pass tables (upload_lut)
-    int n_rowtab = 0;
+    int n_rowtab = 0, rowtab_shift = -1;
     // workspace
     DevBuf<unsigned char> desc_dev; // batch call descriptors (single calls travel in the kernel arguments)
     DevBuf<YmItemState> states;
@@ -751,8 +751,13 @@ int upload_lut(ym_matcher *m) {
     // sits at bit q + h.  Table j, indexed by the seven bits 7j .. 7j + 6, holds for every cell the distance to the nearest
     // of THOSE bits that is set and at most h away (127: none); the group's distances are the byte-wise minimum over j.
     m->n_rowtab = 0;
+    m->rowtab_shift = -1;
     if (2 * h + 8 <= 32) {
-        const int nt = (2 * h + 8 + 6) / 7;
+        // h <= 10: the mirrored form -- the window shifted into the middle of 28 bits, two tables stored (groups 0 and 1; groups 3
+        // and 2 are their mirror images).  h = 11, 12: one table per group of seven bits.
+        const bool mirror = h <= 10;
+        const int shift = mirror ? (28 - (2 * h + 8)) / 2 : 0;
+        const int nt = mirror ? 2 : (2 * h + 8 + 6) / 7;
         std::vector<uint8_t> t((size_t)nt * 128 * 8);
         for (int j = 0; j < nt; j++)
             for (int v = 0; v < 128; v++)
@@ -760,11 +765,12 @@ int upload_lut(ym_matcher *m) {
                     int best = 127;
                     for (int i = 0; i < 7; i++)
                         if ((v >> i) & 1) {
-                            const int d = std::abs(7 * j + i - (c + h));
+                            const int d = std::abs(7 * j + i - (c + h + shift));
                             if (d <= h && d < best) best = d;
                         }
                     t[((size_t)j * 128 + v) * 8 + c] = (uint8_t)best;
                 }
+        if (mirror) m->rowtab_shift = shift;
         if ((rc = m->rowtab.ensure(t.size()))) return rc;
         HIP_TRY(hipMemcpy(m->rowtab.p, t.data(), t.size(), hipMemcpyHostToDevice));
         m->n_rowtab = nt;
@@ -1581,7 +1587,7 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
     a.tile_zero = m->tile_zero.p; a.planes_only = m->raster_planes_only;
-    a.n_rowtab = m->raster_no_rowtab ? 0 : m->n_rowtab; a.rowtab = reinterpret_cast<const uint2 *>(m->rowtab.p);
+    a.n_rowtab = m->raster_no_rowtab ? 0 : m->n_rowtab; a.rowtab = reinterpret_cast<const uint2 *>(m->rowtab.p); a.rowtab_shift = m->rowtab_shift; a.pad1 = 0;
     const size_t rlds = YM_RASTER_LDS_BYTES(P.tile_h, g.half_kernel, a.n_rowtab);
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
     a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.lty = P.lty; a.pad0 = 0;

@@ -29,7 +29,11 @@ struct RasterArgs {
     int32_t lty, pad0;
     const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
     int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
-    int32_t planes_only, n_rowtab; // planes_only: timing experiment, 1 = the row-major window is not written
+    int32_t planes_only, n_rowtab; // planes_only: timing experiment, 1 = the row-major window is not written; n_rowtab: tables STORED
+    int32_t rowtab_shift, pad1;    // >= 0: the mirrored form (h <= 10) -- the 8 + 2h bits, shifted left by this much, sit in the middle
+                                   // of 28 = four groups of seven; tables 0 and 1 serve groups 0 and 1 directly and groups 3 and 2
+                                   // through the mirror image (index bit-reversed, the eight distances in reverse order): 2 KB of LDS
+                                   // instead of 4.  -1: table j serves bits 7j .. 7j + 6
     // the row pass's tables (host, upload_lut; n_rowtab = ceil((8 + 2h) / 7) of them, 0 = none: h > 12): table j, indexed by the
     // seven bitmap bits 7j .. 7j + 6 of the 8 + 2h an 8-cell group sees, holds for each of the eight cells its distance to the
     // nearest of those bits that is set and within reach (127: none)
@@ -286,17 +290,28 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
             const uint32_t m = (ge << 8) - ge;                                  // 0xff there
             return (y & m) | (x & ~m);
         };
-        const int ntab = a.n_rowtab;
+        const int ntab = a.n_rowtab, mshift = a.rowtab_shift;
         for (int i = tid; i < OH * LPR; i += NT) {
             const int ry = i / LPR, rx = (i % LPR) * 8;
             const int w = rx >> 6, sft = rx & 63;
             const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
             const unsigned sw = (unsigned)((sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask); // bits rx .. rx + 7 + 2h
             if (sw) { // (a group without a wall in reach writes nothing: the column pass only reads flagged rows)
-                uint2 g = rtab[sw & 127u];
-                for (int j = 1; j < ntab; j++) {
-                    const uint2 t = rtab[j * 128 + ((sw >> (7 * j)) & 127u)];
-                    g.x = bmin(g.x, t.x); g.y = bmin(g.y, t.y);
+                uint2 g;
+                if (mshift >= 0) { // (block-uniform)
+                    const unsigned s4 = sw << mshift;                       // 28 bits: groups 0 .. 3
+                    const unsigned r4 = __builtin_bitreverse32(s4) >> 4;    // the same 28 bits mirrored: group 3 first
+                    const uint2 t0 = rtab[s4 & 127u], t1 = rtab[128 + ((s4 >> 7) & 127u)];
+                    const uint2 m0 = rtab[r4 & 127u], m1 = rtab[128 + ((r4 >> 7) & 127u)]; // groups 3 and 2, cells in reverse order
+                    const uint2 d = make_uint2(bmin(t0.x, t1.x), bmin(t0.y, t1.y)), m = make_uint2(bmin(m0.x, m1.x), bmin(m0.y, m1.y));
+                    g.x = bmin(d.x, __builtin_amdgcn_perm(0u, m.y, 0x00010203u));
+                    g.y = bmin(d.y, __builtin_amdgcn_perm(0u, m.x, 0x00010203u));
+                } else {
+                    g = rtab[sw & 127u];
+                    for (int j = 1; j < ntab; j++) {
+                        const uint2 t = rtab[j * 128 + ((sw >> (7 * j)) & 127u)];
+                        g.x = bmin(g.x, t.x); g.y = bmin(g.y, t.y);
+                    }
                 }
                 *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = g;
                 atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
