@@ -1100,6 +1100,45 @@ def test_raster_grid_shorter_than_the_tile_list():
             assert np.array_equal(g, r)
 
 
+@pytest.mark.parametrize("gx", [0, 100000])
+def test_raster_sub_block_knowledge_is_invisible(gx):
+    """The raster keeps, per 8 x 8 sub-block of a window tile, whether the window memory holds zeros there, and does not store
+    a sub-block again that is zero now and was zero before.  One matcher sees the same chains at a sequence of poses (walls
+    move across sub-blocks and tiles, come back, disappear): after every call its windows -- single match and batch of 50,
+    work lists and hit slots -- are byte for byte those of a matcher that has never seen anything else.  (gx = 100000: one
+    block per listed tile in ONE launch, the most blocks in flight -- how a race between a block's waves on the tile's flag
+    first showed.)"""
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    scene = synth.Scene()
+    base_poses, q_truth, q_prior = synth.single_match_poses()
+    ranges = [scene.scan_ranges(p, index=i) for i, p in enumerate(base_poses)]
+    q_ranges = scene.scan_ranges(q_truth, index=10)
+    shifts = [(0.0, 0.0, 0.0), (0.13, -0.07, 0.02), (0.0, 0.0, 0.0), (-0.31, 0.22, -0.05), (0.02, 0.01, 0.0), (1.7, -0.9, 0.3), (0.0, 0.0, 0.0)]
+    m = ScanMatcher({"use_response_expansion": False})
+    m.debug_option(16, gx)
+    for k, (dx, dy, dt) in enumerate(shifts):
+        # (the chain moves, the query stays: the window is anchored at the query)
+        base = [synth.resident_scan(r, (p[0] + dx, p[1] + dy, p[2] + dt)) for r, p in zip(ranges, base_poses)]
+        query = synth.resident_scan(q_ranges, q_prior)
+        chains = [base[:max(1, len(base) - (c % 4))] for c in range(50)]
+        fresh = ScanMatcher({"use_response_expansion": False})
+        for mm in (m, fresh):
+            mm.match_scan(query, base, True, True)
+        g, _ = m.debug_grid()
+        gf, _ = fresh.debug_grid()
+        assert np.array_equal(g, gf), "call %d, single match: %d cells differ" % (k, int((g != gf).sum()))
+        pm, _ = m.match_scan_batch(query, chains, True, True)
+        pf, _ = fresh.match_scan_batch(query, chains, True, True)
+        for i in range(50):
+            g, _ = m.debug_grid(item=i)
+            gf, _ = fresh.debug_grid(item=i)
+            assert np.array_equal(g, gf), "call %d, item %d: %d cells differ" % (k, i, int((g != gf).sum()))
+        assert [r.response for r in pm] == [r.response for r in pf]
+        fresh.close()
+    m.close()
+
+
 @pytest.mark.parametrize("sigma_cells", [1.0, 3.0, 6.0, 7.0])
 def test_raster_row_tables_are_invisible(sigma_cells):
     """The raster's row pass finds an 8-cell group's distances to the nearest occupied cell of its row in tables indexed by

@@ -518,6 +518,7 @@ struct ym_matcher {
     DevBuf<uint8_t> grid;
     DevBuf<uint8_t> planes;    // even/odd column planes of every window
     DevBuf<uint8_t> tile_zero; // per raster tile: window memory known to be zero (skips rewriting empty tiles)
+    DevBuf<uint8_t> sub_zero;  // per raster tile that is not: which of its 8 x 8 sub-blocks are (8 bytes per tile)
     size_t tz_sig[6] = {0, 0, 0, 0, 0, 0}; // memory/geometry the flags are valid for
     // per workspace item: tile rectangle (x0, y0, x1, y1) outside which the item's window memory is known to be zero.
     // Items [0, tz_covered) have valid flags and rectangles; a call only rasterises (and cleans) items [0, B), so the
@@ -1402,14 +1403,16 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     // the tiling stay the same, otherwise they are cleared
     const size_t per_item = (size_t)tiles_x * tiles_y, ntiles = (size_t)B * per_item;
     const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, (size_t)P.tile_h};
-    const bool tz_grow = ntiles > m->tile_zero.cap;
+    const bool tz_grow = ntiles > m->tile_zero.cap || ntiles * 8 > m->sub_zero.cap; // (the two grow at different sizes)
     if ((rc = m->tile_zero.ensure(ntiles))) return rc;
+    if ((rc = m->sub_zero.ensure(ntiles * 8))) return rc;
     if (tz_grow || std::memcmp(sig, m->tz_sig, sizeof sig) != 0) {
         std::memcpy(m->tz_sig, sig, sizeof sig);
         m->tz_covered = 0;
     }
     if (B > m->tz_covered) { // items this geometry has not seen yet: unknown memory, every tile is launched once
         HIP_TRY(hipMemsetAsync(m->tile_zero.p + (size_t)m->tz_covered * per_item, 0, (size_t)(B - m->tz_covered) * per_item, m->stream));
+        HIP_TRY(hipMemsetAsync(m->sub_zero.p + (size_t)m->tz_covered * per_item * 8, 0, (size_t)(B - m->tz_covered) * per_item * 8, m->stream));
         m->item_dirty.resize(B);
         for (int i = m->tz_covered; i < B; i++) m->item_dirty[i] = {0, 0, tiles_x - 1, tiles_y - 1};
         m->tz_covered = B;
@@ -1586,7 +1589,7 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.tile_list = P.use_tile_list ? m->tile_list.p : nullptr; a.tile_count = m->tile_count.p; a.tile_cap = P.tile_cap;
     a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
-    a.tile_zero = m->tile_zero.p; a.planes_only = m->raster_planes_only;
+    a.tile_zero = m->tile_zero.p; a.sub_zero = m->sub_zero.p; a.planes_only = m->raster_planes_only;
     a.n_rowtab = m->raster_no_rowtab ? 0 : m->n_rowtab; a.rowtab = reinterpret_cast<const uint2 *>(m->rowtab.p); a.rowtab_shift = m->rowtab_shift; a.pad1 = 0;
     const size_t rlds = YM_RASTER_LDS_BYTES(P.tile_h, g.half_kernel, a.n_rowtab);
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
@@ -2289,7 +2292,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release();
+    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->sub_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release();
     m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();

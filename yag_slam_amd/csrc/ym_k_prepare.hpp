@@ -588,7 +588,6 @@ struct TilesArgs {
     int32_t max_n, max_base, half_kernel;
     int32_t tiles_x, tiles_y, tile_cap;
     int32_t launch[4];       // tile rectangle (x0, y0, x1, y1) the raster covers in this call
-    // per tile of that rectangle the chunk boxes that reach it, so that a raster block does not scan every box of the item:
     // per LIST ENTRY the chunks that reach its tile, so that a raster block neither scans every box of the item nor looks
     // anything up before it can load them (their address depends on the entry's position alone):
     uint16_t *hits;          // [B][tile_cap][YM_TILE_HITS] index of the chunk's first cell in the item's cells; null = no lists (the raster walks the boxes)

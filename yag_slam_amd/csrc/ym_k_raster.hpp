@@ -16,6 +16,8 @@ struct RasterArgs {
     const uint8_t *lut;   // smear kernel value by squared cell distance: lut[dx*dx + dy*dy], 2*h*h + 1 entries
     int32_t max_n, max_base;
     uint8_t *tile_zero;   // [B][tiles_y][tiles_x]: 1 = this tile of the window memory is known to hold zeros
+    uint8_t *sub_zero;    // [B][tiles_y][tiles_x][8]: of a tile that is NOT known to be zero, byte b bit g = the 8 x 8 cells of rows
+                          // 8b .. 8b + 7, columns 8g .. 8g + 7 are known to hold zeros (written by the block that last rastered the tile)
     int32_t tiles_x, tiles_y; // full tiling of the window
     int32_t tile_x0, tile_y0; // first tile of the launched sub-grid (tiles outside it are known to be zero)
     int32_t ltx;              // tile columns of the launched sub-grid
@@ -111,18 +113,42 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     auto store8 = [&](int y, uint32_t p0, uint32_t p1) {
         if (ty0 + y < a.g.win_w) {
             const uint32_t row = (uint32_t)(ty0 + y), col = (uint32_t)(tx0 + x8);
-            if (!a.planes_only) *reinterpret_cast<uint2 *>(grid + (row * (uint32_t)a.g.pitch + col)) = make_uint2(p0, p1);
-            uint8_t *pl = planes + (row * (uint32_t)(a.g.pitch / 2) + col / 2u);
+            // (24-bit multiplies: a 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+            if (!a.planes_only) *reinterpret_cast<uint2 *>(grid + (__umul24(row, (uint32_t)a.g.pitch) + col)) = make_uint2(p0, p1);
+            uint8_t *pl = planes + (__umul24(row, (uint32_t)(a.g.pitch / 2)) + col / 2u);
             *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
             *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
         }
     };
-    auto zero_tile = [&]() {
-        for (int y = y0; y < TH; y += NT / LPR) store8(y, 0u, 0u);
-    };
+    // What is known of the tile's memory (round 4): a tile is either known to be zero, or every 8 x 8 sub-block of it says so
+    // for itself.  A sub-block that is zero now and was zero before is not stored again: walls are thin, so that is half of a
+    // wall tile's bytes -- and the raster's time on a box whose memory takes writes slowly is its stores.
+    static_assert(LPR == 8 && (NT / LPR) % 8 == 0, "a wave stores whole bands of eight rows");
     uint8_t *tz = a.tile_zero + ((size_t)bi * a.tiles_y + tiy) * a.tiles_x + tix;
+    uint8_t *sz = a.sub_zero + (((size_t)bi * a.tiles_y + tiy) * a.tiles_x + tix) * 8;
+    const unsigned tz_old = *tz;
+    const uint2 sz_old = *reinterpret_cast<const uint2 *>(sz);
+    auto old_zero = [&](int y) { // bit g: the band of row y, column group g, is known to hold zeros
+        const unsigned w = (y & 32) ? sz_old.y : sz_old.x;
+        return tz_old ? 0xffu : (w >> (y & 24)) & 0xffu;
+    };
+    // the rows y (one band per wave: lane / 8 = row of the band, lane % 8 = column group) with `flags`: the band's new knowledge
+    auto store_band = [&](int y, uint32_t p0, uint32_t p1, bool flags) {
+        const unsigned long long nz = __ballot((p0 | p1) != 0u);
+        unsigned long long f = nz | (nz >> 32);
+        f |= f >> 16;
+        f |= f >> 8;
+        const unsigned nzb = (unsigned)f & 0xffu, oldb = old_zero(y), g = (unsigned)tid & 7u;
+        if (((nzb >> g) & 1u) || !((oldb >> g) & 1u)) store8(y, p0, p1);
+        if (flags && (tid & 63) == 0) sz[y >> 3] = (uint8_t)(~nzb);
+    };
+    auto zero_tile = [&]() {
+        for (int y = y0; y < TH; y += NT / LPR) store_band(y, 0u, 0u, false);
+    };
     if (entry & 0x8000u) { // no chunk reaches this tile, but its memory still holds an earlier call's bytes
         zero_tile();
+        __syncthreads(); // (every wave has read what was known of the tile before thread 0 says "all zero": a wave that read the
+                         //  new flag instead would skip its rows -- seen with many blocks in flight)
         if (tid == 0) *tz = 1;
         return;
     }
@@ -141,7 +167,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         }
         if (__syncthreads_or(my_hits) == 0) {
             // empty tile: zeros -- unless this memory is already known to be zero from an earlier call
-            if (*tz == 0) {
+            if (tz_old == 0) {
                 zero_tile();
                 __syncthreads();
                 if (tid == 0) *tz = 1;
@@ -188,10 +214,13 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     __syncthreads();
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
     int any = 0;
+    static_assert(RW == 3, "row_words");
+    // (ly * RW * 2 + word as ONE 24-bit multiply-add: hipcc folds "* 6" and the byte scaling into a quarter-rate v_mul_lo_u32 by 24)
+    auto row_words = [](int ly, int word) { int r; asm("v_mad_u32_u24 %0, %1, 6, %2" : "=v"(r) : "v"(ly), "v"(word)); return r; };
     auto stamp = [&](const int2 c2) {
         const int lx = c2.x - lo_x, ly = c2.y - lo_y;
         if (c2.x != YM_CELL_NONE && lx >= 0 && lx < OW && ly >= 0 && ly < OH) {
-            atomicOr(&occ32[ly * (RW * 2) + (lx >> 5)], 1u << (lx & 31));
+            atomicOr(&occ32[row_words(ly, lx >> 5)], 1u << (lx & 31));
             any = 1;
         }
     };
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         atomicAdd(a.stamps + 29, (unsigned long long)nhits);
     }
     if (!any) {
-        if (*tz == 0) {
+        if (tz_old == 0) {
             zero_tile();
             __syncthreads();
             if (tid == 0) *tz = 1;
@@ -285,10 +314,16 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         // to the left and to the right.  Byte-wise minimum of values < 128: the borrow-free difference (a | 0x80) - b keeps
         // bit 7 of a byte exactly where a >= b.
         const unsigned long long gmask = (1ull << (2 * h + 8)) - 1ull;
-        auto bmin = [](uint32_t x, uint32_t y) {
-            const uint32_t ge = (((x | 0x80808080u) - y) >> 7) & 0x01010101u; // 1 in the bytes where x >= y
-            const uint32_t m = (ge << 8) - ge;                                  // 0xff there
-            return (y & m) | (x & ~m);
+        // byte-wise minimum of two entries (x |= min): v_min_u32 with byte selects (SDWA), each replacing one byte of its result;
+        // the two dwords of an entry alternate, because an SDWA write that preserves the rest of its register must not follow
+        // the instruction that wrote that register (one wait state; scripts/exp/sdwa_min.hip: a single chain of four is wrong in
+        // byte 1).  (The portable form -- the borrow-free difference (x | 0x80) - y keeps bit 7 of a byte where x >= y, spread to a
+        // mask, select -- came out of hipcc as nine instructions per dword with a quarter-rate v_mul_lo_u32 by 255 among them.)
+        auto bmin2 = [](uint2 &x, const uint2 y) {
+#define YM_BM(k) "v_min_u32_sdwa %0, %0, %2 dst_sel:BYTE_" #k " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #k " src1_sel:BYTE_" #k "\n\t" \
+                 "v_min_u32_sdwa %1, %1, %3 dst_sel:BYTE_" #k " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #k " src1_sel:BYTE_" #k "\n\t"
+            asm(YM_BM(0) YM_BM(1) YM_BM(2) YM_BM(3) : "+v"(x.x), "+v"(x.y) : "v"(y.x), "v"(y.y));
+#undef YM_BM
         };
         const int ntab = a.n_rowtab, mshift = a.rowtab_shift;
         for (int i = tid; i < OH * LPR; i += NT) {
@@ -301,17 +336,14 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                 if (mshift >= 0) { // (block-uniform)
                     const unsigned s4 = sw << mshift;                       // 28 bits: groups 0 .. 3
                     const unsigned r4 = __builtin_bitreverse32(s4) >> 4;    // the same 28 bits mirrored: group 3 first
-                    const uint2 t0 = rtab[s4 & 127u], t1 = rtab[128 + ((s4 >> 7) & 127u)];
-                    const uint2 m0 = rtab[r4 & 127u], m1 = rtab[128 + ((r4 >> 7) & 127u)]; // groups 3 and 2, cells in reverse order
-                    const uint2 d = make_uint2(bmin(t0.x, t1.x), bmin(t0.y, t1.y)), m = make_uint2(bmin(m0.x, m1.x), bmin(m0.y, m1.y));
-                    g.x = bmin(d.x, __builtin_amdgcn_perm(0u, m.y, 0x00010203u));
-                    g.y = bmin(d.y, __builtin_amdgcn_perm(0u, m.x, 0x00010203u));
+                    g = rtab[s4 & 127u];
+                    bmin2(g, rtab[128 + ((s4 >> 7) & 127u)]);
+                    uint2 m = rtab[r4 & 127u];                              // groups 3 and 2, cells in reverse order
+                    bmin2(m, rtab[128 + ((r4 >> 7) & 127u)]);
+                    bmin2(g, make_uint2(__builtin_amdgcn_perm(0u, m.y, 0x00010203u), __builtin_amdgcn_perm(0u, m.x, 0x00010203u)));
                 } else {
                     g = rtab[sw & 127u];
-                    for (int j = 1; j < ntab; j++) {
-                        const uint2 t = rtab[j * 128 + ((sw >> (7 * j)) & 127u)];
-                        g.x = bmin(g.x, t.x); g.y = bmin(g.y, t.y);
-                    }
+                    for (int j = 1; j < ntab; j++) bmin2(g, rtab[j * 128 + ((sw >> (7 * j)) & 127u)]);
                 }
                 *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = g;
                 atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
@@ -382,14 +414,14 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
         const unsigned long long m64 = (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask; // bit t: halo row y + t, dy = t - h
-        if (m64 == 0ull) { // no wall in reach of these eight cells (whole waves of a tile are like that)
-            store8(y, 0u, 0u);
-            continue;
-        }
+        uint32_t packed[2] = {0u, 0u};
+        if (m64 != 0ull) { // (else: no wall in reach of these eight cells -- whole waves of a tile are like that)
         auto tap = [&](int t) {
             const int dy = t - h;
             const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + t) * TW + x8]);
-            const unsigned short d2 = (unsigned short)__mul24(dy, dy); // (v_mul_i32_i24: full rate; a 32-bit multiply issues at a quarter)
+            int d2i;
+            asm("v_mul_i32_i24 %0, %1, %1" : "=v"(d2i) : "v"(dy)); // (asm: hipcc widens __mul24 of a small value to a quarter-rate v_mul_lo_u32)
+            const unsigned short d2 = (unsigned short)d2i;
             const us2 dd = (us2){d2, d2};
             const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
 #pragma unroll
@@ -421,10 +453,10 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         unsigned mn[8];
         mn[0] = mn2[0].x; mn[2] = mn2[0].y; mn[1] = mn2[1].x; mn[3] = mn2[1].y;
         mn[4] = mn2[2].x; mn[6] = mn2[2].y; mn[5] = mn2[3].x; mn[7] = mn2[3].y;
-        uint32_t packed[2] = {0u, 0u};
 #pragma unroll
         for (int q = 0; q < 8; q++) packed[q >> 2] |= (uint32_t)lut[mn[q]] << (8 * (q & 3));
-        store8(y, packed[0], packed[1]);
+        }
+        store_band(y, packed[0], packed[1], true);
     }
     YM_STAMP(a, 7);
     }; // one_tile
