@@ -349,7 +349,8 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
         loop_m.profile_read(1); loop_m.profile_read(2)
         loop_m.profile(False)
         if corr_n:
-            roof = replayed_roofline("cfg4", "ym::gather_kernel<1, 2, 4>", corr_ms / corr_n * 1e-3)
+            roof = replayed_roofline("cfg4", "ym::gather_kernel<1, 2, 4>", corr_ms / corr_n * 1e-3,
+                                     "region_correlate_body_alignbyte_form")  # (its loop still funnels with v_alignbyte: that body's peak)
             if roof is not None:
                 nbeams = 1081
                 roof["algorithmic_bytes_per_launch"] = float(hi - lo) * 41 * 41 * 21 * nbeams  # one byte per valid beam and hypothesis
