@@ -54,8 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16384, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--launch-batch", type=int, default=4096, help="matches per enqueue (workspace size)")
-    ap.add_argument("--lanes", type=int, default=2, help="matchers (stream + workspace each) the enqueues of a step alternate over: with two, "
-                    "the small kernels at the end of one enqueue run beside the large ones of the next (-3.5 %% step time)")
+    ap.add_argument("--lanes", type=int, default=4, help="matchers (stream + workspace each) the enqueues of a step alternate over: with one "
+                    "per enqueue (four) the kernels of the four enqueues of a step overlap freely -- 18.1 ms per step against 19.1 "
+                    "with two lanes and 19.9 with one (scripts/dev/lanes_ab.sh, same box)")
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-production-legs", action="store_true",
