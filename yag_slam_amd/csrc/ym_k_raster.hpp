@@ -128,9 +128,10 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     uint8_t *sz = a.sub_zero + (((size_t)bi * a.tiles_y + tiy) * a.tiles_x + tix) * 8;
     const unsigned tz_old = *tz;
     const uint2 sz_old = *reinterpret_cast<const uint2 *>(sz);
+    const unsigned long long sz_old64 = (unsigned long long)sz_old.x | (unsigned long long)sz_old.y << 32;
     auto old_zero = [&](int y) { // bit g: the band of row y, column group g, is known to hold zeros
-        const unsigned w = (y & 32) ? sz_old.y : sz_old.x;
-        return tz_old ? 0xffu : (w >> (y & 24)) & 0xffu;
+        // (one 64-bit shift: picking .x or .y by the row sent the pair to scratch)
+        return tz_old ? 0xffu : (unsigned)(sz_old64 >> (y & 56)) & 0xffu;
     };
     // the rows y (one band per wave: lane / 8 = row of the band, lane % 8 = column group) with `flags`: the band's new knowledge
     auto store_band = [&](int y, uint32_t p0, uint32_t p1, bool flags) {
