@@ -613,12 +613,14 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
     __syncthreads();
     const int n_boxes = a.max_base * YM_N_BOXES(a.max_n);
     const int4 *bbox = a.bbox + (size_t)b * n_boxes;
+    const int th_shift = a.tile_h == YM_TILE_H_TALL ? 6 : 5; // (tile heights are 32 or 64: a runtime division costs ~25 instructions)
+    static_assert(YM_TILE_H == 32 && YM_TILE_H_TALL == 64, "tile heights as shifts");
     for (int c = tid; c < n_boxes; c += NT) {
         const int4 bb = bbox[c];
         if (bb.x > bb.z) continue;
         // tiles whose halo-extended rectangle [t*T - h, t*T + T + h - 1] meets the box (the raster kernel's own test)
         const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
-        const int ty0 = max(ly0, max(bb.y - h, 0) / a.tile_h), ty1 = min(ly1, (bb.w + h) / a.tile_h);
+        const int ty0 = max(ly0, max(bb.y - h, 0) >> th_shift), ty1 = min(ly1, (bb.w + h) >> th_shift);
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 const int t = ty * a.tiles_x + tx;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(YM_TILES_THREADS) void tiles_kernel(TilesArgs a) {
         const int slot = c / n_cchunks;
         const uint16_t first_cell = (uint16_t)(slot * a.max_n + (c - slot * n_cchunks) * YM_BOX_CELLS); // (the host: max_base * max_n < 65536)
         const int tx0 = max(lx0, max(bb.x - h, 0) / YM_TILE_W), tx1 = min(lx1, (bb.z + h) / YM_TILE_W);
-        const int ty0 = max(ly0, max(bb.y - h, 0) / a.tile_h), ty1 = min(ly1, (bb.w + h) / a.tile_h);
+        const int ty0 = max(ly0, max(bb.y - h, 0) >> th_shift), ty1 = min(ly1, (bb.w + h) >> th_shift);
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 const int i = (ty - ly0) * ltx + (tx - lx0);
