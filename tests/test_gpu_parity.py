@@ -1139,6 +1139,46 @@ def test_raster_sub_block_knowledge_is_invisible(gx):
     m.close()
 
 
+def test_window_only_calls_and_plane_calls_on_one_matcher():
+    """A batch of 64+ items on the default lattice stages its regions from the row-major window and its raster writes no
+    column planes; single matches and small batches correlate from the planes.  One matcher takes both kinds of call in
+    turn, with the chains moving in between (so that planes left behind by an earlier call would be wrong): every call's
+    responses, poses and covariances are those of a matcher that has seen nothing else, and the integer sum volumes of
+    the large batch equal those of the same batch with the planes kept (debug option 39)."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    scene = synth.Scene()
+    base_poses, q_truth, q_prior = synth.single_match_poses()
+    ranges = [scene.scan_ranges(p, index=i) for i, p in enumerate(base_poses)]
+    query = synth.resident_scan(scene.scan_ranges(q_truth, index=10), q_prior)
+    m = ScanMatcher({"use_response_expansion": False})
+    m.debug_option(12, 1)  # (keep the integer sums)
+
+    def same(a, b):
+        assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
+        assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+    for k, (n, dx, dy, dt) in enumerate([(80, 0.0, 0.0, 0.0), (1, 0.21, -0.13, 0.03), (80, 0.21, -0.13, 0.03), (50, -0.4, 0.3, -0.06),
+                                         (1, -0.4, 0.3, -0.06), (96, 0.05, 0.02, 0.01), (1, 0.0, 0.0, 0.0)]):
+        base = [synth.resident_scan(r, (p[0] + dx, p[1] + dy, p[2] + dt)) for r, p in zip(ranges, base_poses)]
+        fresh = ScanMatcher({"use_response_expansion": False})
+        fresh.debug_option(12, 1)
+        fresh.debug_option(39, 1)  # (the fresh matcher always keeps the planes)
+        if n == 1:
+            same(m.match_scan(query, base, True, True), fresh.match_scan(query, base, True, True))
+        else:
+            chains = [base[:max(1, len(base) - (c % 4))] for c in range(n)]
+            pm, bm = m.match_scan_batch(query, chains, True, True)
+            pf, bf = fresh.match_scan_batch(query, chains, True, True)
+            assert bm == bf
+            for a, b in zip(pm, pf):
+                same(a, b)
+            dims = pm[0].meta["coarse_dims"]
+            for i in (0, 3, n - 1):
+                assert np.array_equal(m.debug_sums(0, item=i, dims=dims), fresh.debug_sums(0, item=i, dims=dims)), "call %d item %d" % (k, i)
+        fresh.close()
+    m.close()
+
+
 @pytest.mark.parametrize("sigma_cells", [1.0, 3.0, 6.0, 7.0])
 def test_raster_row_tables_are_invisible(sigma_cells):
     """The raster's row pass finds an 8-cell group's distances to the nearest occupied cell of its row in tables indexed by

@@ -200,6 +200,7 @@ struct CallPlan {
     int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1, rg_nregions = 0;
     int rg_rsplit = 1;  // blocks that share the regions of an (item, angle block) on small batches
     bool rg_item = false; // correlate_item_kernel: one block of 16 waves per item, the item's sums in LDS
+    bool win_only = false; // the region correlate stages from the row-major window and the raster does not write the planes
     bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
@@ -552,6 +553,7 @@ struct ym_matcher {
     int raster_planes_only = 0; // timing experiment (option 36): the raster does not write the row-major window
     int raster_no_rowtab = 0;   // tests (option 37): the raster's row pass by bit scans instead of its tables
     int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
+    int keep_planes = 0;         // option 39: 1 = every call writes the column planes and the region correlate stages from them
     int corr_region_pad_lds = 0; // development (option 38): dynamic LDS bytes the region correlate is launched with and does not use (fewer blocks per CU)
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
@@ -987,6 +989,8 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             P.rg_item = !P.rg_ws && P.rg_rsplit == 1 && lc.nt <= YM_IT_MAX_NT && m->corr_region_form != 1 &&
                         (m->corr_region_form == 3 || B >= m->item_min_batch);
             P.n_groups = P.rg_ng * P.rg_rsplit;
+            // the default form at eight waves stages from the window: the raster of such a call writes no planes (option 39 = 1: keeps them)
+            P.win_only = !P.rg_ws && !P.rg_item && P.rg_nw == 8 && !m->keep_planes;
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
             // (the wave-specialised form's bins are a third more and hold less each: 20 %)
@@ -1106,7 +1110,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->qnp.ensure(B))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * YM_N_BOXES(max_n)))) return rc;
-    if ((rc = m->grid.ensure((size_t)B * P.grid_stride))) return rc;
+    if ((rc = m->grid.ensure((size_t)B * P.grid_stride + YM_RG_WINDOW_SLACK(g.pitch)))) return rc;
     if ((rc = m->planes.ensure((size_t)B * P.grid_stride + std::max(std::max(YM_RG_PLANES_SLACK(g.pitch / 2), YM_WS_PLANES_SLACK(g.pitch / 2)), YM_GA_PLANES_SLACK(g.pitch / 2, std::max(P.ga_rows, P.ga_nry + P.ga_H), lc.ny, P.ga_P))))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * P.nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
@@ -1402,7 +1406,8 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     // the "tile is already zero" flags describe window MEMORY: they survive from call to call while the buffers and
     // the tiling stay the same, otherwise they are cleared
     const size_t per_item = (size_t)tiles_x * tiles_y, ntiles = (size_t)B * per_item;
-    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, (size_t)P.tile_h};
+    // (+ whether the planes are written: after calls that left them out they are stale, and the knowledge below covers both copies)
+    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, (size_t)P.tile_h | (P.win_only ? 0x100u : 0u)};
     const bool tz_grow = ntiles > m->tile_zero.cap || ntiles * 8 > m->sub_zero.cap; // (the two grow at different sizes)
     if ((rc = m->tile_zero.ensure(ntiles))) return rc;
     if ((rc = m->sub_zero.ensure(ntiles * 8))) return rc;
@@ -1590,7 +1595,7 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     a.cells = m->cells.p; a.bbox = m->bbox.p; a.states = m->states.p; a.g = g; a.grid = m->grid.p;
     a.grid_stride = P.grid_stride; a.planes = m->planes.p; a.lut = m->ktab.p; a.max_n = P.max_n; a.max_base = P.max_base; a.stamps = P.stamps;
     a.tile_zero = m->tile_zero.p; a.sub_zero = m->sub_zero.p; a.planes_only = m->raster_planes_only;
-    a.n_rowtab = m->raster_no_rowtab ? 0 : m->n_rowtab; a.rowtab = reinterpret_cast<const uint2 *>(m->rowtab.p); a.rowtab_shift = m->rowtab_shift; a.pad1 = 0;
+    a.n_rowtab = m->raster_no_rowtab ? 0 : m->n_rowtab; a.rowtab = reinterpret_cast<const uint2 *>(m->rowtab.p); a.rowtab_shift = m->rowtab_shift; a.no_planes = P.win_only ? 1 : 0;
     const size_t rlds = YM_RASTER_LDS_BYTES(P.tile_h, g.half_kernel, a.n_rowtab);
     a.tile_max = m->tile_max.p; a.tile_max_host = P.use_tile_list ? m->tile_max_host : nullptr;
     a.hits = (P.use_tile_list && P.use_tile_hits) ? m->tile_hits.p : nullptr; a.lty = P.lty; a.pad0 = 0;
@@ -1738,7 +1743,10 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         case 10: hipLaunchKernelGGL(ym::correlate_region_kernel<10>, rgrid, dim3(640), 0, st, r); break;
         case 11: hipLaunchKernelGGL(ym::correlate_region_kernel<11>, rgrid, dim3(704), 0, st, r); break;
         case 16: hipLaunchKernelGGL(ym::correlate_region_kernel<16>, rgrid, dim3(1024), 0, st, r); break;
-        default: hipLaunchKernelGGL(ym::correlate_region_kernel<8>, rgrid, dim3(512), (size_t)m->corr_region_pad_lds, st, r); break;
+        default:
+            if (P.win_only) hipLaunchKernelGGL((ym::correlate_region_kernel<8, true>), rgrid, dim3(512), (size_t)m->corr_region_pad_lds, st, r);
+            else hipLaunchKernelGGL(ym::correlate_region_kernel<8>, rgrid, dim3(512), (size_t)m->corr_region_pad_lds, st, r);
+            break;
         }
         return prof_end(m, ev_k);
     }
@@ -3280,6 +3288,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 36) m->raster_planes_only = value;
     else if (option == 37) m->raster_no_rowtab = value;
     else if (option == 38) m->corr_region_pad_lds = value;
+    else if (option == 39) m->keep_planes = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;

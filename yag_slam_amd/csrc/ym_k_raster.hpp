@@ -32,7 +32,8 @@ struct RasterArgs {
     const int32_t *tile_max;   // longest work list of the call (tiles_kernel)
     int32_t *tile_max_host;    // pinned host word block (0, 0) copies it to: the next call sizes its grid by it
     int32_t planes_only, n_rowtab; // planes_only: timing experiment, 1 = the row-major window is not written; n_rowtab: tables STORED
-    int32_t rowtab_shift, pad1;    // >= 0: the mirrored form (h <= 10) -- the 8 + 2h bits, shifted left by this much, sit in the middle
+    int32_t rowtab_shift, no_planes; // no_planes: 1 = the column planes are not written (a call whose correlate stages from the window)
+                                   // rowtab_shift >= 0: the mirrored form (h <= 10) -- the 8 + 2h bits, shifted left by this much, sit in the middle
                                    // of 28 = four groups of seven; tables 0 and 1 serve groups 0 and 1 directly and groups 3 and 2
                                    // through the mirror image (index bit-reversed, the eight distances in reverse order): 2 KB of LDS
                                    // instead of 4.  -1: table j serves bits 7j .. 7j + 6
@@ -115,9 +116,11 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
             const uint32_t row = (uint32_t)(ty0 + y), col = (uint32_t)(tx0 + x8);
             // (24-bit multiplies: a 32-bit v_mul_lo_u32 issues at a quarter of the rate)
             if (!a.planes_only) *reinterpret_cast<uint2 *>(grid + (__umul24(row, (uint32_t)a.g.pitch) + col)) = make_uint2(p0, p1);
-            uint8_t *pl = planes + (__umul24(row, (uint32_t)(a.g.pitch / 2)) + col / 2u);
-            *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
-            *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
+            if (!a.no_planes) {
+                uint8_t *pl = planes + (__umul24(row, (uint32_t)(a.g.pitch / 2)) + col / 2u);
+                *reinterpret_cast<uint32_t *>(pl) = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+                *reinterpret_cast<uint32_t *>(pl + plane_bytes) = __builtin_amdgcn_perm(p1, p0, 0x07050301u);
+            }
         }
     };
     // What is known of the tile's memory (round 4): a tile is either known to be zero, or every 8 x 8 sub-block of it says so

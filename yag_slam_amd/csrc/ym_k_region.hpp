@@ -51,6 +51,8 @@ namespace ym {
 // bytes the host keeps past the last item's planes: a staged region may start up to (ROWS - 1) * 2 + 1 rows and 96 bytes
 // past the last cell of the second plane (never gathered, but read)
 #define YM_RG_PLANES_SLACK(half_pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(half_pitch) + 256)
+// the same past the last item's row-major window, for the kernel that stages from it (WIN): rows of `pitch` bytes, 2 * 16 * SEGS bytes along a row
+#define YM_RG_WINDOW_SLACK(pitch) ((size_t)(2 * YM_RG_ROWS + 2 * YM_RG_H + 2) * (size_t)(pitch) + 512)
 // (what the staging loop of correlate_region_kernel reads of the last item: class 3, task row ROWS - 1 of a region that
 //  starts at most H - 1 class rows before the window's last one, i.e. plane row 2 * (H - 1 + ROWS - 1) + 1 past it, and
 //  16 * SEGS bytes along it)
@@ -361,7 +363,11 @@ __device__ __forceinline__ void rg_odd(uint32_t (&)[8]) {}
 // The walk over the regions is a two-stage pipeline: while region i is gathered, the global loads of region i + 1 are in
 // flight (registers) together with the wave's first 128 entries of it; they go to LDS between the two barriers that end
 // the gather.
-template <int NW>
+// WIN (round 4, large batches): the regions are staged from the ROW-MAJOR WINDOW, not from its column planes -- a staged row of
+// the two column classes of one row parity is 192 contiguous window bytes (16 bytes = eight class bytes of each parity, split by
+// two v_perm_b32 on their way into LDS) instead of 96 + 96 bytes half a megabyte apart, and the raster of such a call does not
+// write the planes at all: half its bytes (on a box whose memory takes writes slowly the raster's time is its stores).
+template <int NW, bool WIN = false>
 __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three blocks per CU: 80 VGPRs */) void correlate_region_kernel(RegionArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int PER = (YM_RG_ROWS + (NT / 4) / YM_RG_SEGS - 1) / ((NT / 4) / YM_RG_SEGS); // copy tasks per thread (rows of its segment)
@@ -462,16 +468,21 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         // wave-uniform, rboxl) is one segment test per region and two row compares per task.
         // Nothing is range-checked against the window: rows past it and blocks past a plane row are other bytes of the planes
         // buffer (the host allocates YM_RG_PLANES_SLACK bytes past the last item), and no patch the window holds reads them.
-        constexpr int TPC = NT / 4;                       // threads per class image
-        constexpr int LPS = TPC / YM_RG_SEGS;             // rows the threads of a class cover at once
+        // (WIN: a thread owns one 16-byte segment of a WINDOW row -- eight class bytes of each column parity -- of one row parity:
+        //  `cls` = the even-column class of its row parity, the odd-column class is the next image; twice the segments per row,
+        //  half the threads per row parity: the same rows at once, the same number of tasks)
+        constexpr int TPC = WIN ? NT / 2 : NT / 4;        // threads per class image (WIN: per row parity)
+        constexpr int NSEG = WIN ? 2 * YM_RG_SEGS : YM_RG_SEGS;
+        constexpr int LPS = TPC / NSEG;                   // rows the threads of a class cover at once
         constexpr int RSTEP = LPS;
         static_assert(LPS >= 1 && LPS * PER >= YM_RG_ROWS, "the copy tasks must cover a class image");
-        const uint32_t cls = (uint32_t)tid / TPC, j = (uint32_t)tid - cls * TPC;
-        const uint32_t seg = j % YM_RG_SEGS, r0 = j / YM_RG_SEGS;
-        const bool copier = j < (uint32_t)(LPS * YM_RG_SEGS);
-        const uint32_t src0 = (cls & 1u) * (uint32_t)plane_bytes + (2u * r0 + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
-        const uint32_t src_step = 2u * RSTEP * (uint32_t)half_pitch;
-        const uint32_t dst0 = (cls * YM_RG_ROWS + r0) * YM_RG_PITCH + 16u * seg;
+        const uint32_t cls = WIN ? 2u * ((uint32_t)tid / TPC) : (uint32_t)tid / TPC, j = (uint32_t)tid % TPC;
+        const uint32_t seg = j % NSEG, r0 = j / NSEG;
+        const bool copier = j < (uint32_t)(LPS * NSEG);
+        const uint32_t src0 = WIN ? (2u * r0 + (cls >> 1)) * (uint32_t)a.g.pitch + 16u * seg
+                                  : (cls & 1u) * (uint32_t)plane_bytes + (2u * r0 + (cls >> 1)) * (uint32_t)half_pitch + 16u * seg;
+        const uint32_t src_step = WIN ? 2u * RSTEP * (uint32_t)a.g.pitch : 2u * RSTEP * (uint32_t)half_pitch;
+        const uint32_t dst0 = (cls * YM_RG_ROWS + r0) * YM_RG_PITCH + (WIN ? 8u : 16u) * seg;
         uint4 v[PER];
         auto in_box = [&](int q, uint32_t bx, bool seg_in) {
             (void)q; (void)bx;
@@ -482,10 +493,17 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         auto band_in = [&](int q, uint32_t bx) {
             return (uint32_t)(q * RSTEP) <= ((bx >> 8) & 0xffu) && (uint32_t)(q * RSTEP + RSTEP - 1) >= (bx & 0xffu);
         };
+        const uint8_t *__restrict__ window = a.grid + (size_t)b * a.grid_stride;
+        // (the box names 16-byte segments of a class row; a window segment holds eight class bytes of each parity)
+        auto seg_inside = [&](uint32_t bx) {
+            return WIN ? copier && seg >= 2u * ((bx >> 16) & 0xffu) && seg <= 2u * (bx >> 24) + 1u
+                       : copier && seg >= ((bx >> 16) & 0xffu) && seg <= (bx >> 24);
+        };
         auto stage_load = [&](int R, uint32_t bx) {
             const int RX = R % a.nrx, RY = R / a.nrx;
-            const uint8_t *src = planes + ((size_t)(2 * RY * YM_RG_H) * half_pitch + (size_t)RX * YM_RG_W); // (wave-uniform)
-            const bool seg_in = copier && seg >= ((bx >> 16) & 0xffu) && seg <= (bx >> 24);
+            const uint8_t *src = WIN ? window + ((size_t)(2 * RY * YM_RG_H) * a.g.pitch + (size_t)RX * (2 * YM_RG_W))
+                                     : planes + ((size_t)(2 * RY * YM_RG_H) * half_pitch + (size_t)RX * YM_RG_W); // (wave-uniform)
+            const bool seg_in = seg_inside(bx);
             // (a task outside the box loads the region's first bytes -- one line for all of them -- and stores nothing; a load
             //  under a per-lane predicate costs the kernel 28 bytes of scratch per lane and is slower)
 #pragma unroll
@@ -493,11 +511,16 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 if (band_in(q, bx)) v[q] = *reinterpret_cast<const uint4 *>(src + (in_box(q, bx, seg_in) ? src0 + (uint32_t)q * src_step : 0u));
         };
         auto stage_store = [&](uint32_t bx) {
-            const bool seg_in = copier && seg >= ((bx >> 16) & 0xffu) && seg <= (bx >> 24);
+            const bool seg_in = seg_inside(bx);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(region + dst0 + (uint32_t)(q * RSTEP * YM_RG_PITCH)); // class images are contiguous
-                if (band_in(q, bx) && in_box(q, bx, seg_in)) { d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w; }
+                if (band_in(q, bx) && in_box(q, bx, seg_in)) {
+                    if (WIN) { // even window columns -> this image, odd ones -> the next
+                        d[0] = __builtin_amdgcn_perm(v[q].y, v[q].x, 0x06040200u); d[1] = __builtin_amdgcn_perm(v[q].w, v[q].z, 0x06040200u);
+                        d[YM_RG_CLS / 4] = __builtin_amdgcn_perm(v[q].y, v[q].x, 0x07050301u); d[YM_RG_CLS / 4 + 1] = __builtin_amdgcn_perm(v[q].w, v[q].z, 0x07050301u);
+                    } else { d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w; }
+                }
             }
         };
         // this wave's entries of a region: [t0, t2) (a multiple of four entries)
