@@ -636,7 +636,10 @@ def main():
             "collective": "all_gather of %d 64-byte best records per rank per step" % E if world > 1 else "none",
         }
         region = LB >= 8 and args.corr_region != 1
-        kernel = "ym::correlate_region_kernel<8>" if region else "ym::correlate_kernel<2, 16, 4>"
+        # (the default region correlate of a large batch stages from the row-major window: template argument WIN = true)
+        kernel = "ym::correlate_region_kernel<8, true>" if region else "ym::correlate_kernel<2, 16, 4>"
+        if region and any(o_ == 39 and v_ for o_, v_ in dev_opts):
+            kernel = "ym::correlate_region_kernel<8>"
         step_alg = hyp_step * nq  # coarse + fine lattice points x one byte per valid beam
         rl = replayed_roofline("cfg2x", kernel, corr_s) if LB == 4096 else None
         if rl is None:
