@@ -1032,7 +1032,8 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             assert vols[0][0][0].any()
             # the region correlate's other forms: wave-specialised (option 32 = 2: gather waves + loader waves, persistent blocks) and
             # one block per item with the item's sums in LDS (= 3: what large batches take), with the lists that fit and without
-            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3)):
+            # and the pooled form at two blocks per item (= 4: a region's patches dealt evenly over twelve waves, 16-bit sums in LDS)
+            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3), (4, 0), (4, 2), (4, 3)):
                 m = ScanMatcher(cfg)
                 m.debug_option(12, 1)
                 m.debug_option(32, form)
@@ -1045,7 +1046,7 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
                 same(other, vols[1])
             # without the kept sums (the production form: the region correlate scores its sums itself; option 21 = 2 leaves
             # that to the score kernel), through either kernel
-            for opts in ({}, {21: 2}, {14: 4}, {32: 2}, {32: 2, 21: 2}, {32: 3}, {32: 3, 21: 2}, {32: 3, 14: 2}):
+            for opts in ({}, {21: 2}, {14: 4}, {32: 2}, {32: 2, 21: 2}, {32: 3}, {32: 3, 21: 2}, {32: 3, 14: 2}, {32: 4}, {32: 4, 21: 2}, {32: 4, 14: 2}, {32: 4, 39: 1}):
                 m = ScanMatcher(cfg)
                 for k, v in opts.items():
                     m.debug_option(k, v)

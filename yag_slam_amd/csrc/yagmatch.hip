@@ -200,6 +200,7 @@ struct CallPlan {
     int rg_nrx = 0, rg_nry = 0, rg_ng = 1, rg_nbins = 0, rg_nw = 7, rg_parts = 1, rg_nregions = 0;
     int rg_rsplit = 1;  // blocks that share the regions of an (item, angle block) on small batches
     bool rg_item = false; // correlate_item_kernel: one block of 16 waves per item, the item's sums in LDS
+    bool rg_pool = false; // correlate_pool_kernel: two blocks of 12 waves per item, a region's patches dealt evenly, 16-bit sums in LDS
     bool win_only = false; // the region correlate stages from the row-major window and the raster does not write the planes
     bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
@@ -981,7 +982,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
             // kernel 121 -> 65 us with four, the enqueue 236 -> 205 us; 128 chains 317 -> 295 with two; scripts/dev/rsplit_time.py)
             P.rg_rsplit = 1;
-            if (!P.rg_ws && m->corr_region_rsplit != 1 && m->corr_region_form != 3) {
+            if (!P.rg_ws && m->corr_region_rsplit != 1 && m->corr_region_form != 3 && m->corr_region_form != 4) {
                 const int blocks = B * P.rg_parts;
                 P.rg_rsplit = m->corr_region_rsplit > 1 ? m->corr_region_rsplit : std::max(1, std::min(8, (3 * m->n_cus) / std::max(1, blocks)));
             }
@@ -989,8 +990,14 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             P.rg_item = !P.rg_ws && P.rg_rsplit == 1 && lc.nt <= YM_IT_MAX_NT && m->corr_region_form != 1 &&
                         (m->corr_region_form == 3 || B >= m->item_min_batch);
             P.n_groups = P.rg_ng * P.rg_rsplit;
+            // the pooled form (option 32 = 4): large batches of at most 22 angles
+            P.rg_pool = !P.rg_ws && !P.rg_item && P.rg_rsplit == 1 && m->corr_region_form == 4 && lc.nt <= 2 * YM_PL_MAX_NK && m->corr_region_nw == 0;
+            if (P.rg_pool) {
+                P.rg_nw = lc.nt <= YM_PL_MAX_NK ? lc.nt : (lc.nt + 1) / 2;
+                P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
+            }
             // the default form at eight waves stages from the window: the raster of such a call writes no planes (option 39 = 1: keeps them)
-            P.win_only = !P.rg_ws && !P.rg_item && P.rg_nw == 8 && !m->keep_planes;
+            P.win_only = !P.rg_ws && !P.rg_item && (P.rg_nw == 8 || P.rg_pool) && !m->keep_planes;
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
             // (the wave-specialised form's bins are a third more and hold less each: 20 %)
@@ -1728,6 +1735,11 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
                 m->item_lds_set = true;
             }
             hipLaunchKernelGGL(ym::correlate_item_kernel, dim3(P.B), dim3(64 * YM_IT_NW), lds, st, r);
+            return prof_end(m, ev_k);
+        }
+        if (P.rg_pool) {
+            if (P.win_only) hipLaunchKernelGGL(ym::correlate_pool_kernel<true>, rgrid, dim3(64 * YM_PL_NW), 0, st, r);
+            else hipLaunchKernelGGL(ym::correlate_pool_kernel<false>, rgrid, dim3(64 * YM_PL_NW), 0, st, r);
             return prof_end(m, ev_k);
         }
         if (P.rg_ws) {
