@@ -332,9 +332,9 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         const int ntab = a.n_rowtab, mshift = a.rowtab_shift;
         for (int i = tid; i < OH * LPR; i += NT) {
             const int ry = i / LPR, rx = (i % LPR) * 8;
-            const int w = rx >> 6, sft = rx & 63;
-            const unsigned long long lo = occ[ry * RW + w], hi = occ[ry * RW + w + 1];
-            const unsigned sw = (unsigned)((sft ? ((lo >> sft) | (hi << (64 - sft))) : lo) & gmask); // bits rx .. rx + 7 + 2h
+            // (the 8 + 2h <= 32 bits from bit rx on: one 32-bit funnel shift over two dwords of the row, not two 64-bit shifts)
+            const unsigned *rw = occ32 + ry * (RW * 2) + (rx >> 5);
+            const unsigned sw = __builtin_amdgcn_alignbit(rw[1], rw[0], (unsigned)rx & 31u) & (unsigned)gmask; // bits rx .. rx + 7 + 2h
             if (sw) { // (a group without a wall in reach writes nothing: the column pass only reads flagged rows)
                 uint2 g;
                 if (mshift >= 0) { // (block-uniform)
@@ -417,7 +417,9 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
         us2 mn2[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
-        const unsigned long long m64 = (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask; // bit t: halo row y + t, dy = t - h
+        // bit t: halo row y + t, dy = t - h  (the usual kernels: a 32-bit funnel shift over two dwords of the group's row flags)
+        const unsigned long long m64 = 2 * h + 1 <= 32 ? (unsigned long long)(__builtin_amdgcn_alignbit(ca[(y >> 5) + 1], ca[y >> 5], (unsigned)y & 31u) & (unsigned)tapmask)
+                                                       : (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask;
         uint32_t packed[2] = {0u, 0u};
         if (m64 != 0ull) { // (else: no wall in reach of these eight cells -- whole waves of a tile are like that)
         auto tap = [&](int t) {
