@@ -554,6 +554,7 @@ struct ym_matcher {
     int raster_planes_only = 0; // timing experiment (option 36): the raster does not write the row-major window
     int raster_no_rowtab = 0;   // tests (option 37): the raster's row pass by bit scans instead of its tables
     int corr_region_rsplit = 0; // 0 = by batch size, 1 = never split an item's regions over blocks, n = always n blocks
+    int tile_list_min_batch = 48; // option 40: batches from this size on get raster work lists (tiles_kernel)
     int keep_planes = 0;         // option 39: 1 = every call writes the column planes and the region correlate stages from them
     int corr_region_pad_lds = 0; // development (option 38): dynamic LDS bytes the region correlate is launched with and does not use (fewer blocks per CU)
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
@@ -1496,7 +1497,7 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     // a work list pays for its extra launch once the items are many
     // (from 48 items on: 256 items 210 -> 159 us, but 8 items 93 us per enqueue with the list against 80 without, 32 items
     //  148 / 144, 64 items 241 / 247)
-    P.use_tile_list = B >= 48 && P.ltx * P.lty > 0 && tiles_x * tiles_y < 32768;
+    P.use_tile_list = B >= m->tile_list_min_batch && P.ltx * P.lty > 0 && tiles_x * tiles_y < 32768;
     if (P.use_tile_list) {
         if ((rc = m->tile_list.ensure((size_t)B * P.tile_cap))) return rc;
         if ((rc = m->tile_count.ensure(B))) return rc;
@@ -3327,6 +3328,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 37) m->raster_no_rowtab = value;
     else if (option == 38) m->corr_region_pad_lds = value;
     else if (option == 39) m->keep_planes = value;
+    else if (option == 40) m->tile_list_min_batch = value;
     else if (option == 19) m->corr_region_cap = value;
     else if (option == 20) m->corr_region_lds = value;
     else if (option == 18) m->raster_hits_per_tile = value;
