@@ -544,6 +544,7 @@ struct ym_matcher {
     // ~190 us whatever the batch, while the direct kernel's time grows with the batch from ~15 us (measured, both lattices:
     // 8 chains 142 / 109 us against 220 / 225 per enqueue, 64 chains equal, 256 chains 675 / 759 against 485 / 452)
     int lds_min_batch = 64;
+    int rg_min_batch = 48;  // the region correlate from this many items on (round 4: 48 items 180 -> 169 us, 56 items 196 -> 184; below 44 the direct kernel wins)
     int prepare_threads = 0;     // development: 512 = the single-item prepare kernel with 512 threads per scan too
     int last_wh = 0;             // half width of the previous call's device window (cells, before clamping)
     bool use_scan_structure = true; // base scans' trigger chains come from ym_scan_create's structure_kernel where that is exact
@@ -977,7 +978,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         // by the per-cell path)
         P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
         P.rg_nbins = P.rg_nregions * lc.nt;
-        P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
+        P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= m->rg_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
                      lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         if (P.region26) {
             // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
@@ -3313,7 +3314,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 24) m->use_scan_structure = value != 0;
     else if (option == 25) m->chain_margin = value;
     else if (option == 26) m->prepare_threads = value;
-    else if (option == 28) m->lds_min_batch = std::max(8, value);
+    else if (option == 28) m->lds_min_batch = m->rg_min_batch = std::max(8, value);
     else if (option == 29) m->overlap_lists = value != 0;
     else if (option == 31) m->staged_queries = value != 0;
     else if (option == 30) m->tile_h_forced = value == YM_TILE_H || value == YM_TILE_H_TALL ? value : 0;
