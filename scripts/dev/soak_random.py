@@ -10,6 +10,7 @@ import test_gpu_parity as T
 from yag_slam_amd.scan_matching import ScanMatcher
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+big = len(sys.argv) > 3  # a third argument: batches of 130 - 600 chains (fused scoring, one-block finish)
 bad = 0
 for seed in range(first, first + n):
     cfg, query, base, pen, fine, rng = T._random_case(seed)
@@ -17,7 +18,7 @@ for seed in range(first, first + n):
         T.compare(cfg, query, base, pen, fine)
         nq, nb = T._mk_native(query), [T._mk_native(b) for b in base]
         chains = []
-        for _ in range(int(rng.integers(64, 101))):
+        for _ in range(int(rng.integers(130, 601)) if big else int(rng.integers(64, 101))):
             kind = int(rng.integers(0, 6))
             lo = int(rng.integers(0, len(nb)))
             hi = int(rng.integers(lo, len(nb))) + 1
