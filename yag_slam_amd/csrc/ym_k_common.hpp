@@ -188,8 +188,10 @@ __device__ __forceinline__ int hyp_cell(double centre, double start, int i, doub
 #define YM_TILE_H 32      // raster tile: 64 x 32 cells -- or 64 x 64 (YM_TILE_H_TALL) on large batches with large windows, chosen per call
 #define YM_TILE_H_TALL 64
 #define YM_RASTER_RW ((YM_TILE_W + 2 * YM_MAX_KERNEL_HALF + 63) / 64 + 1) // 64-bit words per row of the raster's occupancy bitmap
-// dynamic LDS of raster_kernel: bitmap + row distances of the tile and its halo, the row pass's tables, the smear values
-#define YM_RASTER_LDS_BYTES(th, h, ntab) ((size_t)((th) + 2 * (h)) * (YM_RASTER_RW * 8 + YM_TILE_W) + (size_t)(ntab) * 1024 + (size_t)((2 * (h) * (h) + 2 + 15) / 16 * 16))
+#define YM_RASTER_GP (YM_TILE_W + 8) // LDS bytes per row of the raster's row distances / finished tile (read and written with lane = row: 18 dwords apart)
+// dynamic LDS of raster_kernel: row distances of the tile and its halo | bitmap + the row pass's tables, later (with 544 bytes more) the finished tile | the smear values
+#define YM_RASTER_UNION(th, h, ntab) ((size_t)((th) + 2 * (h)) * YM_RASTER_RW * 8 + (size_t)(ntab) * 1024 > (size_t)(th) * YM_RASTER_GP ? (size_t)((th) + 2 * (h)) * YM_RASTER_RW * 8 + (size_t)(ntab) * 1024 : (size_t)(th) * YM_RASTER_GP)
+#define YM_RASTER_LDS_BYTES(th, h, ntab) ((size_t)((th) + 2 * (h)) * YM_RASTER_GP + YM_RASTER_UNION(th, h, ntab) + (size_t)((2 * (h) * (h) + 2 + 15) / 16 * 16))
 #define YM_TILE_HITS 64    // hit slots per entry of the raster's work list: the chunks that reach the entry's tile (four times what the bench scans need of a tall tile)
 
 }  // namespace ym

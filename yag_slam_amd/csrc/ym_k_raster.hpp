@@ -68,14 +68,17 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     constexpr int RW = YM_RASTER_RW;                   // 64-bit words per bitmap row, + 1 so a funnel read never leaves the row
     constexpr int LPR = TW / 8;                        // lanes per tile row (8 cells each)
     static_assert(RW == (TW + 2 * HM + 63) / 64 + 1, "YM_RASTER_RW");
-    // dynamic LDS (YM_RASTER_LDS_BYTES: sized by the kernel half in use, not by the largest one -- 10 KB on the usual kernels,
-    // sixteen blocks per CU): occ | grow | row tables | lut
+    // dynamic LDS (YM_RASTER_LDS_BYTES: sized by the kernel half in use, not by the largest one -- 11 KB on the usual kernels):
+    // grow | occ | row tables | lut; the finished tile (`outb`) takes the place of occ and the tables once the row pass is done.
+    // Rows of grow / outb are GP = 72 bytes apart: the column pass reads and writes them with lane = row.
+    constexpr int GP = YM_RASTER_GP;
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_dyn[];
     const int OHh = TH + 2 * a.g.half_kernel;
-    unsigned long long *occ = reinterpret_cast<unsigned long long *>(rs_dyn);                    // [OH * RW]
-    unsigned char *grow = rs_dyn + (size_t)OHh * RW * 8;                                          // [OH * TW]
-    uint2 *rtab = reinterpret_cast<uint2 *>(grow + (size_t)OHh * TW);                             // [n_rowtab * 128]
-    unsigned char *lut = reinterpret_cast<unsigned char *>(rtab + (size_t)a.n_rowtab * 128);      // [2 h h + 2]
+    unsigned char *grow = rs_dyn;                                                                 // [OH * GP]
+    unsigned long long *occ = reinterpret_cast<unsigned long long *>(rs_dyn + (size_t)OHh * GP);  // [OH * RW]
+    uint2 *rtab = reinterpret_cast<uint2 *>(occ + (size_t)OHh * RW);                              // [n_rowtab * 128]
+    unsigned char *outb = reinterpret_cast<unsigned char *>(occ);                                 // [TH * GP]
+    unsigned char *lut = rs_dyn + YM_RASTER_LDS_BYTES(TH, a.g.half_kernel, a.n_rowtab) - (size_t)((2 * a.g.half_kernel * a.g.half_kernel + 2 + 15) / 16 * 16); // [2 h h + 2]
     __shared__ unsigned colany[TW / 8][4]; // per 8-cell column group: bit ry = the row pass found a wall within reach in halo row ry
     __shared__ int s_hits[MAXHITS], s_left[MAXHITS];
     __shared__ int s_nhits;
@@ -86,7 +89,6 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     uint2 tq[TPT];
 #pragma unroll
     for (int u = 0; u < TPT; u++) tq[u] = (tid + u * NT) < a.n_rowtab * 128 ? a.rowtab[tid + u * NT] : make_uint2(0u, 0u);
-    bool tables_stored = false;
     // grid (x, B).  With a work list (batches) block i takes entry i of its item's list; without one (a few items: one
     // more launch would cost more than it saves) block i is tile i of the sub-grid and finds out by itself whether any
     // chunk box reaches it.
@@ -208,12 +210,9 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     }
     for (int i = tid; i < OH * RW; i += NT) occ[i] = 0ull;
     if (tid < (TW / 8) * 4) (&colany[0][0])[tid] = 0u;
-    if (!tables_stored) { // (once per block: the OVERFLOW blocks go through here once per tile)
 #pragma unroll
-        for (int u = 0; u < TPT; u++)
-            if ((tid + u * NT) < a.n_rowtab * 128) rtab[tid + u * NT] = tq[u];
-        tables_stored = true;
-    }
+    for (int u = 0; u < TPT; u++) // (per tile: the finished tile overwrites them)
+        if ((tid + u * NT) < a.n_rowtab * 128) rtab[tid + u * NT] = tq[u];
     for (int i = tid; i <= 2 * h * h + 1; i += NT) lut[i] = i <= 2 * h * h ? a.lut[i] : (unsigned char)0;
     __syncthreads();
     unsigned *occ32 = reinterpret_cast<unsigned *>(occ);
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                     g = rtab[sw & 127u];
                     for (int j = 1; j < ntab; j++) bmin2(g, rtab[j * 128 + ((sw >> (7 * j)) & 127u)]);
                 }
-                *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = g;
+                *reinterpret_cast<uint2 *>(&grow[ry * GP + rx]) = g;
                 atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
             }
         }
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                     const unsigned dl = left ? (unsigned)(h - 31 + __clz((int)left)) : 255u;
                     out[q >> 2] |= (dr < dl ? dr : dl) << (8 * (q & 3));
                 }
-                *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+                *reinterpret_cast<uint2 *>(&grow[ry * GP + rx]) = make_uint2(out[0], out[1]);
                 atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
             }
         }
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
                         out[q >> 2] = (out[q >> 2] & ~(0xffu << (8 * (q & 3)))) | (g << (8 * (q & 3)));
                     }
                 }
-                *reinterpret_cast<uint2 *>(&grow[ry * TW + rx]) = make_uint2(out[0], out[1]);
+                *reinterpret_cast<uint2 *>(&grow[ry * GP + rx]) = make_uint2(out[0], out[1]);
                 atomicOr(&colany[i % LPR][ry >> 5], 1u << (ry & 31));
             }
         }
@@ -410,59 +409,74 @@ __global__ __launch_bounds__(NT) void raster_kernel(RasterArgs a) {
     // the group's row mask): walls are thin, most (row, group) pairs have none and write zeros at once.
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const unsigned max_d2 = (unsigned)(2 * h * h);
-    const unsigned *ca = colany[x8 / 8];
-    const unsigned long long ca_lo = (unsigned long long)ca[0] | (unsigned long long)ca[1] << 32, ca_hi = (unsigned long long)ca[2] | (unsigned long long)ca[3] << 32; // (y + 2h <= TH - 1 + 40 < 128)
     const unsigned long long tapmask = (1ull << (2 * h + 1)) - 1ull;
+    // Round 4 (second half): a wave takes the rows of ONE column group (two groups of a 32-row tile), lane = row, not eight rows of
+    // all eight groups: along a wall that crosses the rows every lane of a group's wave has the same taps and the waves of the
+    // groups out of reach have none (a wave costs what its busiest lane costs).  The finished bytes go through LDS so that
+    // the stores stay row-wise (64 contiguous bytes of a window row per 8 lanes, sub-block knowledge per band).
+    {
+        constexpr int RPW = TH >= 64 ? 64 : TH, GPW = 64 / RPW; // rows and column groups per wave
+        static_assert(TH % RPW == 0 && TH <= 64 && (TH * LPR) % NT == 0, "a wave takes whole column groups of the tile");
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int it = 0; it < (TH * LPR) / NT; it++) {
+            const int grp = (it * (NT / 64) + wv) * GPW + ln / RPW, y = ln % RPW, gx8 = grp * 8;
+            const unsigned *ca = colany[grp];
+            const unsigned long long ca_lo = (unsigned long long)ca[0] | (unsigned long long)ca[1] << 32, ca_hi = (unsigned long long)ca[2] | (unsigned long long)ca[3] << 32; // (y + 2h <= TH - 1 + 40 < 128)
+            us2 mn2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
+            // bit t: halo row y + t, dy = t - h  (the usual kernels: a 32-bit funnel shift over two dwords of the group's row flags)
+            const unsigned long long m64 = 2 * h + 1 <= 32 ? (unsigned long long)(__builtin_amdgcn_alignbit(ca[(y >> 5) + 1], ca[y >> 5], (unsigned)y & 31u) & (unsigned)tapmask)
+                                                           : (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask;
+            uint32_t packed[2] = {0u, 0u};
+            if (m64 != 0ull) { // (else: no wall in reach of these eight cells)
+                auto tap = [&](int t) {
+                    const int dy = t - h;
+                    const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + t) * GP + gx8]);
+                    int d2i;
+                    asm("v_mul_i32_i24 %0, %1, %1" : "=v"(d2i) : "v"(dy)); // (asm: hipcc widens __mul24 of a small value to a quarter-rate v_mul_lo_u32)
+                    const unsigned short d2 = (unsigned short)d2i;
+                    const us2 dd = (us2){d2, d2};
+                    const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        us2 gq;
+                        __builtin_memcpy(&gq, &u[q], 4);
+                        mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 or 127 (none) is larger than any real distance
+                    }
+                };
+                if (2 * h + 1 <= 32) { // (block-uniform; the usual kernels: the tap mask is a 32-bit word, its scan half the instructions)
+                    unsigned m = (unsigned)m64;
+                    while (m) {
+                        const int t = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        tap(t);
+                    }
+                } else {
+                    unsigned long long m = m64;
+                    while (m) {
+                        const int t = __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        tap(t);
+                    }
+                }
+                // (lut[max_d2 + 1] = 0: anything farther is clamped to that index, two cells per v_pk_min_u16, no branch per cell)
+                const unsigned short cap = (unsigned short)(max_d2 + 1u);
+#pragma unroll
+                for (int q = 0; q < 4; q++) mn2[q] = __builtin_elementwise_min(mn2[q], (us2){cap, cap});
+                unsigned mn[8];
+                mn[0] = mn2[0].x; mn[2] = mn2[0].y; mn[1] = mn2[1].x; mn[3] = mn2[1].y;
+                mn[4] = mn2[2].x; mn[6] = mn2[2].y; mn[5] = mn2[3].x; mn[7] = mn2[3].y;
+#pragma unroll
+                for (int q = 0; q < 8; q++) packed[q >> 2] |= (uint32_t)lut[mn[q]] << (8 * (q & 3));
+            }
+            *reinterpret_cast<uint2 *>(&outb[y * GP + gx8]) = make_uint2(packed[0], packed[1]);
+        }
+    }
+    __syncthreads();
     for (int y = y0; y < TH; y += NT / LPR) {
-        us2 mn2[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) mn2[q] = (us2){0xffff, 0xffff};
-        // bit t: halo row y + t, dy = t - h  (the usual kernels: a 32-bit funnel shift over two dwords of the group's row flags)
-        const unsigned long long m64 = 2 * h + 1 <= 32 ? (unsigned long long)(__builtin_amdgcn_alignbit(ca[(y >> 5) + 1], ca[y >> 5], (unsigned)y & 31u) & (unsigned)tapmask)
-                                                       : (y ? (ca_lo >> y) | (ca_hi << (64 - y)) : ca_lo) & tapmask;
-        uint32_t packed[2] = {0u, 0u};
-        if (m64 != 0ull) { // (else: no wall in reach of these eight cells -- whole waves of a tile are like that)
-        auto tap = [&](int t) {
-            const int dy = t - h;
-            const uint2 gg = *reinterpret_cast<const uint2 *>(&grow[(y + t) * TW + x8]);
-            int d2i;
-            asm("v_mul_i32_i24 %0, %1, %1" : "=v"(d2i) : "v"(dy)); // (asm: hipcc widens __mul24 of a small value to a quarter-rate v_mul_lo_u32)
-            const unsigned short d2 = (unsigned short)d2i;
-            const us2 dd = (us2){d2, d2};
-            const uint32_t u[4] = {gg.x & 0x00ff00ffu, (gg.x >> 8) & 0x00ff00ffu, gg.y & 0x00ff00ffu, (gg.y >> 8) & 0x00ff00ffu};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                us2 gq;
-                __builtin_memcpy(&gq, &u[q], 4);
-                mn2[q] = __builtin_elementwise_min(mn2[q], (us2)(gq * gq + dd)); // g = 255 or 127 (none) is larger than any real distance
-            }
-        };
-        if (2 * h + 1 <= 32) { // (block-uniform; the usual kernels: the tap mask is a 32-bit word, its scan half the instructions)
-            unsigned m = (unsigned)m64;
-            while (m) {
-                const int t = __ffs((int)m) - 1;
-                m &= m - 1u;
-                tap(t);
-            }
-        } else {
-            unsigned long long m = m64;
-            while (m) {
-                const int t = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                tap(t);
-            }
-        }
-        // (lut[max_d2 + 1] = 0: anything farther is clamped to that index, two cells per v_pk_min_u16, no branch per cell)
-        const unsigned short cap = (unsigned short)(max_d2 + 1u);
-#pragma unroll
-        for (int q = 0; q < 4; q++) mn2[q] = __builtin_elementwise_min(mn2[q], (us2){cap, cap});
-        unsigned mn[8];
-        mn[0] = mn2[0].x; mn[2] = mn2[0].y; mn[1] = mn2[1].x; mn[3] = mn2[1].y;
-        mn[4] = mn2[2].x; mn[6] = mn2[2].y; mn[5] = mn2[3].x; mn[7] = mn2[3].y;
-#pragma unroll
-        for (int q = 0; q < 8; q++) packed[q >> 2] |= (uint32_t)lut[mn[q]] << (8 * (q & 3));
-        }
-        store_band(y, packed[0], packed[1], true);
+        const uint2 v = *reinterpret_cast<const uint2 *>(&outb[y * GP + x8]);
+        store_band(y, v.x, v.y, true);
     }
     YM_STAMP(a, 7);
     }; // one_tile
