@@ -1433,3 +1433,13 @@ def test_scan_pool_under_threads():
         t.join()
     assert not errors, errors
     assert all(got[t] == want for t in range(4))
+
+
+def test_large_lattice_fine_stage_against_the_oracle():
+    """configs[4]'s lattice (201 x 201 x 46) on single matches: the fine stage for lattices beyond 2048 cells keeps sixteen block
+    maxima per thread in registers and 32 loads of the covariance block in flight (`fine_kernel<true>`): response, pose and
+    covariance as the oracle's, on the full chain, a short one and one scan."""
+    cfg = dict(search_size=2.0, resolution=0.005, coarse_search_angle_offset=0.785)
+    q, base = cfg2_scans()
+    for chain in (base, base[:4], base[7:8]):
+        compare(cfg, q, chain, True, True)

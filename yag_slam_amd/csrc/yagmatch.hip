@@ -1889,7 +1889,8 @@ void enqueue_finish(ym_matcher *m, Slot &slot, const CallPlan &P) {
         if (small_blocks) hipLaunchKernelGGL(ym::finish_kernel<256>, dim3(P.B), dim3(256), lds, st, a);
         else hipLaunchKernelGGL(ym::finish_kernel<1024>, dim3(P.B), dim3(1024), lds, st, a);
     } else {
-        hipLaunchKernelGGL(ym::fine_kernel, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
+        if (lc.nx * lc.ny > 8 * YM_CANON) hipLaunchKernelGGL(ym::fine_kernel<true>, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
+        else hipLaunchKernelGGL(ym::fine_kernel<false>, dim3(call.refine ? lf.nt + 1 : 1, P.B), dim3(YM_FINE_THREADS), 0, st, a);
         if (P.B == 1 && m->poll_completion && !call.chain_step) { // the caller polls a word final_kernel writes after the result (no stream event to wait for)
             if (++slot.serial_counter == 0) slot.serial_counter = 1;
             slot.poll_serial = a.serial = slot.serial_counter;

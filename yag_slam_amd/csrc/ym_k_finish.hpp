@@ -245,24 +245,24 @@ __device__ __forceinline__ void tie_trig_table(const YmLattice &L, double start_
 // Coarse tail of CorrelateScan for one item: best response, mean of all hypotheses with
 // DoubleEqual(response, best).  Runs redundantly in every block that needs the coarse mean.
 // Returns best (unclamped); mean[] and *status valid in every thread.
-template <int NT>
+template <int NT, int KEEP = 4 /* block maxima per thread that stay in registers (all in flight together, no second read) */>
 __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const double *resp, const double *bm,
                                                        int n_blocks, const double pose[3], double mean[3], int *status,
                                                        double *scratch /* >= 80 */, int *s_list /* NT */, int *s_tmp /* NT */,
                                                        int *s_nlist, double2 *s_trig /* L.nt */,
-                                                       const double *first_round = nullptr /* [4]: bm[tid + u * NT] or -1, loaded by the caller */) {
+                                                       const double *first_round = nullptr /* [KEEP]: bm[tid + u * NT] or -1, loaded by the caller */) {
     const int tid = threadIdx.x;
     const int nh = L.nx * L.ny * L.nt;
     const double start_angle = pose[2] - L.angle_off;
     if (tid == 0) *s_nlist = 0;
     double lb = -1.0;
-    double v0[4]; // (the first round of block maxima is in flight while the table is computed)
+    double v0[KEEP]; // (the first round of block maxima is in flight while the table is computed)
 #pragma unroll
-    for (int u = 0; u < 4; u++) v0[u] = first_round ? first_round[u] : (tid + u * NT) < n_blocks ? bm[tid + u * NT] : -1.0;
+    for (int u = 0; u < KEEP; u++) v0[u] = first_round ? first_round[u] : (tid + u * NT) < n_blocks ? bm[tid + u * NT] : -1.0;
     tie_trig_table<NT>(L, start_angle, s_trig);
 #pragma unroll
-    for (int u = 0; u < 4; u++) lb = v0[u] > lb ? v0[u] : lb;
-    for (int i0 = tid + 4 * NT; i0 < n_blocks; i0 += 4 * NT) {
+    for (int u = 0; u < KEEP; u++) lb = v0[u] > lb ? v0[u] : lb;
+    for (int i0 = tid + KEEP * NT; i0 < n_blocks; i0 += 4 * NT) {
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = (i0 + u * NT) < n_blocks ? bm[i0 + u * NT] : -1.0;
@@ -274,7 +274,13 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
     // which hypothesis must not depend on a race.  Unordered compaction by atomics, then every entry finds its
     // rank among the (few) others.
     int overflow = 0;
-    for (int i = tid; i < n_blocks; i += NT)
+#pragma unroll
+    for (int u = 0; u < KEEP; u++) // (from the registers: the maxima are -1 beyond the last block)
+        if (v0[u] >= best - YM_KT_TOLERANCE) {
+            const int at = atomicAdd(s_nlist, 1);
+            if (at < NT) s_tmp[at] = tid + u * NT; else overflow = 1;
+        }
+    for (int i = tid + KEEP * NT; i < n_blocks; i += NT)
         if (bm[i] >= best - YM_KT_TOLERANCE) {
             const int at = atomicAdd(s_nlist, 1);
             if (at < NT) s_tmp[at] = i; else overflow = 1;
@@ -320,7 +326,7 @@ __device__ __forceinline__ double coarse_best_and_mean(const YmLattice &L, const
 }
 
 // ScanMatcher::ComputePositionalCovariance over the per-(x,y) maxima of the coarse pass; cov valid in every thread
-template <int NT>
+template <int NT, bool WIDE = false /* 32 loads in flight on lattices beyond 2048 cells (fine_kernel: registers to spare) */>
 __device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b, const YmItemState &st, const double mean[3],
                                                       double best, double cov[9], double *scratch) {
     const int tid = threadIdx.x;
@@ -333,25 +339,32 @@ __device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b
     const double dx = mean[0] - cxw, dy = mean[1] - cyw;
     if (!(best < YM_KT_TOLERANCE)) {
         const double *probs = a.probs + (size_t)b * a.probs_stride;
-        // eight loads in flight; the additions stay in increasing cell order (the canonical order above)
-        for (int c0 = tid; c0 < nxy && tid < YM_CANON; c0 += 8 * YM_CANON) {
-            double pv[8];
+        // U loads in flight; the additions stay in increasing cell order (the canonical order above).  A large lattice
+        // (configs[4]: 201 x 201 cells) is 158 cells per canonical thread: at eight loads per round that was twenty dependent
+        // round trips in the one block everything after it waits for.
+        auto walk = [&](auto u_tag) {
+            constexpr int U = decltype(u_tag)::value;
+            for (int c0 = tid; c0 < nxy && tid < YM_CANON; c0 += U * YM_CANON) {
+                double pv[U];
 #pragma unroll
-            for (int u = 0; u < 8; u++) pv[u] = (c0 + u * YM_CANON) < nxy ? probs[c0 + u * YM_CANON] : -1.0;
+                for (int u = 0; u < U; u++) pv[u] = (c0 + u * YM_CANON) < nxy ? probs[c0 + u * YM_CANON] : -1.0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int c = c0 + u * YM_CANON;
-                const double response = pv[u];
-                if (c < nxy && response >= (best - 0.1)) {
-                    const int iy = c / nx, ix = c - iy * nx;
-                    const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
-                    sums[0] += response;
-                    sums[1] += ((x - dx) * (x - dx)) * response;
-                    sums[2] += ((x - dx) * (y - dy) * response);
-                    sums[3] += ((y - dy) * (y - dy)) * response;
+                for (int u = 0; u < U; u++) {
+                    const int c = c0 + u * YM_CANON;
+                    const double response = pv[u];
+                    if (c < nxy && response >= (best - 0.1)) {
+                        const int iy = c / nx, ix = c - iy * nx;
+                        const double x = start_x + ix * L.step_x, y = start_y + iy * L.step_y;
+                        sums[0] += response;
+                        sums[1] += ((x - dx) * (x - dx)) * response;
+                        sums[2] += ((x - dx) * (y - dy) * response);
+                        sums[3] += ((y - dy) * (y - dy)) * response;
+                    }
                 }
             }
-        }
+        };
+        if (WIDE && nxy > 8 * YM_CANON) walk(std::integral_constant<int, WIDE ? 32 : 8>());
+        else walk(std::integral_constant<int, 8>());
     }
     block_sum_vec<4>(sums, scratch);
     if (best < YM_KT_TOLERANCE) {
@@ -378,6 +391,7 @@ __device__ __forceinline__ void positional_covariance(const FinishArgs &a, int b
 // ---- K6a fine: grid (nt_f + 1, B) (or (1, B) without refinement).  Block k < nt_f scores the 3x3 fine lattice for
 // fine angle k; the extra block computes the coarse pass's positional covariance at the same time.
 #define YM_FINE_THREADS 512
+template <bool WIDE /* a coarse lattice beyond 2048 cells: the covariance block keeps 32 loads in flight (131 VGPRs instead of 94) */>
 __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     constexpr int NT = YM_FINE_THREADS;
     __shared__ double scratch[16 * 5];
@@ -394,9 +408,10 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     // the block maxima leave together with the item's state: the "no readings" test on the state would otherwise put a
     // memory round trip of its own in front of them
     const double *bm = a.blockmax + (size_t)b * a.n_blocks;
-    double bm0[4];
+    constexpr int KEEP = WIDE ? 16 : 4; // (configs[4]: 7268 block maxima, fourteen per thread -- one round trip, not four, and no second read)
+    double bm0[KEEP];
 #pragma unroll
-    for (int u = 0; u < 4; u++) bm0[u] = (tid + u * NT) < a.n_blocks ? bm[tid + u * NT] : -1.0;
+    for (int u = 0; u < KEEP; u++) bm0[u] = (tid + u * NT) < a.n_blocks ? bm[tid + u * NT] : -1.0;
     YmItemState &st = a.states[b];
     const int nq = st.nq;
     if (nq == 0) return;
@@ -404,11 +419,11 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     const double off_x = st.off_x, off_y = st.off_y;
     double mean[3];
     int status = 0;
-    const double best = coarse_best_and_mean<NT>(a.lc, a.resp + (size_t)b * a.sums_stride, bm, a.n_blocks, pose, mean, &status,
-                                                 scratch, s_list, s_tmp, &s_nlist, s_trig, bm0);
+    const double best = coarse_best_and_mean<NT, KEEP>(a.lc, a.resp + (size_t)b * a.sums_stride, bm, a.n_blocks, pose, mean, &status,
+                                                       scratch, s_list, s_tmp, &s_nlist, s_trig, bm0);
     if (k == (a.refine ? a.lf.nt : 0)) { // extra block: coarse result + positional covariance for final_kernel
         double cov[9];
-        positional_covariance<NT>(a, b, st, mean, best, cov, scratch);
+        positional_covariance<NT, WIDE>(a, b, st, mean, best, cov, scratch);
         if (tid == 0) {
             st.center[0] = mean[0]; st.center[1] = mean[1]; st.center[2] = mean[2];
             st.coarse_response = best; // unclamped
