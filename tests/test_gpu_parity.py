@@ -1443,3 +1443,31 @@ def test_large_lattice_fine_stage_against_the_oracle():
     q, base = cfg2_scans()
     for chain in (base, base[:4], base[7:8]):
         compare(cfg, q, chain, True, True)
+
+
+def test_order_dependent_smear_split_form():
+    """On up to eight items the "value already set" rule runs split: hash and earlier-neighbour search as launches over all
+    points (tables in global memory, left zeroed), the chain of decisions in one block per item.  The surviving cells and the
+    grid equal the one-block kernel's (debug option 41 = 0) on single matches and on a batch of five ragged chains, call
+    after call on one matcher (the tables must come back clean), and the oracle's sequential rule."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    q, base = cfg2_scans(range_threshold=12.0)
+    nq, nb = _mk_native(q), [_mk_native(b) for b in base]
+    cfg = dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0)
+    a, b = ScanMatcher(cfg), ScanMatcher(cfg)
+    b.debug_option(41, 0)
+    for chain in (nb, nb[:3], nb[4:], nb[::-1], nb[2:3], nb):
+        ra, rb = a.match_scan(nq, chain, True, True), b.match_scan(nq, chain, True, True)
+        assert ra.response == rb.response and ra.covariance == rb.covariance
+        assert np.array_equal(a.debug_cells()[0], b.debug_cells()[0])
+        assert np.array_equal(a.debug_grid()[0], b.debug_grid()[0])
+    chains = [nb[:4], nb[2:6], nb[:2], nb[5:], nb[:4][::-1]]
+    for _ in range(2):
+        pa, _ = a.match_scan_batch(nq, chains, True, True)
+        pb, _ = b.match_scan_batch(nq, chains, True, True)
+        for x, y, ch in zip(pa, pb, chains):
+            assert x.response == y.response and x.covariance == y.covariance
+            z = a.match_scan(nq, ch, True, True)
+            assert x.response == z.response and x.covariance == z.covariance
+    a.close(); b.close()
+    compare(cfg, q, base[3:8], True, True)

@@ -596,6 +596,8 @@ struct ym_matcher {
     int cache_off = 0;                     // development: 1 = never cache (every call projects every scan)
     int64_t cache_hits = 0, cache_misses = 0;
     DevBuf<unsigned> sel_scratch; // select on long chains: hash, states and neighbour lists in global memory
+    DevBuf<unsigned> sel_tables;  // select on a few items (split form): hash keys and earliest-point table, zero between calls
+    DevBuf<uint4> sel_rec;        // ... and the record per point
     DevBuf<uint32_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
     DevBuf<int32_t> tile_max;        // [1] longest raster work list of the call
@@ -617,6 +619,7 @@ struct ym_matcher {
     int keep_sums = 0;      // development: keep the coarse integer sums of batches too (ym_debug_sums)
     int finish_threads = 0; // development: force the finish kernel's block size (256 / 1024)
     int select_global = 0; // development / tests: always evaluate the order-dependent smear rule with the global-memory kernel
+    int select_split_max = 8; // items up to which the rule runs in its split form (tests: 0 = the one-block kernel always)
     DevBuf<double> tmp_ranges;   // device copy of ranges for the descriptor-based entry
     PinnedBuf tmp_ranges_host;
     Slot slots[kAsyncSlots + 1]; // last one serves the synchronous entry points
@@ -1573,6 +1576,24 @@ int enqueue_select(ym_matcher *m, const CallPlan &P) {
         else hipLaunchKernelGGL(ym::select_global_kernel<9>, dim3(P.B), dim3(1024), lds, m->stream, g);
         return YM_OK;
     }
+    if (m->z2max <= 1 && P.B <= m->select_split_max) {
+        // a few items: the parallel steps (hash, earlier neighbours) as launches over all points, the chain of decisions in one
+        // block per item (ym_k_prepare.hpp, select_relax_kernel)
+        const size_t cap = (size_t)1 << log2cap;
+        const size_t had = m->sel_tables.cap;
+        int rc = m->sel_tables.ensure((size_t)2 * P.B * cap);
+        if (rc) return rc;
+        if (m->sel_tables.cap != had) HIP_TRY(hipMemsetAsync(m->sel_tables.p, 0, m->sel_tables.cap * sizeof(unsigned), m->stream));
+        if ((rc = m->sel_rec.ensure((size_t)P.B * pts))) return rc;
+        ym::SelectSplitArgs s;
+        s.cells = m->cells.p; s.max_n = P.max_n; s.max_base = P.max_base; s.log2cap = log2cap; s.pad = 0;
+        s.keys = m->sel_tables.p; s.mx = s.keys + (size_t)P.B * cap; s.rec = m->sel_rec.p; s.stamps = P.stamps;
+        const dim3 grid((unsigned)((pts + YM_SELECT_SPLIT_THREADS - 1) / YM_SELECT_SPLIT_THREADS), P.B);
+        hipLaunchKernelGGL(ym::select_hash_kernel, grid, dim3(YM_SELECT_SPLIT_THREADS), 0, m->stream, s);
+        hipLaunchKernelGGL(ym::select_neighbours_kernel, grid, dim3(YM_SELECT_SPLIT_THREADS), 0, m->stream, s);
+        hipLaunchKernelGGL(ym::select_relax_kernel, dim3(P.B), dim3(1024), cap, m->stream, s);
+        return YM_OK;
+    }
     ym::SelectArgs a;
     a.cells = m->cells.p; a.max_n = P.max_n; a.max_base = P.max_base; a.z2max = m->z2max; a.log2cap = log2cap; a.stamps = P.stamps;
     const size_t lds = (size_t)9 << log2cap;
@@ -2294,6 +2315,7 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_relax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2315,7 +2337,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->sub_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release();
+    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->sub_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release(); m->sel_tables.release(); m->sel_rec.release();
     m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
@@ -3306,6 +3328,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 6) m->finish_form = value;
     else if (option == 9) m->corr_cw = value;
     else if (option == 10) m->select_global = value;
+    else if (option == 41) m->select_split_max = value;
     else if (option == 11) m->finish_threads = value;
     else if (option == 12) m->keep_sums = value;
     else if (option == 13) m->corr_dedup = value;

@@ -867,6 +867,141 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     YM_STAMP(a, 31);
 }
 
+// ---- the same rule on a FEW items (z2max = 1), split by what is parallel and what is not (round 4).  Steps (1) and (2a) of
+// select_kernel are parallel work that one block does alone: 45 of its 79 us are 16 waves issuing ~4000 instructions each on
+// one CU.  Here they are two launches over all points (hash and earliest-point table in global memory, left zeroed for the
+// next call), and the one block per item that remains only runs the chain of dependent decisions (2b) and the erase (3) from
+// a 16-byte record per point: rec.x = slot | owned << 16 | effective << 17 (0xffffffff: no point), rec.y / rec.z = the slots of
+// the neighbour cells with an earlier point, 16 bits each (0xffff: none).
+struct SelectSplitArgs {
+    int2 *cells;          // [B][max_base][max_n]
+    int32_t max_n, max_base;
+    int32_t log2cap, pad;
+    unsigned *keys;       // [B][cap]  zero between calls
+    unsigned *mx;         // [B][cap]  zero between calls: max over the cell's points of ~index (= its earliest point)
+    uint4 *rec;           // [B][max_base * max_n]
+    unsigned long long *stamps;
+};
+#define YM_SELECT_SPLIT_THREADS 256
+// (1) grid (ceil(total / 256), B)
+__global__ __launch_bounds__(YM_SELECT_SPLIT_THREADS) void select_hash_kernel(SelectSplitArgs a) {
+    const int b = blockIdx.y, e = blockIdx.x * YM_SELECT_SPLIT_THREADS + threadIdx.x;
+    const int total = a.max_base * a.max_n;
+    if (e >= total) return;
+    const unsigned cap = 1u << a.log2cap, bmask = (cap >> 2) - 1u;
+    const int shift = 32 - (a.log2cap - 2);
+    const int2 c = a.cells[(size_t)b * total + e];
+    unsigned slot = 0xffffffffu;
+    if (c.x != YM_CELL_NONE) {
+        slot = (unsigned)select_insert(a.keys + (size_t)b * cap, bmask, shift, select_key(c.x, c.y));
+        atomicMax(&a.mx[(size_t)b * cap + slot], ~(unsigned)e);
+    }
+    a.rec[(size_t)b * total + e].x = slot;
+}
+// (2a) grid (ceil(total / 256), B)
+__global__ __launch_bounds__(YM_SELECT_SPLIT_THREADS) void select_neighbours_kernel(SelectSplitArgs a) {
+    constexpr int DX[5] = {0, 1, -1, 0, 0};
+    constexpr int DY[5] = {0, 0, 0, 1, -1};
+    const int b = blockIdx.y, e = blockIdx.x * YM_SELECT_SPLIT_THREADS + threadIdx.x;
+    const int total = a.max_base * a.max_n;
+    if (e >= total) return;
+    const unsigned cap = 1u << a.log2cap, bmask = (cap >> 2) - 1u;
+    const int shift = 32 - (a.log2cap - 2);
+    const unsigned *keys = a.keys + (size_t)b * cap, *mx = a.mx + (size_t)b * cap;
+    uint4 *rec = a.rec + (size_t)b * total + e;
+    const unsigned s = rec->x;
+    if (s == 0xffffffffu) return;
+    const int2 c = a.cells[(size_t)b * total + e];
+    const unsigned mine = ~(unsigned)e;
+    if (mx[s] != mine) { // a later point of its cell: never effective, nothing to decide
+        *rec = make_uint4(s, 0xffffffffu, 0xffffffffu, 0u);
+        return;
+    }
+    unsigned nbv[4];
+    bool any = false;
+#pragma unroll
+    for (int n = 1; n < 5; n++) {
+        const int t = select_find(keys, bmask, shift, select_key(c.x + DX[n], c.y + DY[n]));
+        const bool earlier = t >= 0 && mx[t] > mine; // (~index larger = index smaller)
+        nbv[n - 1] = earlier ? (unsigned)t : 0xffffu;
+        any |= earlier;
+    }
+    *rec = make_uint4(s | 1u << 16 | (any ? 0u : 1u << 17), nbv[0] | nbv[1] << 16, nbv[2] | nbv[3] << 16, 0u);
+}
+// (2b) + (3): grid (B), 1024 threads, dynamic LDS = one state byte per slot
+__global__ __launch_bounds__(1024) void select_relax_kernel(SelectSplitArgs a) {
+    constexpr int NT = 1024, PMAX = 12;
+    extern __shared__ unsigned sel_lds[];
+    unsigned char *status = reinterpret_cast<unsigned char *>(sel_lds); // 0 undecided, 1 effective, 2 out
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned cap = 1u << a.log2cap;
+    const int total = a.max_base * a.max_n;
+    int2 *cells = a.cells + (size_t)b * total;
+    const uint4 *rec = a.rec + (size_t)b * total;
+    // a thread takes `per` CONSECUTIVE points (see select_kernel: a wall's chain of decisions resolves inside one thread)
+    const int per = (total + NT - 1) / NT, e0 = tid * per;
+    YM_STAMP(a, 24);
+    uint4 r[PMAX];
+#pragma unroll
+    for (int q = 0; q < PMAX; q++) {
+        const int e = e0 + q;
+        r[q] = (q < per && e < total) ? rec[e] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+    }
+    for (unsigned i = tid; i < cap / 4; i += NT) sel_lds[i] = 0u;
+    __syncthreads();
+    unsigned und = 0;
+#pragma unroll
+    for (int q = 0; q < PMAX; q++) {
+        if (r[q].x == 0xffffffffu || !(r[q].x & (1u << 16))) continue;
+        if (r[q].x & (1u << 17)) status[r[q].x & 0xffffu] = 1;
+        else und |= 1u << q;
+    }
+    YM_STAMP(a, 3);
+    // asynchronous relaxation, no barriers (select_kernel, step (2b))
+    unsigned char *vst = status;
+    unsigned wmask = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; k++) wmask |= __ballot((und >> k) & 1u) ? (1u << k) : 0u;
+    while (wmask) {
+#pragma unroll
+        for (int k = 0; k < PMAX; k++) { // (unrolled: r[k] stays in registers; a point without undecided lanes costs a scalar test)
+            if (!((wmask >> k) & 1u)) continue;
+            bool still = false;
+            asm volatile("" ::: "memory"); // re-read the states every time
+            if ((und >> k) & 1u) {
+                bool knocked = false, pending = false;
+                const unsigned nbs[4] = {r[k].y & 0xffffu, r[k].y >> 16, r[k].z & 0xffffu, r[k].z >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (nbs[j] != 0xffffu) {
+                        const unsigned char stt = vst[nbs[j]];
+                        knocked |= stt == 1;
+                        pending |= stt == 0;
+                    }
+                }
+                const unsigned s = r[k].x & 0xffffu;
+                if (knocked) vst[s] = 2;
+                else if (!pending) vst[s] = 1;
+                else still = true;
+                if (!still) und &= ~(1u << k);
+            }
+            if (__ballot(still) == 0ull) wmask &= ~(1u << k);
+        }
+    }
+    __syncthreads();
+    YM_STAMP(a, 30);
+    // (3) keep only the earliest point of every effective cell
+#pragma unroll
+    for (int q = 0; q < PMAX; q++) {
+        if (r[q].x == 0xffffffffu) continue;
+        if (!((r[q].x & (1u << 16)) && status[r[q].x & 0xffffu] == 1)) cells[e0 + q] = make_int2(YM_CELL_NONE, YM_CELL_NONE);
+    }
+    // the tables as the next call expects them
+    uint4 *k4 = reinterpret_cast<uint4 *>(a.keys + (size_t)b * cap), *m4 = reinterpret_cast<uint4 *>(a.mx + (size_t)b * cap);
+    for (unsigned i = tid; i < cap / 4; i += NT) { k4[i] = make_uint4(0u, 0u, 0u, 0u); m4[i] = make_uint4(0u, 0u, 0u, 0u); }
+    YM_STAMP(a, 31);
+}
+
 // ---- the same rule for chains too long for one CU's LDS (more than 12 288 readings): hash, earliest-point index, neighbour
 // lists and states live in global memory (one 1024-thread block per item again -- the relaxation is a chain of
 // dependent decisions, not a parallel job -- but its reads now cost an L2 round trip instead of an LDS one).  LDS only
