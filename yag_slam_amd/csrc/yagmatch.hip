@@ -598,6 +598,7 @@ struct ym_matcher {
     DevBuf<unsigned> sel_scratch; // select on long chains: hash, states and neighbour lists in global memory
     DevBuf<unsigned> sel_tables;  // select on a few items (split form): hash keys and earliest-point table, zero between calls
     DevBuf<uint4> sel_rec;        // ... and the record per point
+    DevBuf<unsigned> sel_slot;    // ... and the point's slot (between the hash and the neighbour launch)
     DevBuf<uint32_t> tile_list; // raster work list per item
     DevBuf<int32_t> tile_count;
     DevBuf<int32_t> tile_max;        // [1] longest raster work list of the call
@@ -1584,10 +1585,11 @@ int enqueue_select(ym_matcher *m, const CallPlan &P) {
         int rc = m->sel_tables.ensure((size_t)2 * P.B * cap);
         if (rc) return rc;
         if (m->sel_tables.cap != had) HIP_TRY(hipMemsetAsync(m->sel_tables.p, 0, m->sel_tables.cap * sizeof(unsigned), m->stream));
-        if ((rc = m->sel_rec.ensure((size_t)P.B * pts))) return rc;
+        if ((rc = m->sel_rec.ensure((size_t)P.B * 12 * 1024))) return rc;
+        if ((rc = m->sel_slot.ensure((size_t)P.B * pts))) return rc;
         ym::SelectSplitArgs s;
         s.cells = m->cells.p; s.max_n = P.max_n; s.max_base = P.max_base; s.log2cap = log2cap; s.pad = 0;
-        s.keys = m->sel_tables.p; s.mx = s.keys + (size_t)P.B * cap; s.rec = m->sel_rec.p; s.stamps = P.stamps;
+        s.keys = m->sel_tables.p; s.mx = s.keys + (size_t)P.B * cap; s.rec = m->sel_rec.p; s.slot_of = m->sel_slot.p; s.stamps = P.stamps;
         const dim3 grid((unsigned)((pts + YM_SELECT_SPLIT_THREADS - 1) / YM_SELECT_SPLIT_THREADS), P.B);
         hipLaunchKernelGGL(ym::select_hash_kernel, grid, dim3(YM_SELECT_SPLIT_THREADS), 0, m->stream, s);
         hipLaunchKernelGGL(ym::select_neighbours_kernel, grid, dim3(YM_SELECT_SPLIT_THREADS), 0, m->stream, s);
@@ -2337,7 +2339,7 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->sub_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release(); m->sel_tables.release(); m->sel_rec.release();
+    m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->sub_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release(); m->sel_tables.release(); m->sel_rec.release(); m->sel_slot.release();
     m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();

@@ -871,7 +871,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
 // select_kernel are parallel work that one block does alone: 45 of its 79 us are 16 waves issuing ~4000 instructions each on
 // one CU.  Here they are two launches over all points (hash and earliest-point table in global memory, left zeroed for the
 // next call), and the one block per item that remains only runs the chain of dependent decisions (2b) and the erase (3) from
-// a 16-byte record per point: rec.x = slot | owned << 16 | effective << 17 (0xffffffff: no point), rec.y / rec.z = the slots of
+// a 16-byte record per point (SelectSplitArgs::rec): rec.x = slot | owned << 16 | effective << 17 (0xffffffff: no point), rec.y / rec.z = the slots of
 // the neighbour cells with an earlier point, 16 bits each (0xffff: none).
 struct SelectSplitArgs {
     int2 *cells;          // [B][max_base][max_n]
@@ -879,7 +879,9 @@ struct SelectSplitArgs {
     int32_t log2cap, pad;
     unsigned *keys;       // [B][cap]  zero between calls
     unsigned *mx;         // [B][cap]  zero between calls: max over the cell's points of ~index (= its earliest point)
-    uint4 *rec;           // [B][max_base * max_n]
+    unsigned *slot_of;    // [B][max_base * max_n]  the point's slot (0xffffffff: no cell)
+    uint4 *rec;           // [B][12 * 1024]  the record of point e = t * per + q at [q * 1024 + t]: thread t of select_relax_kernel reads its
+                          //                 `per` = ceil(points / 1024) consecutive points with coalesced loads
     unsigned long long *stamps;
 };
 #define YM_SELECT_SPLIT_THREADS 256
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(YM_SELECT_SPLIT_THREADS) void select_hash_kernel(Se
         slot = (unsigned)select_insert(a.keys + (size_t)b * cap, bmask, shift, select_key(c.x, c.y));
         atomicMax(&a.mx[(size_t)b * cap + slot], ~(unsigned)e);
     }
-    a.rec[(size_t)b * total + e].x = slot;
+    a.slot_of[(size_t)b * total + e] = slot;
 }
 // (2a) grid (ceil(total / 256), B)
 __global__ __launch_bounds__(YM_SELECT_SPLIT_THREADS) void select_neighbours_kernel(SelectSplitArgs a) {
@@ -908,22 +910,47 @@ __global__ __launch_bounds__(YM_SELECT_SPLIT_THREADS) void select_neighbours_ker
     const unsigned cap = 1u << a.log2cap, bmask = (cap >> 2) - 1u;
     const int shift = 32 - (a.log2cap - 2);
     const unsigned *keys = a.keys + (size_t)b * cap, *mx = a.mx + (size_t)b * cap;
-    uint4 *rec = a.rec + (size_t)b * total + e;
-    const unsigned s = rec->x;
-    if (s == 0xffffffffu) return;
-    const int2 c = a.cells[(size_t)b * total + e];
+    const int per = (total + 1023) / 1024;
+    uint4 *rec = a.rec + (size_t)b * 12 * 1024 + (size_t)(e % per) * 1024 + e / per;
+    const unsigned s = a.slot_of[(size_t)b * total + e];
+    const int2 c = a.cells[(size_t)b * total + e]; // (a point without a cell: YM_CELL_NONE, any bucket)
+    // the first probe of every neighbour leaves before the point's own entry is looked at: one round trip, not two
+    unsigned nkey[5], nbk[5];
+    uint4 nq[5];
+#pragma unroll
+    for (int n = 1; n < 5; n++) {
+        nkey[n] = select_key(c.x + DX[n], c.y + DY[n]);
+        nbk[n] = (nkey[n] * 2654435761u) >> shift;
+        nq[n] = *reinterpret_cast<const uint4 *>(keys + 4 * nbk[n]);
+    }
+    if (s == 0xffffffffu) {
+        *rec = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+        return;
+    }
     const unsigned mine = ~(unsigned)e;
     if (mx[s] != mine) { // a later point of its cell: never effective, nothing to decide
         *rec = make_uint4(s, 0xffffffffu, 0xffffffffu, 0u);
         return;
     }
+    int tn[5];
+#pragma unroll
+    for (int n = 1; n < 5; n++) {
+        const uint4 q4 = nq[n];
+        const unsigned key = nkey[n];
+        int t = q4.x == key ? (int)(4 * nbk[n]) : q4.y == key ? (int)(4 * nbk[n] + 1) : q4.z == key ? (int)(4 * nbk[n] + 2)
+                : q4.w == key ? (int)(4 * nbk[n] + 3) : q4.w == 0u ? -1 : -2;
+        if (t == -2) t = select_find_from(keys, bmask, (nbk[n] + 1u) & bmask, key); // (a full bucket without the key: go on)
+        tn[n] = t;
+    }
+    unsigned mt[5];
+#pragma unroll
+    for (int n = 1; n < 5; n++) mt[n] = mx[tn[n] >= 0 ? tn[n] : (int)s]; // (the four entries together)
     unsigned nbv[4];
     bool any = false;
 #pragma unroll
     for (int n = 1; n < 5; n++) {
-        const int t = select_find(keys, bmask, shift, select_key(c.x + DX[n], c.y + DY[n]));
-        const bool earlier = t >= 0 && mx[t] > mine; // (~index larger = index smaller)
-        nbv[n - 1] = earlier ? (unsigned)t : 0xffffu;
+        const bool earlier = tn[n] >= 0 && mt[n] > mine; // (~index larger = index smaller)
+        nbv[n - 1] = earlier ? (unsigned)tn[n] : 0xffffu;
         any |= earlier;
     }
     *rec = make_uint4(s | 1u << 16 | (any ? 0u : 1u << 17), nbv[0] | nbv[1] << 16, nbv[2] | nbv[3] << 16, 0u);
@@ -937,7 +964,7 @@ __global__ __launch_bounds__(1024) void select_relax_kernel(SelectSplitArgs a) {
     const unsigned cap = 1u << a.log2cap;
     const int total = a.max_base * a.max_n;
     int2 *cells = a.cells + (size_t)b * total;
-    const uint4 *rec = a.rec + (size_t)b * total;
+    const uint4 *rec = a.rec + (size_t)b * 12 * 1024;
     // a thread takes `per` CONSECUTIVE points (see select_kernel: a wall's chain of decisions resolves inside one thread)
     const int per = (total + NT - 1) / NT, e0 = tid * per;
     YM_STAMP(a, 24);
@@ -945,7 +972,7 @@ __global__ __launch_bounds__(1024) void select_relax_kernel(SelectSplitArgs a) {
 #pragma unroll
     for (int q = 0; q < PMAX; q++) {
         const int e = e0 + q;
-        r[q] = (q < per && e < total) ? rec[e] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+        r[q] = (q < per && e < total) ? rec[q * NT + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
     }
     for (unsigned i = tid; i < cap / 4; i += NT) sel_lds[i] = 0u;
     __syncthreads();
