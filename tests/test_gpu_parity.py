@@ -21,6 +21,7 @@ def compare(cfg, query, base, penalty, fine, loop=False, resident=True, check_gr
     o = orc.Oracle(cfg, "karto", loop=loop)
     ro = o.match_scan(query, base, penalty, fine)
     m = ScanMatcher(cfg, loop=loop)
+    m.debug_option(12, 1)  # (keep the integer sums whatever the lattice size)
     if resident:
         rq, rb = _mk_native(query), [_mk_native(b) for b in base]
     else:

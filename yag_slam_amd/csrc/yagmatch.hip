@@ -1868,7 +1868,9 @@ void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
     ym::ScoreArgs a;
     a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
-    a.sums = (P.B >= 8 && !m->keep_sums) ? nullptr : m->sums.p;
+    // (the integer sums are kept for ym_debug_sums on a few items of an ordinary lattice; on configs[4]'s 1.86 million hypotheses
+    //  they are a sixth of this stage's writes: debug option 12 keeps them there too)
+    a.sums = (m->keep_sums || (P.B < 8 && P.sums_c <= 65536)) ? m->sums.p : nullptr;
     a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
     a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
     a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
@@ -2001,7 +2003,7 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     m->last_B = P.B; m->last_max_n = P.max_n; m->last_max_base = P.max_base;
     m->last_nt_stride = P.nt_stride; m->last_dim_stride = P.dim_stride;
     m->last_grid_stride = P.grid_stride;
-    m->last_sums_stride[0] = P.yag ? P.yvol : (P.B >= 8 && !m->keep_sums) ? 0 : P.sums_c;
+    m->last_sums_stride[0] = P.yag ? P.yvol : (m->keep_sums || (P.B < 8 && P.sums_c <= 65536)) ? P.sums_c : 0;
     m->last_sums_stride[1] = slot.call.refine ? (P.yag ? P.yvol : P.sums_f) : 0;
     m->last_valid = true;
     return YM_OK;
