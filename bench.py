@@ -406,12 +406,13 @@ def leg_cfg5(device, query, chain, rank, world, torch, dist):
                "hypotheses_per_match": r.meta["hypotheses"], "us_per_match": dt * 1e6, "scan_matches_per_s": 1.0 / dt,
                "hypotheses_per_s": r.meta["hypotheses"] / dt, "correlate_kernel_us": corr_s * 1e6,
                "correlate_algorithmic_GBps": alg / corr_s / 1e9, "correlate_frac_of_hbm_peak": alg / corr_s / 1e9 / HBM_PEAK_GBS}
-        # the two kernels that are most of this match: the direct correlate (duration measured here) and the one-block
-        # select step of the order-dependent smear (duration from the profiled run), against their counters
+        # the direct correlate (duration measured here) and the one-block
+        # step of the order-dependent smear rule (duration from the profiled run), against their counters
         out["roofline"] = replayed_roofline("cfg5", "ym::correlate_kernel<2, 16, 1>", corr_s, "generic")
-        out["roofline_select"] = replayed_roofline("cfg5", "ym::select_kernel<5>", None, "generic", cus=1)
+        out["roofline_select"] = replayed_roofline("cfg5", "ym::select_relax_kernel", None, "generic", cus=1)
         if out["roofline_select"]:
-            out["roofline_select"]["note"] = "one block on one CU (a chain of dependent decisions): fractions are of that CU; no resource is the bound, the latency of its LDS round trips is"
+            out["roofline_select"]["note"] = ("the one-block step of the order-dependent smear rule (a chain of dependent decisions; its parallel steps are "
+                                              "select_hash_kernel and select_neighbours_kernel): fractions are of that CU; no resource is the bound, the latency of its LDS round trips is")
     if world > 1:
         sp = ymdist.AngleSplitMatcher(m, rank, world)
         g = sp.match_scan(query, chain, True, True)

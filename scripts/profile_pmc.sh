@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: the counter passes of a round for the three workloads whose kernels dominate a BASELINE config -- the
 # metric's batch (cfg2x: correlate_region_kernel, raster, finish, cells), the loop-closure batch (cfg4: gather_kernel) and the
-# stress match (cfg5: correlate_kernel<2,16,1>, select_kernel) --, each counter group in its own rocprofv3 run, nothing else
+# stress match (cfg5: correlate_kernel<2,16,1>, select_relax_kernel) --, each counter group in its own rocprofv3 run, nothing else
 # traced, copy kernels excluded; plus one kernel-trace pass per workload for the durations.  Summarised on the box
 # (scripts/summarise_counters.py: the CSVs are too large to travel) into gpurun_out/<tag>_counters.json.
 #   scripts/profile_pmc.sh r04p

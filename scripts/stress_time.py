@@ -29,5 +29,5 @@ ms, n = 0, 0
 m.debug_stamps(True)
 m.match_scan(nq, nb, True, True)
 st = m.debug_stamps(False)
-print("select_kernel phases (us): init %.1f, hash %.1f, neighbour slots %.1f, relaxation %.1f, erase %.1f" % tuple(
-    (st[b_] - st[a_]) / 100.0 for a_, b_ in ((24, 25), (25, 26), (26, 3), (3, 30), (30, 31))))
+print("select_relax_kernel phases (us): records + states %.1f, relaxation %.1f, erase + table reset %.1f" % tuple(
+    (st[b_] - st[a_]) / 100.0 for a_, b_ in ((24, 3), (3, 30), (30, 31))))
