@@ -279,7 +279,8 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * 1 = fine + final kernels, 2 = one-block finish kernel); 7: point cache of resident base scans (0 = on, 1 = off,
  * 2 = drop every entry); 8: point cache limit in KiB; 9: chunk-waves per correlate block; 10: order-dependent smear rule
  * always through the global-memory kernel; 11: threads per finish block (256 / 1024, 0 = by batch size);
- * 12: keep the coarse integer sums of batches of 8 or more items for ym_debug_sums (single matches always do);
+ * 12: keep the coarse integer sums for ym_debug_sums whatever the call (by default: fewer than 8 items on a lattice of at most
+ *     65536 hypotheses);
  * 13: merging of consecutive beams with the same lookup offset in the correlate kernel (0 = by grid coarseness, 1 = always,
  * 2 = never); 14: coarse correlate of batches (0 = the region correlate on lattices up to 26 x 32, the gather correlate on
  * others up to 48 x 64, else the direct kernel; 1 = always the direct kernel, 2 = the LDS correlates' per-cell path, 3 = their
@@ -294,7 +295,8 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * from the scan's creation-time structure; 25: tiles added around the raster rectangle a device-chained step predicts
  * (1; negative values make every chained step a fault); 26: 512 = the single-item prepare kernel with 512 threads per
  * scan; 28: batch size from which the LDS correlates replace the direct kernel (64; at least 8); 29: 0 = the region path's pair lists are built on the call's stream instead of next to the raster on the matcher's second stream; 31: 0 = a synchronous match waits for the creation launch of a just-created query scan instead of reading its staged readings; 30: rows per raster tile, 32 or 64, whatever the call (0 = the host's choice: 64 for 512+ items over windows of 768+ cells); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
- * (0: it scores them itself unless option 12 asks for the integer sums). */
+ * (0: it scores them itself unless option 12 asks for the integer sums); 41: items up to which the order-dependent smear
+ * rule runs in its split form (8; 0 = one block per item always). */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.
