@@ -1,7 +1,7 @@
 #!/bin/bash
 # development aid (GPU box): kernel trace of the sequential mapping loop; period between successive prepare kernels
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/seqprof -o seq -- python3 scripts/dev/seq_chain_only.py 600 ${1:-1} > gpurun_out/seqprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/seqprof -o seq -- python3 scripts/dev/seq_chain_only.py 600 ${1:-1} ${@:2} > gpurun_out/seqprof.log 2>&1
 python3 - <<'PY'
 import csv,glob,statistics
 f=glob.glob('gpurun_out/seqprof/**/seq_kernel_stats.csv',recursive=True)[0]

@@ -8,6 +8,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 chain = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
 truth, scans = synth.trajectory_scans(N)
 m = ScanMatcher()
+for o_, v_ in zip(sys.argv[3::2], sys.argv[4::2]):  # debug options: pairs after the two arguments
+    m.debug_option(int(o_), int(v_))
 for s in scans:
     s.native(0)
 mp = SequentialMapper(m)

@@ -505,6 +505,31 @@ __global__ __launch_bounds__(YM_FINE_THREADS) void fine_kernel(FinishArgs a) {
     YM_STAMP(a, 15);
 }
 
+// The loop over the fine angles of ComputeAngularCovariance: thread k takes angle k (its response -- an fp64 division -- and its
+// weighted term; eleven divisions in a row in EVERY thread were 0.4 us at the end of every match), then the sums are taken in
+// k order as the sequential loop takes them (an angle it skips contributes +0.0: x + 0.0 == x).  tmp: 2 * nt doubles that are
+// free; the result in every thread.  (Block-uniform call: it holds a barrier.)
+template <int NT>
+__device__ __forceinline__ double angular_cov_sums(const unsigned *s_asum, int nt, int nq, double start_angle, double angle_res,
+                                                   double best, double best_angle, double *tmp, double *norm_out) {
+    for (int k = threadIdx.x; k < nt; k += NT) {
+        const double angle = start_angle + k * angle_res;
+        double r = (double)s_asum[k];
+        r /= (double)(nq * YM_OCCUPIED);
+        const bool in = r >= (best - 0.1);
+        tmp[2 * k] = in ? r : 0.0;
+        tmp[2 * k + 1] = in ? ((angle - best_angle) * (angle - best_angle)) * r : 0.0;
+    }
+    __syncthreads();
+    double norm = 0.0, accv = 0.0;
+    for (int k = 0; k < nt; k++) {
+        norm += tmp[2 * k];
+        accv += tmp[2 * k + 1];
+    }
+    *norm_out = norm;
+    return accv;
+}
+
 // a chained step's pose and the next step's odometry prior (ym_map_sequence; yag_slam_amd/transform.py: a + b)
 __device__ __forceinline__ void chain_next_pose(const FinishArgs &a, const double pose[3]) {
     const double c = cos(pose[2]), s = sin(pose[2]);
@@ -631,16 +656,8 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
             }
         }
         __syncthreads();
-        double norm = 0.0, accv = 0.0;
-        for (int k = 0; k < nt; k++) {
-            const double angle = start_angle + k * L.angle_res;
-            double r = (double)s_asum[k];
-            r /= (double)(nq * YM_OCCUPIED);
-            if (r >= (best - 0.1)) {
-                norm += r;
-                accv += ((angle - best_angle) * (angle - best_angle)) * r;
-            }
-        }
+        double norm = 0.0;
+        double accv = angular_cov_sums<NT>(s_asum, nt, nq, start_angle, L.angle_res, best, best_angle, s_fresp, &norm);
         if (norm > YM_KT_TOLERANCE) {
             if (accv < YM_KT_TOLERANCE) accv = L.angle_res * L.angle_res;
             accv /= norm;
@@ -834,16 +851,8 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
             }
         }
         __syncthreads();
-        double norm = 0.0, accv = 0.0;
-        for (int k = 0; k < nt; k++) {
-            const double angle = start_angle + k * L.angle_res;
-            double r = (double)s_asum[k];
-            r /= (double)(nq * YM_OCCUPIED);
-            if (r >= (best - 0.1)) {
-                norm += r;
-                accv += ((angle - best_angle) * (angle - best_angle)) * r;
-            }
-        }
+        double norm = 0.0;
+        double accv = angular_cov_sums<NT>(s_asum, nt, nq, start_angle, L.angle_res, best, best_angle, s_fresp, &norm);
         if (norm > YM_KT_TOLERANCE) {
             if (accv < YM_KT_TOLERANCE) accv = L.angle_res * L.angle_res;
             accv /= norm;
