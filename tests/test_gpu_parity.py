@@ -1472,3 +1472,23 @@ def test_order_dependent_smear_split_form():
             assert x.response == z.response and x.covariance == z.covariance
     a.close(); b.close()
     compare(cfg, q, base[3:8], True, True)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_order_dependent_smear_random_chains(seed):
+    """Random chains (a random subset of the base scans in random order, poses jittered by up to 3 cm / 0.02 rad, one scan
+    repeated so that whole walls coincide cell for cell) under smear_deviation = 10 * resolution: window, sums, response, pose
+    and covariance of the split select rule against the oracle's sequential "value already set" rule."""
+    rng = np.random.default_rng(seed)
+    q, base = cfg2_scans(range_threshold=12.0)
+    order = list(rng.permutation(len(base))[: int(rng.integers(2, 7))])
+    order.append(order[0])  # (the same scan again: every one of its cells is taken already)
+    chain = []
+    for i in order:
+        b = base[i]
+        p = b.corrected_pose
+        chain.append(PlainScan(b.ranges, b.min_angle, b.angle_increment, b.min_range, 12.0,
+                               (p.x + rng.uniform(-0.03, 0.03), p.y + rng.uniform(-0.03, 0.03), p.euler[-1] + rng.uniform(-0.02, 0.02))))
+    chain[-1] = PlainScan(base[order[0]].ranges, base[order[0]].min_angle, base[order[0]].angle_increment, base[order[0]].min_range, 12.0,
+                          (chain[0].corrected_pose.x, chain[0].corrected_pose.y, chain[0].corrected_pose.euler[-1]))
+    compare(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0, search_size=0.2), q, chain, True, True)
