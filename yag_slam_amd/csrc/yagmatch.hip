@@ -1539,6 +1539,7 @@ void enqueue_prepare(ym_matcher *m, const CallPlan &P) {
     a.fault = nullptr; a.step = 0; a.pad1 = 0;
     for (int k = 0; k < 4; k++) a.cell_box[k] = P.cell_box[k];
     if (P.chain_step) { a.fault = m->seq_fault.p; a.step = P.chain_step; }
+    a.tile_max_zero = P.use_tile_list ? m->tile_max.p : nullptr;
     const size_t lds = YM_PREP_LDS_BYTES(P.max_n);
     if (P.split_prepare) {
         if (P.n_jobs > 0) hipLaunchKernelGGL(ym::points_kernel, dim3(P.n_jobs), dim3(YM_POINTS_THREADS), lds, m->stream, a);
@@ -1614,7 +1615,6 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
         t.tile_max = m->tile_max.p;
         t.hits = P.use_tile_hits ? m->tile_hits.p : nullptr; t.tile_h = P.tile_h;
         t.hit_limit = m->raster_hits_per_tile > 0 ? std::min(m->raster_hits_per_tile, YM_TILE_HITS) : YM_TILE_HITS;
-        (void)hipMemsetAsync(m->tile_max.p, 0, sizeof(int32_t), st);
         t.max_n = P.max_n; t.max_base = P.max_base; t.half_kernel = g.half_kernel;
         t.tiles_x = P.tiles_x; t.tiles_y = P.tiles_y; t.tile_cap = P.tile_cap;
         for (int k = 0; k < 4; k++) t.launch[k] = P.launch[k];
@@ -1726,7 +1726,10 @@ int enqueue_region_lists_aside(ym_matcher *m, CallPlan &P) {
         HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     }
-    HIP_TRY(hipEventRecord(m->ev_fork, m->stream));
+    HIP_TRY(hipEventRecord(m->ev_fork, m->stream)); // (after the prepare stage; the lists themselves are enqueued by
+    return YM_OK;                                   //  enqueue_region_lists_joined, once the raster's launches are out)
+}
+int enqueue_region_lists_joined(ym_matcher *m, CallPlan &P) {
     HIP_TRY(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
     int rc = enqueue_region_lists(m, P, m->side_stream);
     if (rc) return rc;
@@ -1962,9 +1965,14 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     emark(0);
     enqueue_prepare(m, P);
     emark(1);
-    if (P.region26 && !P.yag && m->overlap_lists && !P.stamps && P.k_end > P.k_begin && (rc = enqueue_region_lists_aside(m, P))) return rc;
+    // the region correlate's pair lists are built next to the raster on the matcher's second stream: the fork right behind the
+    // prepare stage, the launches of that stream after the raster's -- while the host made them first, the device sat idle
+    // between the prepare stage and the raster's first kernel (17 us of a 64-item enqueue's 214)
+    const bool lists_aside = P.region26 && !P.yag && m->overlap_lists && !P.stamps && P.k_end > P.k_begin;
+    if (lists_aside && (rc = enqueue_region_lists_aside(m, P))) return rc;
     if ((rc = enqueue_select(m, P))) return rc;
     if ((rc = enqueue_raster(m, P))) return rc;
+    if (lists_aside && (rc = enqueue_region_lists_joined(m, P))) return rc;
     emark(2);
     if (P.yag) {
         enqueue_yagpy_passes(m, slot, P);

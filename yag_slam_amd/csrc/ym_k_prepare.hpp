@@ -39,6 +39,8 @@ struct PrepareArgs {
     int32_t *fault;          // null: not a chained step
     int32_t step, pad1;
     int32_t cell_box[4];     // x0, y0, x1, y1 (inclusive)
+    int32_t *tile_max_zero;  // batches with raster work lists: the word tiles_kernel raises to the longest list, zeroed here (a
+                             // memset of its own was one more launch in the chain), or null
 };
 
 // LDS carve-up shared by the kernels that project a scan
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(NT) void prepare_kernel(PrepareArgs a) {
     if (a.stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.stamps[28] = wall_clock64() - a.stamps[19]; // idle since the previous call's end
     YM_STAMP(a, 0);
     const int b = blockIdx.y;
+    if (a.tile_max_zero && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *a.tile_max_zero = 0;
     const YmItem it = a.use_inline ? a.inl.item : a.items[b];
     const bool is_query = blockIdx.x == 0;
     const int slot = (int)blockIdx.x - 1;
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(YM_POINTS_THREADS) void points_kernel(PrepareArgs a
 __global__ __launch_bounds__(256) void cells_kernel(PrepareArgs a) {
     constexpr int NT = 256;
     const int b = blockIdx.y;
+    if (a.tile_max_zero && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *a.tile_max_zero = 0;
     const YmItem it = a.items[b];
     const int slot = (int)blockIdx.x - 1;
     const YmScanRef qr = a.scans[it.query];
