@@ -59,6 +59,9 @@ def parse_args(argv=None):
                     "with two lanes and 19.9 with one (scripts/dev/lanes_ab.sh, same box)")
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-distinct-queries", action="store_true", help="skip the cfg2x_distinct_queries leg (one query per item)")
+    ap.add_argument("--headline", default="one_query", choices=("one_query", "distinct_queries"),
+                    help="which cfg2x workload the metric line times: every item against the SAME query object, or every item with its own query")
     ap.add_argument("--no-production-legs", action="store_true",
                     help="skip cfg2x_batch_sweep / _fresh_query / _cold (profiling runs: only launches of the metric's batch size)")
     ap.add_argument("--cfg4-chains", type=int, default=CFG4_CHAINS)
@@ -189,6 +192,69 @@ def cpu_baseline(seconds=6.0):
     return out
 
 
+def physical_cores():
+    """(physical cores, logical cpus) this process may run on: distinct (package, core) pairs of the cpus in its affinity mask"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            cores.add(("?", str(c)))
+    return len(cores), len(allowed)
+
+
+def cpu_throughput(seconds=6.0):
+    """The CPU figure that belongs beside a GPU THROUGHPUT: independent cfg2 matches on every physical core of the host at once,
+    one oracle context (own grid, one thread) per core -- what a host-side farm of Karto matchers would do with the same
+    workload.  Python threads: the C call releases the GIL and lasts milliseconds."""
+    import threading
+    from oracle import oracle as orc
+    from tests.util import cfg2_scans
+    try:
+        lib = orc.load(orc.build(native=True))
+    except Exception:
+        lib = orc.load()
+    q, base = cfg2_scans()
+    phys, logical = physical_cores()
+    workers = []
+    for _ in range(phys):
+        o = orc.Oracle(None, "karto", threads=1, lib=lib)
+        qs, keep = orc.scan_from(q)
+        bs = [orc.scan_from(b) for b in base]
+        workers.append((o, qs, [b[0] for b in bs], keep, bs))
+    hyp = workers[0][0].match_raw(workers[0][1], workers[0][2], True, True).hypotheses
+    counts = [0] * phys
+    go = threading.Event()
+    deadline = [0.0]
+
+    def run(i):
+        o, qs, arr = workers[i][:3]
+        o.match_raw(qs, arr, True, True)  # (first touch of the context's grid on the core's memory)
+        go.wait()
+        while time.perf_counter() < deadline[0]:
+            o.match_raw(qs, arr, True, True)
+            counts[i] += 1
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(phys)]
+    for t in ts:
+        t.start()
+    time.sleep(0.5)
+    t0 = time.perf_counter()
+    deadline[0] = t0 + seconds
+    go.set()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = sum(counts)
+    return dict(hyp_per_s=n * hyp / dt, matches=n, seconds=dt, cores=phys, logical_cpus=logical, matches_per_s=n / dt,
+                ms_per_match_per_core=dt / max(1, n) * phys * 1e3)
+
+
 # ------------------------------------------------------------------------------------------------ inputs
 def generate_inputs(args, rank, world, legs):
     """Every range array the run needs, generated on the host BEFORE the GPU is touched (fork pool)."""
@@ -206,6 +272,12 @@ def generate_inputs(args, rank, world, legs):
             rng = np.random.default_rng(100000 * (rank + 1) + c)
             noisy.append([e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape) for e in exact])
         out["cfg2"] = (scene.scan_ranges(q_truth, index=10), q_prior, base_poses, noisy)
+        if "cfg2x" in legs and not args.no_distinct_queries:
+            # one query PER ITEM: its own true pose (seeded, within the search box of its prior), its own readings, its own prior
+            rng = np.random.default_rng(424242 + rank)
+            dq_truth = np.array(q_truth) + np.concatenate([rng.uniform(-0.05, 0.05, size=(n, 2)), rng.uniform(-0.03, 0.03, size=(n, 1))], axis=1)
+            dq_prior = np.array(q_prior) + np.concatenate([rng.uniform(-0.02, 0.02, size=(n, 2)), rng.uniform(-0.01, 0.01, size=(n, 1))], axis=1)
+            out["cfg2_queries"] = (synth.scan_ranges_many([(tuple(dq_truth[c]), 200000 + c) for c in range(n)], scene, workers), dq_prior)
     if "cfg3" in legs and rank == 0:
         out["cfg3"] = synth.scan_ranges_many(synth.trajectory_jobs(args.cfg3_scans), scene, workers)
     if "cfg4" in legs:
@@ -374,7 +446,7 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
             "ms_per_query": dt * 1e3, "ms_per_query_first_use_of_the_slots": dt_first * 1e3, "one_shot_ms_incl_results": one_shot * 1e3,
             "chain_matches_per_s": args.cfg4_chains / dt, "hypotheses_per_s": hyp_total / dt,
             "hypotheses": hyp_total, "winner": winner, "roofline": roof,
-            "collective": "all_gather of one 64-byte best record per rank" if world > 1 else "none"}
+            "collective": "all_gather of one 64-byte best record per rank" if dist is not None else "none"}
 
 
 def leg_cfg5(device, query, chain, rank, world, torch, dist):
@@ -413,7 +485,7 @@ def leg_cfg5(device, query, chain, rank, world, torch, dist):
         if out["roofline_select"]:
             out["roofline_select"]["note"] = ("the one-block step of the order-dependent smear rule (a chain of dependent decisions; its parallel steps are "
                                               "select_hash_kernel and select_neighbours_kernel): fractions are of that CU; no resource is the bound, the latency of its LDS round trips is")
-    if world > 1:
+    if dist is not None:  # (also the one-rank dry run of the RCCL path, YM_BENCH_FORCE_DIST)
         sp = ymdist.AngleSplitMatcher(m, rank, world)
         g = sp.match_scan(query, chain, True, True)
         for _ in range(3):
@@ -531,6 +603,15 @@ def main():
             lm.set_stream(ls.cuda_stream)
         NL = len(lanes)
         batches = [lanes[e % NL].make_batch(query, chains[e * LB:(e + 1) * LB]) for e in range(E)]
+        # the same chains, every item with its OWN query (own readings, own prior): ym_pairs_create
+        pbatches = dqueries = None
+        if "cfg2_queries" in gen:
+            dq_ranges, dq_prior = gen["cfg2_queries"]
+            dqueries = [synth.resident_scan(r, p) for r, p in zip(dq_ranges, dq_prior)]
+            for s_ in dqueries:
+                s_.native(local_rank)
+            pbatches = [lanes[e % NL].make_pairs_batch(dqueries[e * LB:(e + 1) * LB], chains[e * LB:(e + 1) * LB]) for e in range(E)]
+        headline_distinct = args.headline == "distinct_queries" and pbatches is not None
         nslots = min(64, 2 * ((E + NL - 1) // NL))
         nbuf = 2
         records = torch.zeros((nbuf, E, ymdist.RECORD), dtype=torch.float64, device="cuda")
@@ -539,7 +620,7 @@ def main():
         used = [[None] * nslots for _ in lanes]  # per lane: which batch object a slot's call belongs to
         counter = [0] * NL
 
-        def step(i, one_at_a_time=False):
+        def step(i, bs, one_at_a_time=False, marks=None):
             b = i % nbuf
             if works[b] is not None:
                 works[b].wait()  # its gathered records are about to be overwritten
@@ -550,12 +631,17 @@ def main():
                 counter[ln] += 1
                 if used[ln][s] is not None:
                     used[ln][s].wait(s, per_chain=False)  # recycle the slot (long since finished)
-                batches[e].run_async(True, True, slot=s, chain_id_base=rank * args.batch + e * LB,
-                                     dev_best_out=records[b, e].data_ptr())
-                used[ln][s] = batches[e]
+                bs[e].run_async(True, True, slot=s, chain_id_base=rank * args.batch + e * LB,
+                                dev_best_out=records[b, e].data_ptr())
+                used[ln][s] = bs[e]
                 if one_at_a_time:  # (the profiling pass: a kernel's duration means something only while nothing runs beside it)
-                    batches[e].wait(s, per_chain=False)
+                    bs[e].wait(s, per_chain=False)
                     used[ln][s] = None
+            if marks is not None:  # when this step's work is complete on the device: the latest of its lanes' marks
+                evs = [torch.cuda.Event(enable_timing=True) for _ in lane_streams]
+                for ev_, ls in zip(evs, lane_streams):
+                    ev_.record(ls)
+                marks.append(evs)
             if dist is not None:
                 # cross-rank arg-max payload: E 64-byte records per rank.  Asynchronous: RCCL's stream waits for this
                 # step's records (on every lane's stream), the launch streams go straight on to the next step
@@ -574,6 +660,44 @@ def main():
                     works[b].wait()
                     works[b] = None
 
+        def timed_steps(bs, steps, warmup):
+            """`warmup` untimed steps, then `steps` steps between two barriers; returns (seconds, max over the ranks; per-step
+            completion intervals in ms on this rank, from HIP events on the lanes' streams)"""
+            import gc
+            for i in range(warmup):
+                step(i, bs)
+            drain()
+            gc.collect()
+            gc.disable()  # (a generation-2 pass over the 170 000 resident scan objects takes 80 ms: not inside a 0.9 s measurement)
+            barrier()
+            marks = []
+            start = torch.cuda.Event(enable_timing=True)
+            start.record(lane_streams[0])
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i, bs, marks=marks)
+            barrier()
+            dt_ = time.perf_counter() - t0
+            gc.enable()
+            if dist is not None:  # the last step's gather carries this rank's own records in their place
+                b_last = (steps - 1) % nbuf
+                works[b_last].wait()
+                got = gathered[b_last].view(world, E, ymdist.RECORD)[rank]
+                assert torch.equal(got, records[b_last])
+            drain()
+            t = torch.tensor([dt_], dtype=torch.float64, device="cuda")
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ends = [max(start.elapsed_time(ev_) for ev_ in evs) for evs in marks]
+            per_step = [b_ - a_ for a_, b_ in zip([0.0] + ends[:-1], ends)]
+            return float(t.item()), per_step
+
+        def spread(per_step):
+            v = sorted(per_step)
+            return {"min": v[0], "median": v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), "max": v[-1],
+                    "what": "ms between the completion of consecutive steps on the device (HIP events on the lanes' streams; the steps are "
+                            "enqueued back to back, so the first one also carries the pipeline's fill)"}
+
         # correctness of what is timed: first enqueue against the single-call path
         per, best, bi = (batches[0].run_async(True, True, slot=0) or batches[0].wait(0))
         hyp_per_match = per[0].meta["hypotheses"]
@@ -581,36 +705,21 @@ def main():
         hyp_step = hyp_per_match * args.batch
         ref = m.match_scan(query, chains[0], True, True)
         assert ref.response == per[0].response and ref.covariance == per[0].covariance
+        if pbatches is not None:  # ... and of the distinct-query form: three of its items against their single calls
+            pper, _, _ = (pbatches[0].run_async(True, True, slot=0) or pbatches[0].wait(0))
+            assert all(p.meta["hypotheses"] == hyp_per_match for p in pper)
+            for i_ in (0, LB // 2, LB - 1):
+                ref = m.match_scan(dqueries[i_], chains[i_], True, True)
+                assert ref.response == pper[i_].response and ref.covariance == pper[i_].covariance, i_
 
-        for i in range(args.warmup):
-            step(i)
-        drain()
-        import gc
-        gc.collect()
-        gc.disable()  # (a generation-2 pass over the 170 000 resident scan objects takes 80 ms: not inside a 0.9 s measurement)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        barrier()
-        dt = time.perf_counter() - t0
-        gc.enable()
-        if dist is not None:  # the last step's gather carries this rank's own records in their place
-            b_last = (args.steps - 1) % nbuf
-            works[b_last].wait()
-            got = gathered[b_last].view(world, E, ymdist.RECORD)[rank]
-            assert torch.equal(got, records[b_last])
-        drain()
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        hb = pbatches if headline_distinct else batches
+        dt, per_step = timed_steps(hb, args.steps, args.warmup)
 
         # roofline of the dominant kernel (coarse correlate): HIP events on the launch stream, second pass
         for lm in lanes:
             lm.profile(True)
         for i in range(min(args.steps, 4)):
-            step(i, one_at_a_time=NL > 1)
+            step(i, hb, one_at_a_time=NL > 1)
         drain()
         corr_ms = corr_n = call_ms = call_n = 0
         for lm in lanes:
@@ -627,15 +736,33 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         line["value"] = hyp_step * world * args.steps / dt
         line["ms_per_step"] = ms_per_step
+        line["ms_per_step_spread"] = spread(per_step)
         line["config"] = {
-            "workload": "cfg2 x batch: %d independent single-match problems per step per GPU (1081-beam query vs distinct "
-                        "10-scan chains, search 0.5 m / 0.349 rad, resolution 0.01, coarse 26x26x21 + fine 3x3x11, penalty "
-                        "on), Karto semantics, issued as %d enqueues of %d" % (args.batch, E, LB),
+            "workload": ("cfg2 x batch: %d INDEPENDENT single-match problems per step per GPU -- every item its own 1081-beam query (own "
+                         "readings, own prior) against its own 10-scan chain" if headline_distinct else
+                         "cfg2 x batch: ONE 1081-beam query against %d distinct 10-scan chains per step per GPU (every item its own "
+                         "correlation grid and search; the query object and its pair lists are shared by the items of an enqueue)") % args.batch +
+                        ", search 0.5 m / 0.349 rad, resolution 0.01, coarse 26x26x21 + fine 3x3x11, penalty "
+                        "on, Karto semantics, issued as %d enqueues of %d, resident batches enqueued again every step (plan replay, warm point cache)" % (E, LB),
+            "queries_per_enqueue": LB if headline_distinct else 1,
             "batch_per_gpu": args.batch, "launch_batch": LB, "lanes": NL, "hypotheses_per_match": hyp_per_match,
             "scan_matches_per_s": args.batch * world * args.steps / dt,
             "timed_seconds": dt,
-            "collective": "all_gather of %d 64-byte best records per rank per step" % E if world > 1 else "none",
+            "collective": "all_gather of %d 64-byte best records per rank per step" % E if dist is not None else "none",
         }
+        # the other form of the workload, same lanes, same step function, fewer steps
+        if pbatches is not None:
+            ob = batches if headline_distinct else pbatches
+            odt, oper = timed_steps(ob, max(4, args.steps // 2), 2)
+            osteps = max(4, args.steps // 2)
+            by_config["cfg2x_one_query" if headline_distinct else "cfg2x_distinct_queries"] = {
+                "what": ("every item against the SAME query object" if headline_distinct else
+                         "every item its OWN query (own readings, own prior): %d distinct queries per enqueue, ym_pairs_create" % LB) +
+                        "; same chains, lanes and step function as the metric line",
+                "queries_per_enqueue": 1 if headline_distinct else LB, "steps": osteps, "ms_per_step": odt / osteps * 1e3,
+                "ms_per_step_spread": spread(oper), "hypotheses_per_s": hyp_step * world * osteps / odt,
+                "scan_matches_per_s": args.batch * world * osteps / odt,
+                "ratio_to_metric_line": (hyp_step * world * osteps / odt) / line["value"]}
         region = LB >= 8 and args.corr_region != 1
         # (the default region correlate of a large batch stages from the row-major window: template argument WIN = true)
         kernel = "ym::correlate_region_kernel<8, true>" if region else "ym::correlate_kernel<2, 16, 4>"
@@ -749,7 +876,7 @@ def main():
             sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold)]
         else:
             sweep_legs = []
-        del batches
+        del batches, pbatches
         for lm in lanes[1:]:
             lm.close()
     else:
@@ -814,11 +941,19 @@ def main():
         guarded("cfg4_loop_closure_batch", run_cfg4, collective=world > 1)
     if "cpu" in legs and rank == 0 and world == 1:  # the CPU baseline is a single-GPU-run item
         cb = cpu_baseline()
+        ct = cpu_throughput()
         line["cpu_baseline"] = {
             "value": cb["single"]["hyp_per_s"], "unit": "hypotheses/s", "cores": 1, "kind": "port",
             "sample": "%d cfg2 matches (coarse+fine, penalty) in %.1f s, oracle/ym_oracle.c karto semantics, "
                       "-O3 -march=native, 1 thread" % (cb["single"]["matches"], cb["single"]["seconds"]),
-            "host": {"cpu_model": cpu_model(), "logical_cpus": os.cpu_count() or 1},
+            "host": {"cpu_model": cpu_model(), "logical_cpus": os.cpu_count() or 1, "physical_cores": ct["cores"],
+                     "logical_cpus_in_affinity_mask": ct["logical_cpus"]},
+            # what belongs beside a GPU THROUGHPUT figure: independent matches on every physical core at once
+            "throughput": {"value": ct["hyp_per_s"], "unit": "hypotheses/s", "cores": ct["cores"], "scan_matches_per_s": ct["matches_per_s"],
+                           "ms_per_match_per_core": ct["ms_per_match_per_core"],
+                           "sample": "%d independent cfg2 matches (coarse+fine, penalty) in %.1f s on %d threads, one per physical core, each with "
+                                     "its own oracle context (own correlation grid, one thread), oracle/ym_oracle.c karto semantics, -O3 "
+                                     "-march=native" % (ct["matches"], ct["seconds"], ct["cores"])},
             "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
                           "serial_fraction": cb["all"]["serial_fraction"],
                           "sample": "%d matches in %.1f s, OpenMP over the coarse lattice; grid clear and rasterisation "

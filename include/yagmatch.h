@@ -15,6 +15,9 @@
  *   ym_match                      same call, for callers that hold plain range arrays (no resident scan)
  *   ym_match_batch, ym_batch_*    the serial chain loop of GraphSlam.try_to_close_loop
  *                                 /root/reference/yag_slam/graph_slam.py:217-236 (one query, many chains)
+ *   ym_match_pairs, ym_pairs_create  N independent Wrapper.match_scan calls (N x /root/reference/yag_slam/graph_slam.py:326:
+ *                                 N robots, or N segments of a log replayed side by side) in one enqueue: item i =
+ *                                 query i against chain i
  *   ym_result                     the returned object's .response / .covariance / .best_pose
  *                                 /root/reference/yag_slam/scan_matching.py:42, /root/reference/test.py:39-41
  *
@@ -200,6 +203,19 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
                        int64_t chain_id_base, void *dev_best_out);
 int ym_batch_wait(ym_matcher *m, int slot, ym_result *per_chain, ym_result *best, int32_t *best_chain);
 
+/* n_items INDEPENDENT matches in one enqueue: item i = queries[i] against scans[chain_offsets[i] .. chain_offsets[i+1])
+ * -- what n_items separate Wrapper.match_scan(query_i._scan, chain_i, penalty, do_fine) calls compute
+ * (/root/reference/yag_slam/scan_matching.py:40-42, called once per incoming scan at /root/reference/yag_slam/graph_slam.py:326),
+ * item for item bit-identical to ym_match_scans(queries[i], chain i).  A query object may serve several items (it is projected,
+ * and its (beam, angle) pair lists are built, once per distinct object); ym_match_batch is the special case of ONE query.
+ * per_item receives n_items results.  ym_pairs_create gives the reusable form: the object is a ym_batch -- run it with
+ * ym_batch_run_async / ym_batch_wait (whose best / best_chain then name the item with the highest response), free it with
+ * ym_batch_destroy. */
+int ym_match_pairs(ym_matcher *m, const ym_scan *const *queries, const ym_scan *const *scans,
+                   const int32_t *chain_offsets, int n_items, int penalize, int refine, ym_result *per_item);
+ym_batch *ym_pairs_create(ym_matcher *m, const ym_scan *const *queries, const ym_scan *const *scans,
+                          const int32_t *chain_offsets, int n_items);
+
 /* ---- one match split over several matchers by coarse angle (BASELINE configs[4] on 8 GPUs: one matcher per GPU) ----
  * Every rank rasterises the same grid and scores the coarse angles [k_begin, k_end) only, writing their responses at
  * their place in the caller-owned device volume dev_resp[nt][ny][nx] (doubles) and the per-(x, y) maxima of its slices
@@ -294,7 +310,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * of polling the completion word; 24: 0 = the trigger chains of base scans are recomputed at every pose instead of taken
  * from the scan's creation-time structure; 25: tiles added around the raster rectangle a device-chained step predicts
  * (1; negative values make every chained step a fault); 26: 512 = the single-item prepare kernel with 512 threads per
- * scan; 28: batch size from which the LDS correlates replace the direct kernel (64; at least 8); 29: 0 = the region path's pair lists are built on the call's stream instead of next to the raster on the matcher's second stream; 31: 0 = a synchronous match waits for the creation launch of a just-created query scan instead of reading its staged readings; 30: rows per raster tile, 32 or 64, whatever the call (0 = the host's choice: 64 for 512+ items over windows of 768+ cells); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
+ * scan; 28: batch size from which BOTH LDS correlates replace the direct kernel (at least 8; 0 = the defaults again: gather correlate 64, region correlate 48); 42: the region correlate's threshold alone (0 = 48); 29: 0 = the region path's pair lists are built on the call's stream instead of next to the raster on the matcher's second stream; 31: 0 = a synchronous match waits for the creation launch of a just-created query scan instead of reading its staged readings; 30: rows per raster tile, 32 or 64, whatever the call (0 = the host's choice: 64 for 512+ items over windows of 768+ cells); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
  * (0: it scores them itself unless option 12 asks for the integer sums); 41: items up to which the order-dependent smear
  * rule runs in its split form (8; 0 = one block per item always). */
 int ym_debug_option(ym_matcher *m, int option, int value);

@@ -103,7 +103,8 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.path.join(_HERE, "libym_oracle.so")
+    # (YM_ORACLE_LIB: another build of the same file, e.g. the sanitizer build `make -C oracle asan`)
+    p = path or os.environ.get("YM_ORACLE_LIB") or os.path.join(_HERE, "libym_oracle.so")
     if not os.path.exists(p):
         build()
     lib = C.CDLL(p)

@@ -15,6 +15,22 @@ def _mk_native(plain):
                               plain.min_range, plain.max_range, plain.range_threshold, p.x, p.y, p.euler[-1])
 
 
+def _has_experimental_forms():
+    """The correlate forms that lost to correlate_region_kernel (debug option 32 = 2, 3, 4) are compiled only into builds made
+    with -DYM_EXPERIMENTAL; a default build refuses the option with YM_ERR_UNSUPPORTED and the tests leave those forms out."""
+    from yag_slam_amd import _capi
+    from yag_slam_amd.scan_matching import ScanMatcher
+    m = ScanMatcher()
+    try:
+        m.debug_option(32, 2)
+        return True
+    except _capi.YmError as e:
+        assert e.code == -4
+        return False
+    finally:
+        m.close()
+
+
 def compare(cfg, query, base, penalty, fine, loop=False, resident=True, check_grid=True):
     from oracle import oracle as orc
     from yag_slam_amd.scan_matching import ScanMatcher
@@ -1001,6 +1017,7 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
         m_ = _ScanMatcher(*args, **kw)
         m_.debug_option(28, 8)
         return m_
+    experimental = _has_experimental_forms()
     q, base = cfg2_scans()
     nq, nb = _mk_native(q), [_mk_native(b) for b in base]
     cut = lambda s, n: PlainScan(s.ranges[:n], s.min_angle, s.angle_increment, s.min_range, 20.0, (3.0, 3.0, 0.0))
@@ -1034,7 +1051,7 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             # the region correlate's other forms: wave-specialised (option 32 = 2: gather waves + loader waves, persistent blocks) and
             # one block per item with the item's sums in LDS (= 3: what large batches take), with the lists that fit and without
             # and the pooled form at two blocks per item (= 4: a region's patches dealt evenly over twelve waves, 16-bit sums in LDS)
-            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3), (4, 0), (4, 2), (4, 3)):
+            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3), (4, 0), (4, 2), (4, 3)) if experimental else ():
                 m = ScanMatcher(cfg)
                 m.debug_option(12, 1)
                 m.debug_option(32, form)
@@ -1048,6 +1065,8 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             # without the kept sums (the production form: the region correlate scores its sums itself; option 21 = 2 leaves
             # that to the score kernel), through either kernel
             for opts in ({}, {21: 2}, {14: 4}, {32: 2}, {32: 2, 21: 2}, {32: 3}, {32: 3, 21: 2}, {32: 3, 14: 2}, {32: 4}, {32: 4, 21: 2}, {32: 4, 14: 2}, {32: 4, 39: 1}):
+                if 32 in opts and not experimental:
+                    continue
                 m = ScanMatcher(cfg)
                 for k, v in opts.items():
                     m.debug_option(k, v)
@@ -1492,3 +1511,64 @@ def test_order_dependent_smear_random_chains(seed):
     chain[-1] = PlainScan(base[order[0]].ranges, base[order[0]].min_angle, base[order[0]].angle_increment, base[order[0]].min_range, 12.0,
                           (chain[0].corrected_pose.x, chain[0].corrected_pose.y, chain[0].corrected_pose.euler[-1]))
     compare(dict(resolution=0.005, smear_deviation=0.05, range_threshold=12.0, search_size=0.2), q, chain, True, True)
+
+
+def test_two_matchers_on_two_streams_with_pose_writes_between_their_enqueues():
+    """bench.py's lanes in small: two matchers, each on its own stream, enqueue resident batches alternately WITHOUT waiting for
+    each other; the batches share scan objects (one scan pool, one global pose epoch, a point cache per matcher) and poses are
+    written between the enqueues.  Every enqueue must give what a third matcher gives for the same batch at the pose state of
+    the moment it was enqueued, bit for bit."""
+    import torch
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    scene = synth.Scene()
+    q, _ = synth.single_match_scans(scene)
+    base_poses, _, _ = synth.single_match_poses()
+    exact = [scene.cast(*p) for p in base_poses]
+    chains = []
+    for c in range(96):
+        rng = np.random.default_rng(7000 + c)
+        chains.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
+    A, B = chains[:64], chains[32:]  # chains 32..63 belong to both batches
+    rounds = 4
+
+    def write(r, half):
+        # a base scan of a shared chain, the query, and a scan of a chain only the OTHER batch holds
+        for s, d in ((chains[40 + r][3], 0.004 * (r + 1)), (q, 0.002 * (r + 1)), (chains[70 + r if half == 0 else 5 + r][6], -0.003 * (r + 1))):
+            p = s.corrected_pose
+            s.corrected_pose = Transform(p.x + d, p.y - 0.5 * d, 0.0, p.euler[-1] + 0.1 * d)
+
+    def snapshot():
+        return [(s, s.corrected_pose) for ch in chains for s in ch] + [(q, q.corrected_pose)]
+    start = snapshot()
+    key = lambda per: [(p.response, tuple(map(tuple, p.covariance)), p.best_pose.x, p.best_pose.y, p.best_pose.euler[-1]) for p in per]
+    # pass 1: the reference, one synchronous matcher replaying the sequence of enqueues and writes
+    m0 = ScanMatcher()
+    want = []
+    for r in range(rounds):
+        want.append(key(m0.match_scan_batch(q, A, True, True)[0]))
+        write(r, 0)
+        want.append(key(m0.match_scan_batch(q, B, True, True)[0]))
+        write(r, 1)
+    for s, p in start:
+        s.corrected_pose = p
+    # pass 2: two lanes, nothing waits until everything is enqueued
+    m1, m2 = ScanMatcher(), ScanMatcher()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    m1.set_stream(s1.cuda_stream)
+    m2.set_stream(s2.cuda_stream)
+    b1, b2 = m1.make_batch(q, A), m2.make_batch(q, B)
+    for r in range(rounds):
+        b1.run_async(True, True, slot=r)
+        write(r, 0)
+        b2.run_async(True, True, slot=r)
+        write(r, 1)
+    got = []
+    for r in range(rounds):
+        got.append(key(b1.wait(r)[0]))
+        got.append(key(b2.wait(r)[0]))
+    torch.cuda.synchronize()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "enqueue %d (lane %d, round %d) differs from the single-matcher result" % (i, i % 2, i // 2)
+    assert want[0] != want[2]  # (the writes did change results: the test compares something)

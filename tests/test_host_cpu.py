@@ -462,3 +462,67 @@ def test_batch_results_is_a_lazy_sequence_over_the_records():
     with pytest.raises(IndexError):
         res[5]
     assert not BatchResults(a[:0]) and BatchResults(a[:0]).best() == -1
+
+
+def test_map_sequence_forgets_the_previous_calls_results_before_it_can_raise():
+    # ScanMatcher.map_sequence publishes the scans it matched in `sequence_done`, which SequentialMapper.process_scans reads in
+    # its except branch.  A call that raises BEFORE it reaches the library (a scan that is not resident, no odom_pose) must not
+    # leave the previous call's list there: the mapper would commit those results again and take unmatched scans into its
+    # running chain (round-4 advisor finding).
+    import pytest
+    from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.models import LocalizedRangeScan
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    m = ScanMatcher.__new__(ScanMatcher)  # (no device here: the call below fails before it needs one)
+    m.device, m._m, m._lib = 0, None, None
+    m.sequence_done = ["a result of the previous call"]
+    with pytest.raises(TypeError):
+        m.map_sequence([object(), object()], 1, 10)
+    assert m.sequence_done == []
+    # ... and the mapper on top of it: state unchanged by the failed call
+    stale = ["stale-1", "stale-2"]
+
+    class Seq:
+        sequence_done = stale
+        def match_scan(self, q, base, pen, fine):
+            raise AssertionError("not reached")
+        def map_sequence(self, seq, start, buffer_len, pen, fine, device_chain):
+            return ScanMatcher.map_sequence(m, [object()] * len(seq), start, buffer_len, pen, fine, device_chain)
+
+    def scan(i):
+        s = LocalizedRangeScan([1.0] * 5, -1, 1, 0.5, 0, 10, 5, 0, 0, 0)
+        s.odom_pose = Transform(0.1 * i, 0.0, 0, 0.0)
+        return s
+    seqm = Seq()
+    seqm.sequence_done = m.sequence_done  # (what the real matcher's attribute would be)
+    mp = SequentialMapper(seqm, scan_buffer_len=4)
+    mp.running_scans = [scan(0), scan(1)]
+    before = list(mp.running_scans)
+    with pytest.raises(TypeError):
+        mp.process_scans([scan(2), scan(3), scan(4)])
+    assert mp.running_scans == before and mp.results == []
+
+
+def test_oracle_under_sanitizers():
+    # SURVEY section 5 proposes a sanitizer pass for the CPU side: the oracle built with -fsanitize=address,undefined
+    # (`make -C oracle asan`) runs the reference's golden vectors (tests/test_oracle_golden.py) in a child process with the
+    # sanitizer runtime preloaded; any report aborts the child (-fno-sanitize-recover, ASan's default abort on error).
+    import os
+    import shutil
+    import subprocess
+    import sys
+    import pytest
+    from tests.util import REPO
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("gcc has no libasan here")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "asan"])
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1",
+               YM_ORACLE_LIB=os.path.join(REPO, "oracle", "_asan", "libym_oracle.so"))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_oracle_golden.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr

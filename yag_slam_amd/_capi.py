@@ -18,6 +18,7 @@ EXPORTS = (
     "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scans_set_poses", "ym_scan_get_pose",
     "ym_scan_size", "ym_scan_structure_trusted", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_map_sequence", "ym_process_scan", "ym_sequence_stats", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
+    "ym_match_pairs", "ym_pairs_create",
     "ym_batch_run_async", "ym_batch_wait", "ym_debug_grid_info",
     "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_option", "ym_debug_stamps",
     "ym_profile_enable",
@@ -163,6 +164,9 @@ def lib():
                                  C.POINTER(YmResult), ip]
     L.ym_batch_create.restype = vp
     L.ym_batch_create.argtypes = [vp, vp, C.POINTER(vp), ip, C.c_int]
+    L.ym_pairs_create.restype = vp
+    L.ym_pairs_create.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), ip, C.c_int]
+    L.ym_match_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), ip, C.c_int, C.c_int, C.c_int, C.POINTER(YmResult)]
     L.ym_batch_destroy.argtypes = [vp]
     L.ym_batch_destroy.restype = None
     L.ym_batch_size.argtypes = [vp]

@@ -480,11 +480,12 @@ struct ym_occupancy {
 };
 
 struct ym_batch {
-    const ym_scan *query;
+    std::vector<const ym_scan *> queries; // the distinct query scans (one for ym_batch_create; ym_pairs_create: up to one per item)
+    std::vector<int32_t> item_query;      // per item: its query's index in `queries`
     std::vector<const ym_scan *> scans;
     std::vector<int32_t> offsets;
     mutable std::vector<int> cache_hints; // per scan: its entry in the owning matcher's point cache (validated on use)
-    mutable int query_hint = -1;
+    mutable std::vector<int> query_hints; // the same per query
     uint64_t uid = 0; // unique per created batch
 };
 
@@ -746,7 +747,10 @@ int upload_lut(ym_matcher *m) {
     m->z2max = 0;
     for (int i = 0; i < n; i++)
         if (lut[i] == YM_OCCUPIED) m->z2max = i;
-    if (m->z2max > 2) return set_err(YM_ERR_UNSUPPORTED, "smear kernel holds 100 out to squared distance %d", m->z2max);
+    // (smear_deviation <= 10 * resolution, the reference's own assertion checked above, keeps the kernel below 100 from squared
+    //  distance 2 on: 100 * exp(-0.5 * 2 / 100) rounds to 99.  The nine-neighbour form of the select rule is therefore never
+    //  needed and no longer instantiated -- select_kernel<9> spilled 240 bytes per lane.)
+    if (m->z2max > 1) return set_err(YM_ERR_UNSUPPORTED, "smear kernel holds 100 out to squared distance %d", m->z2max);
     std::vector<uint8_t> q(n + 8, 0);
     for (int i = 0; i < n; i++) {
         if (lut[i] < 0) { q[i] = (uint8_t)prev; continue; } // unreachable distance: never looked up
@@ -1565,7 +1569,7 @@ int enqueue_select(ym_matcher *m, const CallPlan &P) {
                        m->cfg.smear_deviation / m->cfg.resolution);
     if (log2cap > 14 || m->select_global) { // too long for one CU's LDS: the same rule with its tables in global memory
         const size_t cap = (size_t)1 << log2cap;
-        const int nb = m->z2max <= 1 ? 5 : 9;
+        const int nb = 5; // (z2max <= 1 always: build_geometry)
         int rc = m->sel_scratch.ensure((size_t)P.B * cap * (3 + (nb - 1)));
         if (rc) return rc;
         ym::SelectGlobalArgs g;
@@ -1574,8 +1578,7 @@ int enqueue_select(ym_matcher *m, const CallPlan &P) {
         HIP_TRY(hipMemsetAsync(g.keys, 0, (size_t)2 * P.B * cap * sizeof(unsigned), m->stream));
         HIP_TRY(hipMemsetAsync(g.minidx, 0xff, (size_t)P.B * cap * sizeof(unsigned), m->stream));
         const size_t lds = cap; // one byte per slot: the threads' lists of undecided slots
-        if (nb == 5) hipLaunchKernelGGL(ym::select_global_kernel<5>, dim3(P.B), dim3(1024), lds, m->stream, g);
-        else hipLaunchKernelGGL(ym::select_global_kernel<9>, dim3(P.B), dim3(1024), lds, m->stream, g);
+        hipLaunchKernelGGL(ym::select_global_kernel<5>, dim3(P.B), dim3(1024), lds, m->stream, g);
         return YM_OK;
     }
     if (m->z2max <= 1 && P.B <= m->select_split_max) {
@@ -1600,8 +1603,7 @@ int enqueue_select(ym_matcher *m, const CallPlan &P) {
     ym::SelectArgs a;
     a.cells = m->cells.p; a.max_n = P.max_n; a.max_base = P.max_base; a.z2max = m->z2max; a.log2cap = log2cap; a.stamps = P.stamps;
     const size_t lds = (size_t)9 << log2cap;
-    if (m->z2max <= 1) hipLaunchKernelGGL(ym::select_kernel<5>, dim3(P.B), dim3(1024), lds, m->stream, a);
-    else hipLaunchKernelGGL(ym::select_kernel<9>, dim3(P.B), dim3(1024), lds, m->stream, a);
+    hipLaunchKernelGGL(ym::select_kernel<5>, dim3(P.B), dim3(1024), lds, m->stream, a);
     return YM_OK;
 }
 
@@ -1715,7 +1717,9 @@ int enqueue_region_lists(ym_matcher *m, const CallPlan &P, hipStream_t st) {
         m->bin_lds_limit = bin_lds;
     }
     hipLaunchKernelGGL(ym::bin_kernel, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
+#ifdef YM_EXPERIMENTAL
     if (P.rg_ws) hipLaunchKernelGGL(ym::region_walk_kernel, dim3(P.rg_parts, P.n_qslots), dim3(64), 0, st, r);
+#endif
     return YM_OK;
 }
 
@@ -1756,6 +1760,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         else if ((rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts * P.rg_rsplit, P.B);
+#ifdef YM_EXPERIMENTAL // (the three forms that lost to correlate_region_kernel: profiles/r04_region_study.md; option 32 refuses them otherwise)
         if (P.rg_item) {
             const size_t lds = YM_IT_ACC_BYTES(P.lc.nt);
             if (!m->item_lds_set) {
@@ -1775,6 +1780,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
             hipLaunchKernelGGL(ym::region_percell_kernel, rgrid, dim3(64 * YM_WS_NG), 0, st, r);
             return prof_end(m, ev_k);
         }
+#endif
         switch (P.rg_nw) {
         case 4: hipLaunchKernelGGL(ym::correlate_region_kernel<4>, rgrid, dim3(256), 0, st, r); break;
         case 5: hipLaunchKernelGGL(ym::correlate_region_kernel<5>, rgrid, dim3(320), 0, st, r); break;
@@ -2326,10 +2332,8 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
     m->stream = m->own_stream;
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_relax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_global_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ym::prepare_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2791,24 +2795,53 @@ int ym_wait(ym_matcher *m, int slot_idx, ym_result *out) {
     return YM_OK;
 }
 
-ym_batch *ym_batch_create(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
-                          int n_chains) {
-    if (!m || !query || !chain_offsets) { set_err(YM_ERR_INVALID, "null argument"); return nullptr; }
+// items of a batch: item c = queries[item_query[c]] against scans[chain_offsets[c] .. chain_offsets[c + 1])
+static ym_batch *batch_new(ym_matcher *m, const ym_scan *const *queries, int n_queries, bool per_item, const ym_scan *const *scans,
+                           const int32_t *chain_offsets, int n_chains) {
+    if (!m || !queries || !chain_offsets) { set_err(YM_ERR_INVALID, "null argument"); return nullptr; }
     if (n_chains <= 0) { set_err(YM_ERR_INVALID, "n_chains must be > 0"); return nullptr; }
     const int n_scans = chain_offsets[n_chains];
     if (chain_offsets[0] != 0 || n_scans < 0 || (n_scans > 0 && !scans)) { set_err(YM_ERR_INVALID, "bad scan list"); return nullptr; }
     for (int c = 0; c < n_chains; c++)
         if (chain_offsets[c + 1] < chain_offsets[c]) { set_err(YM_ERR_INVALID, "chain_offsets must be non-decreasing"); return nullptr; }
-    if (query->device != m->device) { set_err(YM_ERR_INVALID, "query scan lives on another device"); return nullptr; }
+    for (int i = 0; i < n_queries; i++) {
+        if (!queries[i]) { set_err(YM_ERR_INVALID, "query %d is null", i); return nullptr; }
+        if (queries[i]->device != m->device) { set_err(YM_ERR_INVALID, "query scan %d lives on another device", i); return nullptr; }
+    }
     for (int i = 0; i < n_scans; i++)
         if (!scans[i] || scans[i]->device != m->device) { set_err(YM_ERR_INVALID, "scan %d is null or lives on another device", i); return nullptr; }
     static std::atomic<uint64_t> next_uid{1};
     ym_batch *b = new ym_batch();
     b->uid = next_uid.fetch_add(1);
-    b->query = query;
+    b->item_query.resize(n_chains, 0);
+    if (per_item) { // a query object that serves several items is projected, and its pair lists are built, once
+        std::unordered_map<const ym_scan *, int32_t> seen;
+        for (int c = 0; c < n_chains; c++) {
+            auto it = seen.find(queries[c]);
+            if (it == seen.end()) {
+                it = seen.emplace(queries[c], (int32_t)b->queries.size()).first;
+                b->queries.push_back(queries[c]);
+            }
+            b->item_query[c] = it->second;
+        }
+    } else {
+        b->queries.push_back(queries[0]);
+    }
+    b->query_hints.assign(b->queries.size(), -1);
     b->scans.assign(scans, scans + n_scans);
     b->offsets.assign(chain_offsets, chain_offsets + n_chains + 1);
     return b;
+}
+
+ym_batch *ym_batch_create(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
+                          int n_chains) {
+    if (!query) { set_err(YM_ERR_INVALID, "null argument"); return nullptr; }
+    return batch_new(m, &query, 1, false, scans, chain_offsets, n_chains);
+}
+
+ym_batch *ym_pairs_create(ym_matcher *m, const ym_scan *const *queries, const ym_scan *const *scans, const int32_t *chain_offsets,
+                          int n_items) {
+    return batch_new(m, queries, n_items, true, scans, chain_offsets, n_items);
 }
 
 void ym_batch_destroy(ym_batch *b) { delete b; }
@@ -2826,15 +2859,15 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     const uint64_t epoch = g_pose_epoch.load(std::memory_order_relaxed);
     // the slot still holds this batch's Call and no scan anywhere has moved since it was built: nothing to rebuild
     // (40 961 scattered ym_scan objects are not even looked at; 1.7 ms per enqueue of 4096 chains otherwise)
-    const bool same = call.batch_uid == b->uid && call.pose_epoch == epoch && call.scans.size() == 1 + (size_t)n_scans &&
+    const int nq = (int)b->queries.size();
+    const bool same = call.batch_uid == b->uid && call.pose_epoch == epoch && call.scans.size() == (size_t)nq + (size_t)n_scans &&
                       call.penalize == (penalize ? 1 : 0) && call.refine == (refine ? 1 : 0) && !call.slice && !call.chain_step;
     int rc;
     if (!same) {
         call = Call();
-        call.scans.resize(1 + (size_t)n_scans);
-        if ((rc = scan_to_call(b->query, m->cfg.semantics, &call.scans[0]))) return rc;
+        call.scans.resize((size_t)nq + (size_t)n_scans);
         b->cache_hints.resize(n_scans, -1);
-        call.scans[0].qcache_hint = b->query_hint;
+        b->query_hints.resize(nq, -1);
         // (40 960 scattered ym_scan objects: ask for the ones ahead while this one is copied -- the loop was 3.3 ms of cache misses)
         auto touch = [](const ym_scan *s) {
             if (!s) return;
@@ -2848,17 +2881,22 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
             for (int i = lo; i < hi && i < lo + 16; i++) touch(b->scans[i]);
             for (int i = lo; i < hi; i++) {
                 if (i + 16 < hi) touch(b->scans[i + 16]);
-                const int r_ = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[1 + i]);
+                const int r_ = scan_to_call(b->scans[i], m->cfg.semantics, &call.scans[nq + i]);
                 if (r_) return r_;
-                call.scans[1 + i].cache_hint = b->cache_hints[i];
+                call.scans[nq + i].cache_hint = b->cache_hints[i];
             }
             return YM_OK;
         };
+        for (int i = 0; i < nq; i++) {
+            if (i + 8 < nq) touch(b->queries[i + 8]);
+            if ((rc = scan_to_call(b->queries[i], m->cfg.semantics, &call.scans[i]))) return rc;
+            call.scans[i].qcache_hint = b->query_hints[i];
+        }
         // (tried: four threads, a quarter each -- 3.9 -> 4.4 ms, and the caller's next ym_scans_set_poses 0.75 -> 2.7 ms: the
         //  scans' cache lines then live in other cores' caches)
         if ((rc = fill(0, n_scans))) return rc;
         call.items.resize(n_chains);
-        for (int c = 0; c < n_chains; c++) call.items[c] = CallItem{0, 1 + b->offsets[c], b->offsets[c + 1] - b->offsets[c]};
+        for (int c = 0; c < n_chains; c++) call.items[c] = CallItem{b->item_query[c], nq + b->offsets[c], b->offsets[c + 1] - b->offsets[c]};
         call.penalize = penalize ? 1 : 0;
         call.refine = refine ? 1 : 0;
         call.batch_uid = b->uid;
@@ -2871,8 +2909,8 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
     rc = launch_call(m, slot);
     slot.dev_best_out = nullptr; // a response-expansion re-run must not overwrite the caller's buffer
     if (!same) {
-        for (int i = 0; i < n_scans; i++) b->cache_hints[i] = call.scans[1 + i].cache_hint;
-        b->query_hint = call.scans[0].qcache_hint;
+        for (int i = 0; i < n_scans; i++) b->cache_hints[i] = call.scans[nq + i].cache_hint;
+        for (int i = 0; i < nq; i++) b->query_hints[i] = call.scans[i].qcache_hint;
     }
     return rc;
 }
@@ -2894,9 +2932,7 @@ int ym_batch_wait(ym_matcher *m, int slot_idx, ym_result *per_chain, ym_result *
     return YM_OK;
 }
 
-int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
-                   int n_chains, int penalize, int refine, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
-    ym_batch *b = ym_batch_create(m, query, scans, chain_offsets, n_chains);
+static int batch_run_once(ym_matcher *m, ym_batch *b, int penalize, int refine, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
     if (!b) return YM_ERR_INVALID;
     // use the last async slot that is free
     int slot_idx = -1;
@@ -2907,6 +2943,16 @@ int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *sc
     if (rc == YM_OK) rc = ym_batch_wait(m, slot_idx, per_chain, best, best_chain);
     ym_batch_destroy(b);
     return rc;
+}
+
+int ym_match_batch(ym_matcher *m, const ym_scan *query, const ym_scan *const *scans, const int32_t *chain_offsets,
+                   int n_chains, int penalize, int refine, ym_result *per_chain, ym_result *best, int32_t *best_chain) {
+    return batch_run_once(m, ym_batch_create(m, query, scans, chain_offsets, n_chains), penalize, refine, per_chain, best, best_chain);
+}
+
+int ym_match_pairs(ym_matcher *m, const ym_scan *const *queries, const ym_scan *const *scans, const int32_t *chain_offsets,
+                   int n_items, int penalize, int refine, ym_result *per_item) {
+    return batch_run_once(m, ym_pairs_create(m, queries, scans, chain_offsets, n_items), penalize, refine, per_item, nullptr, nullptr);
 }
 
 // ---- one match split by coarse angle over several matchers (one per GPU): BASELINE configs[4] on 8 GPUs
@@ -3350,17 +3396,31 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 24) m->use_scan_structure = value != 0;
     else if (option == 25) m->chain_margin = value;
     else if (option == 26) m->prepare_threads = value;
-    else if (option == 28) m->lds_min_batch = m->rg_min_batch = std::max(8, value);
+    else if (option == 28) { // both LDS correlates from `value` items on (at least 8); 0 = the defaults again (gather 64, region 48)
+        if (value == 0) { m->lds_min_batch = 64; m->rg_min_batch = 48; }
+        else m->lds_min_batch = m->rg_min_batch = std::max(8, value);
+    }
+    else if (option == 42) m->rg_min_batch = value == 0 ? 48 : std::max(8, value); // the region correlate's threshold alone
     else if (option == 29) m->overlap_lists = value != 0;
     else if (option == 31) m->staged_queries = value != 0;
     else if (option == 30) m->tile_h_forced = value == YM_TILE_H || value == YM_TILE_H_TALL ? value : 0;
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
-    else if (option == 32) m->corr_region_form = value;
+    else if (option == 32) {
+#ifndef YM_EXPERIMENTAL
+        if (value >= 2) return set_err(YM_ERR_UNSUPPORTED, "correlate form %d is compiled only into builds made with -DYM_EXPERIMENTAL", value);
+#endif
+        m->corr_region_form = value;
+    }
     else if (option == 33) m->corr_region_dbg = value;
     else if (option == 34) m->corr_region_rsplit = value;
-    else if (option == 35) m->item_min_batch = value;
+    else if (option == 35) {
+#ifndef YM_EXPERIMENTAL
+        return set_err(YM_ERR_UNSUPPORTED, "correlate_item_kernel is compiled only into builds made with -DYM_EXPERIMENTAL");
+#endif
+        m->item_min_batch = value;
+    }
     else if (option == 36) m->raster_planes_only = value;
     else if (option == 37) m->raster_no_rowtab = value;
     else if (option == 38) m->corr_region_pad_lds = value;

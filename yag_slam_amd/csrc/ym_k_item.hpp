@@ -34,6 +34,7 @@ namespace ym {
 #define YM_IT_ACC_BYTES(nt) ((size_t)(nt) * YM_IT_KSTRIDE * 4)
 #define YM_IT_MAX_NT 31                      // 31 x 3328 B of sums + the static 55 KB stay below 160 KB
 
+#ifdef YM_EXPERIMENTAL // (both forms measured slower than correlate_region_kernel: compiled only with -DYM_EXPERIMENTAL, debug option 32 = 3 / 4)
 // grid (B), 1024 threads, dynamic LDS = YM_IT_ACC_BYTES(nt)
 __global__ __launch_bounds__(64 * YM_IT_NW, 4) void correlate_item_kernel(RegionArgs a) {
     constexpr int NW = YM_IT_NW, NT = 64 * NW;
@@ -329,9 +330,11 @@ __global__ __launch_bounds__(64 * YM_IT_NW, 4) void correlate_item_kernel(Region
 //     set m exactly when the count passes 652 (m + 1) -- a bin that straddles such a boundary is gathered in two SUB-ROUNDS with the
 //     flush between them (a barrier each side; ~one per angle and item) -- so the sets are the region correlate's sets;
 //   * the block scores its angles from LDS (+ the sets it wrote), wave w the angles w, w + 12, ...
+#endif // YM_EXPERIMENTAL
 #define YM_PL_NW 12
 #define YM_PL_MAX_NK 11
 #define YM_PL_MAXE 2048
+#ifdef YM_EXPERIMENTAL
 template <bool WIN>
 __global__ __launch_bounds__(64 * YM_PL_NW, 6 /* two blocks = 24 waves per CU: 80 VGPRs */) void correlate_pool_kernel(RegionArgs a) {
     constexpr int NW = YM_PL_NW, NT = 64 * NW;
@@ -663,5 +666,7 @@ __global__ __launch_bounds__(64 * YM_PL_NW, 6 /* two blocks = 24 waves per CU: 8
     for (int i = tid; i < nxy; i += NT)
         if (pmax[i]) atomicMax(reinterpret_cast<unsigned long long *>(a.probs) + (size_t)b * a.probs_stride + i, pmax[i]);
 }
+
+#endif // YM_EXPERIMENTAL
 
 } // namespace ym

@@ -745,6 +745,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
 #define YM_WS_WALK_WORDS (16 + (2 + YM_WS_NG) * YM_RG_MAX_REGIONS)
 static_assert(YM_WS_ZERO + YM_WS_ZERO_BYTES < 65536, "entries are 16-bit LDS offsets");
 
+#ifdef YM_EXPERIMENTAL // (measured slower than correlate_region_kernel: compiled only into builds made with -DYM_EXPERIMENTAL, debug option 32 = 2)
 // grid (parts, Q), one wave: the walk of angle block p of query slot q
 __global__ __launch_bounds__(64) void region_walk_kernel(RegionArgs a) {
     __shared__ int rl[YM_RG_MAX_REGIONS];
@@ -1018,5 +1019,7 @@ __global__ __launch_bounds__(64 * (YM_WS_NG + YM_WS_NL), 8 /* two blocks of 16 w
         while (flushed < ng) flush(); // the set being filled, then empty ones
     }
 }
+
+#endif // YM_EXPERIMENTAL
 
 } // namespace ym

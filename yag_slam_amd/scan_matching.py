@@ -133,9 +133,15 @@ class ScanMatcher(object):
         self._m = self._lib.ym_create(C.byref(self._cfg), self.device)
         if not self._m:
             raise _capi.YmError(-1, _capi.last_error())
-        for kv in filter(None, os.environ.get("YM_DEBUG_OPTIONS", "").split(",")):  # development: "32=1,33=2" -> ym_debug_option
-            k, v = kv.split("=")
-            self.debug_option(int(k), int(v))
+        # development only, and only on request: YM_DEVELOPMENT=1 YM_DEBUG_OPTIONS="32=1,33=2" -> ym_debug_option on every
+        # matcher of the process.  Without YM_DEVELOPMENT an inherited YM_DEBUG_OPTIONS changes nothing in a library user.
+        if os.environ.get("YM_DEVELOPMENT") == "1":
+            for kv in filter(None, (t.strip() for t in os.environ.get("YM_DEBUG_OPTIONS", "").split(","))):
+                try:
+                    k, v = (int(t) for t in kv.split("="))
+                except ValueError:
+                    raise ValueError("YM_DEBUG_OPTIONS: cannot read %r (expected option=value, both integers)" % kv)
+                self.debug_option(k, v)
 
     def close(self):
         if getattr(self, "_m", None):
@@ -195,6 +201,7 @@ class ScanMatcher(object):
         device_chain: no host round trip between the steps either (the device hands each step's pose to the next;
         include/yagmatch.h) -- the priors are then composed with the device's cos / sin, so poses agree with the
         step-by-step form to rounding, not bit for bit."""
+        self.sequence_done = []  # (before anything can raise: a caller's except branch must not see the previous call's results)
         n = len(scans)
         handles = (C.c_void_p * max(1, n))(*[self._require_native(s) for s in scans])
         odom = np.empty((max(1, n), 3), dtype=np.float64)
@@ -277,6 +284,29 @@ class ScanMatcher(object):
     def make_batch(self, query, chains):
         """Reusable (query, chains) batch for the pipelined loop-closure path."""
         return MatchBatch(self, query, chains)
+
+    def match_pairs(self, queries, chains, penalty=True, do_fine=False):
+        """len(queries) INDEPENDENT matches in one enqueue: item i = `match_scan(queries[i], chains[i], penalty, do_fine)`
+        (N x /root/reference/yag_slam/graph_slam.py:326 -- N robots, or N segments of a log replayed side by side), item for
+        item bit-identical to the single calls.  Returns the per-item results (BatchResults)."""
+        if len(queries) != len(chains):
+            raise ValueError("match_pairs needs one chain per query (%d queries, %d chains)" % (len(queries), len(chains)))
+        if not queries:
+            return BatchResults(np.zeros(0, dtype=_RESULT_DTYPE))
+        flat, offs = [], [0]
+        for ch in chains:
+            flat.extend(ch)
+            offs.append(len(flat))
+        hq = (C.c_void_p * len(queries))(*self._handles(queries))
+        hs = (C.c_void_p * max(1, len(flat)))(*self._handles(flat))
+        co = (C.c_int32 * len(offs))(*offs)
+        per = (_capi.YmResult * len(chains))()
+        _capi.check(self._lib.ym_match_pairs(self._m, hq, hs, co, len(chains), int(bool(penalty)), int(bool(do_fine)), per))
+        return _results(per, check=True)
+
+    def make_pairs_batch(self, queries, chains):
+        """Reusable form of `match_pairs` (resident on the device, runnable many times; poses are read at every run)."""
+        return MatchBatch(self, queries, chains, pairs=True)
 
     def _handles(self, scans):
         """ym_scan* of every scan; the twins that already live on this device are taken without a call"""
@@ -478,19 +508,27 @@ class MatchBatch(object):
     Replaces the serial `for chain in chains: loop_matcher.match_scan(scan, chain, False, False)` of
     /root/reference/yag_slam/graph_slam.py:217-220 by one enqueue per batch."""
 
-    def __init__(self, matcher, query, chains):
+    def __init__(self, matcher, query, chains, pairs=False):
+        """pairs: `query` is a sequence of queries, item i = query[i] against chains[i] (ScanMatcher.make_pairs_batch)"""
         self.m = matcher
         self.query = query
         self.chains = [list(c) for c in chains]
+        self._queries = list(query) if pairs else [query]
+        if pairs and len(self._queries) != len(self.chains):
+            raise ValueError("a pairs batch needs one chain per query")
         flat, offs = [], [0]
         for ch in self.chains:
             flat.extend(ch)
             offs.append(len(flat))
         self._flat = flat
-        hq = matcher._require_native(query)
         hs = (C.c_void_p * max(1, len(flat)))(*matcher._handles(flat))
         co = (C.c_int32 * len(offs))(*offs)
-        self._h = matcher._lib.ym_batch_create(matcher._m, hq, hs, co, len(self.chains))
+        if pairs:
+            hq = (C.c_void_p * max(1, len(self._queries)))(*matcher._handles(self._queries))
+            self._h = matcher._lib.ym_pairs_create(matcher._m, hq, hs, co, len(self.chains))
+        else:
+            hq = matcher._require_native(query)
+            self._h = matcher._lib.ym_batch_create(matcher._m, hq, hs, co, len(self.chains))
         if not self._h:
             raise _capi.YmError(-1, _capi.last_error())
         self.n = len(self.chains)
@@ -505,7 +543,7 @@ class MatchBatch(object):
 
     def push_poses(self):
         """Write the scans' current corrected poses through to their device twins."""
-        scans = [self.query] + self._flat
+        scans = self._queries + self._flat
         hs = self.m._handles(scans)
         xyz = np.array([_pose_of(s) for s in scans], dtype=np.float64).reshape(len(scans), 3)
         _capi.check(self.m._lib.ym_scans_set_poses((C.c_void_p * len(hs))(*hs), xyz.ctypes.data_as(C.POINTER(C.c_double)), len(hs)))
