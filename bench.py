@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--only", default="", help="comma list of {cfg2x,single,cfg3,cfg4,cfg5,cpu}: run only these legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-distinct-queries", action="store_true", help="skip the cfg2x_distinct_queries leg (one query per item)")
+    ap.add_argument("--only-headline", action="store_true", help="profiling runs: do not time the other form of the cfg2x workload")
     ap.add_argument("--headline", default="one_query", choices=("one_query", "distinct_queries"),
                     help="which cfg2x workload the metric line times: every item against the SAME query object, or every item with its own query")
     ap.add_argument("--no-production-legs", action="store_true",
@@ -193,66 +194,50 @@ def cpu_baseline(seconds=6.0):
 
 
 def physical_cores():
-    """(physical cores, logical cpus) this process may run on: distinct (package, core) pairs of the cpus in its affinity mask"""
+    """(physical cores, logical cpus, one cpu of every core) this process may run on: distinct (package, core) pairs of the cpus in
+    its affinity mask"""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
         allowed = list(range(os.cpu_count() or 1))
-    cores = set()
+    cores = {}
     for c in allowed:
         try:
             base = "/sys/devices/system/cpu/cpu%d/topology/" % c
-            cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+            key = (open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip())
         except OSError:
-            cores.add(("?", str(c)))
-    return len(cores), len(allowed)
+            key = ("?", str(c))
+        cores.setdefault(key, c)
+    return len(cores), len(allowed), sorted(cores.values())
 
 
 def cpu_throughput(seconds=6.0):
     """The CPU figure that belongs beside a GPU THROUGHPUT: independent cfg2 matches on every physical core of the host at once,
-    one oracle context (own grid, one thread) per core -- what a host-side farm of Karto matchers would do with the same
-    workload.  Python threads: the C call releases the GIL and lasts milliseconds."""
-    import threading
-    from oracle import oracle as orc
+    one oracle context (own correlation grid, one thread) per core, each thread pinned to its core -- what a host-side farm of
+    Karto matchers would do with the same workload.  A C driver (oracle/ym_throughput.c, built here with -march=native): no
+    Python in the loop."""
+    import tempfile
     from tests.util import cfg2_scans
-    try:
-        lib = orc.load(orc.build(native=True))
-    except Exception:
-        lib = orc.load()
+    from yag_slam_amd.config import default_config
+    oracle_dir = os.path.join(REPO, "oracle")
+    subprocess.check_call(["make", "-s", "-B", "-C", oracle_dir, "throughput", "ARCH=native"])  # (-B: never a binary built on another host)
     q, base = cfg2_scans()
-    phys, logical = physical_cores()
-    workers = []
-    for _ in range(phys):
-        o = orc.Oracle(None, "karto", threads=1, lib=lib)
-        qs, keep = orc.scan_from(q)
-        bs = [orc.scan_from(b) for b in base]
-        workers.append((o, qs, [b[0] for b in bs], keep, bs))
-    hyp = workers[0][0].match_raw(workers[0][1], workers[0][2], True, True).hypotheses
-    counts = [0] * phys
-    go = threading.Event()
-    deadline = [0.0]
-
-    def run(i):
-        o, qs, arr = workers[i][:3]
-        o.match_raw(qs, arr, True, True)  # (first touch of the context's grid on the core's memory)
-        go.wait()
-        while time.perf_counter() < deadline[0]:
-            o.match_raw(qs, arr, True, True)
-            counts[i] += 1
-
-    ts = [threading.Thread(target=run, args=(i,)) for i in range(phys)]
-    for t in ts:
-        t.start()
-    time.sleep(0.5)
-    t0 = time.perf_counter()
-    deadline[0] = t0 + seconds
-    go.set()
-    for t in ts:
-        t.join()
-    dt = time.perf_counter() - t0
-    n = sum(counts)
-    return dict(hyp_per_s=n * hyp / dt, matches=n, seconds=dt, cores=phys, logical_cpus=logical, matches_per_s=n / dt,
-                ms_per_match_per_core=dt / max(1, n) * phys * 1e3)
+    c = default_config
+    head = [c["angle_variance_penalty"], c["distance_variance_penalty"], c["coarse_search_angle_offset"], c["coarse_angle_resolution"],
+            c["fine_search_angle_resolution"], float(bool(c["use_response_expansion"])), c["range_threshold"], c["minimum_angle_penalty"],
+            0.5, c["search_size"], c["resolution"], c["smear_deviation"], float(len(base)), float(len(q.ranges)),
+            q.min_angle, q.angle_increment, q.min_range, q.range_threshold]
+    rows = [np.concatenate([[s.corrected_pose.x, s.corrected_pose.y, s.corrected_pose.euler[-1]], s.ranges]) for s in [q] + list(base)]
+    phys, logical, cpus = physical_cores()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "cfg2.bin")
+        np.concatenate([np.array(head, dtype=np.float64)] + rows).astype(np.float64).tofile(path)
+        p = subprocess.run([os.path.join(oracle_dir, "_native", "ym_throughput"), path, str(seconds), ",".join(str(c_) for c_ in cpus)],
+                           capture_output=True, text=True, check=True)
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    n, dt, hyp = r["matches"], r["seconds"], r["hypotheses_per_match"]
+    return dict(hyp_per_s=n * hyp / dt, matches=n, seconds=dt, cores=r["threads"], logical_cpus=logical, matches_per_s=n / dt,
+                ms_per_match_per_core=dt / max(1, n) * r["threads"] * 1e3, min_max_matches_per_thread=[r["min_matches_per_thread"], r["max_matches_per_thread"]])
 
 
 # ------------------------------------------------------------------------------------------------ inputs
@@ -751,7 +736,7 @@ def main():
             "collective": "all_gather of %d 64-byte best records per rank per step" % E if dist is not None else "none",
         }
         # the other form of the workload, same lanes, same step function, fewer steps
-        if pbatches is not None:
+        if pbatches is not None and not args.only_headline:
             ob = batches if headline_distinct else pbatches
             odt, oper = timed_steps(ob, max(4, args.steps // 2), 2)
             osteps = max(4, args.steps // 2)
@@ -951,9 +936,10 @@ def main():
             # what belongs beside a GPU THROUGHPUT figure: independent matches on every physical core at once
             "throughput": {"value": ct["hyp_per_s"], "unit": "hypotheses/s", "cores": ct["cores"], "scan_matches_per_s": ct["matches_per_s"],
                            "ms_per_match_per_core": ct["ms_per_match_per_core"],
-                           "sample": "%d independent cfg2 matches (coarse+fine, penalty) in %.1f s on %d threads, one per physical core, each with "
-                                     "its own oracle context (own correlation grid, one thread), oracle/ym_oracle.c karto semantics, -O3 "
-                                     "-march=native" % (ct["matches"], ct["seconds"], ct["cores"])},
+                           "matches_per_thread_min_max": ct["min_max_matches_per_thread"],
+                           "sample": "%d independent cfg2 matches (coarse+fine, penalty) in %.1f s on %d pinned threads, one per physical core, each "
+                                     "with its own oracle context (own correlation grid, one thread), oracle/ym_throughput.c + ym_oracle.c karto "
+                                     "semantics, -O3 -march=native" % (ct["matches"], ct["seconds"], ct["cores"])},
             "all_cores": {"value": cb["all"]["hyp_per_s"], "cores": cb["all"]["threads"],
                           "serial_fraction": cb["all"]["serial_fraction"],
                           "sample": "%d matches in %.1f s, OpenMP over the coarse lattice; grid clear and rasterisation "

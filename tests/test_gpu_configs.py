@@ -379,12 +379,16 @@ def test_cfg2_batch_512_distinct_chains_region_correlate_against_direct_and_orac
     m = ScanMatcher()
     per, best = m.match_scan_batch(q, chains, True, True)
     assert len(per) == n_chains and all(tuple(p.meta["coarse_dims"]) == (26, 26, 21) for p in per)
-    for opt, mode in ((14, 1), (14, 4), (32, 2), (32, 3)):  # the direct kernel; the general gather correlate; the region correlate's wave-specialised and one-block-per-item forms
+    # the direct kernel; the general gather correlate; the region correlate's wave-specialised and one-block-per-item forms; sixteen
+    # waves per block with regions of 80 / 100 / 128 rows (option 43)
+    for opt, mode in ((14, 1), (14, 4), (32, 2), (32, 3), (43, 80), (43, 100), (43, 128)):
         md = ScanMatcher()
         try:
+            if opt == 43:
+                md.debug_option(32, 5)
             md.debug_option(opt, mode)
         except _capi.YmError as e:  # (option 32 = 2, 3: forms compiled only with -DYM_EXPERIMENTAL)
-            assert e.code == -4 and opt == 32
+            assert e.code == -4 and opt in (32, 43)
             continue
         perd, bestd = md.match_scan_batch(q, chains, True, True)
         assert best == bestd == int(np.argmax([p.response for p in per]))

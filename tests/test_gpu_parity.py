@@ -1051,10 +1051,13 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             # the region correlate's other forms: wave-specialised (option 32 = 2: gather waves + loader waves, persistent blocks) and
             # one block per item with the item's sums in LDS (= 3: what large batches take), with the lists that fit and without
             # and the pooled form at two blocks per item (= 4: a region's patches dealt evenly over twelve waves, 16-bit sums in LDS)
-            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3), (4, 0), (4, 2), (4, 3)) if experimental else ():
+            # round 5: sixteen waves per block, two or three per angle (option 32 = 5; 43 = region height: form 80 / 100 / 128)
+            for form, irregular in ((2, 0), (3, 0), (3, 2), (3, 3), (4, 0), (4, 2), (4, 3), (80, 0), (100, 0), (128, 0), (128, 2), (100, 3)) if experimental else ():
                 m = ScanMatcher(cfg)
                 m.debug_option(12, 1)
-                m.debug_option(32, form)
+                if form >= 80:
+                    m.debug_option(43, form)
+                m.debug_option(32, 5 if form >= 80 else form)
                 if irregular:
                     m.debug_option(14, irregular)
                 per, best = m.match_scan_batch(nquery, chains, True, True)
@@ -1067,6 +1070,12 @@ def test_region_correlate_equals_the_direct_kernel_and_the_oracle():
             for opts in ({}, {21: 2}, {14: 4}, {32: 2}, {32: 2, 21: 2}, {32: 3}, {32: 3, 21: 2}, {32: 3, 14: 2}, {32: 4}, {32: 4, 21: 2}, {32: 4, 14: 2}, {32: 4, 39: 1}):
                 if 32 in opts and not experimental:
                     continue
+                if opts.get(32) == 4 and len(opts) == 1:  # (rides along: the sixteen-wave form with its three region heights)
+                    for h in (80, 100, 128):
+                        m = ScanMatcher(cfg)
+                        m.debug_option(43, h)
+                        m.debug_option(32, 5)
+                        same((None,) + tuple(m.match_scan_batch(nquery, chains, True, True)), vols[1])
                 m = ScanMatcher(cfg)
                 for k, v in opts.items():
                     m.debug_option(k, v)

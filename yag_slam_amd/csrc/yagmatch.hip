@@ -203,6 +203,8 @@ struct CallPlan {
     bool rg_pool = false; // correlate_pool_kernel: two blocks of 12 waves per item, a region's patches dealt evenly, 16-bit sums in LDS
     bool win_only = false; // the region correlate stages from the row-major window and the raster does not write the planes
     bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
+    bool rg2 = false;   // correlate_region2_kernel (round 5): sixteen waves per block, several waves per angle, regions rg2_h rows high
+    int rg2_h = 0;
     size_t rg_entries_stride = 0, rg_starts_stride = 0;
     // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
     // always scores its sums
@@ -561,6 +563,9 @@ struct ym_matcher {
     int corr_region_pad_lds = 0; // development (option 38): dynamic LDS bytes the region correlate is launched with and does not use (fewer blocks per CU)
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
+    int rg2_min_batch = 1 << 30; // batches from this many items on take correlate_region2_kernel (option 32 = 5: always where it can)
+    int rg2_h = 128;          // option 43: class rows a region of correlate_region2_kernel owns (80, 100 or 128)
+    size_t rg2_lds_limit = 0;
     int corr_fuse_score = 0; // tests: 2 = the region correlate never scores itself (score_kernel does)
     // gather correlate: per query slot of a call the (beam, angle) units sorted by region, the bin table, the work
     // lists and the counters they are built with; the lane -> (row, segment) table of the lattice
@@ -978,7 +983,13 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             P.rg_nw = YM_WS_NG;
             P.rg_parts = (lc.nt + YM_WS_NG - 1) / YM_WS_NG;
         }
-        const int rg_h = P.rg_ws ? YM_WS_H : YM_RG_H;
+        // round 5: large batches on up to 24 angles -- sixteen waves per block, two or three per angle (ym_k_region2.hpp)
+        // (below two blocks per CU the regions of the first form are dealt out to more blocks instead: rsplit)
+        P.rg2 = !P.rg_ws && m->corr_region_nw == 0 && !m->keep_planes && lc.nt > 0 &&
+                (m->corr_region_form == 5 || (m->corr_region_form == 0 && B >= m->rg2_min_batch && 3 * B >= 2 * m->n_cus));
+        P.rg2_h = m->rg2_h == 80 ? 80 : m->rg2_h == 100 ? 100 : 128;
+        if (P.rg2) { P.rg_nw = lc.nt <= 8 ? lc.nt : 8; P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw; }
+        const int rg_h = P.rg_ws ? YM_WS_H : P.rg2 ? P.rg2_h : YM_RG_H;
         P.rg_nrx = (half_w + YM_RG_W - 1) / YM_RG_W;
         P.rg_nry = (half_w + rg_h - 1) / rg_h;
         P.rg_nregions = P.rg_nrx * P.rg_nry;
@@ -992,22 +1003,22 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
             // kernel 121 -> 65 us with four, the enqueue 236 -> 205 us; 128 chains 317 -> 295 with two; scripts/dev/rsplit_time.py)
             P.rg_rsplit = 1;
-            if (!P.rg_ws && m->corr_region_rsplit != 1 && m->corr_region_form != 3 && m->corr_region_form != 4) {
+            if (!P.rg_ws && !P.rg2 && m->corr_region_rsplit != 1 && m->corr_region_form != 3 && m->corr_region_form != 4) {
                 const int blocks = B * P.rg_parts;
                 P.rg_rsplit = m->corr_region_rsplit > 1 ? m->corr_region_rsplit : std::max(1, std::min(8, (3 * m->n_cus) / std::max(1, blocks)));
             }
             // batches that fill the chip with one block per item: correlate_item_kernel (option 32: 1 = never, 3 = always)
-            P.rg_item = !P.rg_ws && P.rg_rsplit == 1 && lc.nt <= YM_IT_MAX_NT && m->corr_region_form != 1 &&
+            P.rg_item = !P.rg_ws && !P.rg2 && P.rg_rsplit == 1 && lc.nt <= YM_IT_MAX_NT && m->corr_region_form != 1 &&
                         (m->corr_region_form == 3 || B >= m->item_min_batch);
-            P.n_groups = P.rg_ng * P.rg_rsplit;
+            P.n_groups = P.rg_ng * P.rg_rsplit * (P.rg2 ? YM_R2_MAX_WPA : 1); // (rg2: every slice of an angle writes its own sets)
             // the pooled form (option 32 = 4): large batches of at most 22 angles
-            P.rg_pool = !P.rg_ws && !P.rg_item && P.rg_rsplit == 1 && m->corr_region_form == 4 && lc.nt <= 2 * YM_PL_MAX_NK && m->corr_region_nw == 0;
+            P.rg_pool = !P.rg_ws && !P.rg2 && !P.rg_item && P.rg_rsplit == 1 && m->corr_region_form == 4 && lc.nt <= 2 * YM_PL_MAX_NK && m->corr_region_nw == 0;
             if (P.rg_pool) {
                 P.rg_nw = lc.nt <= YM_PL_MAX_NK ? lc.nt : (lc.nt + 1) / 2;
                 P.rg_parts = (lc.nt + P.rg_nw - 1) / P.rg_nw;
             }
             // the default form at eight waves stages from the window: the raster of such a call writes no planes (option 39 = 1: keeps them)
-            P.win_only = !P.rg_ws && !P.rg_item && (P.rg_nw == 8 || P.rg_pool) && !m->keep_planes;
+            P.win_only = !P.rg_ws && !P.rg_item && (P.rg_nw == 8 || P.rg_pool || P.rg2) && !m->keep_planes;
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
             // (the wave-specialised form's bins are a third more and hold less each: 20 %)
@@ -1117,7 +1128,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     P.dim_stride = std::max(lc.nx, lc.ny);
     P.sums_c = (size_t)lc.nt * lc.ny * lc.nx;
     P.sums_f = (size_t)lf.nt * lf.ny * lf.nx;
-    P.partial_stride = P.region26 ? (size_t)P.rg_ng * P.rg_rsplit * lc.nt * 64 * 16 : P.region ? (size_t)P.ga_ng * lc.nt * P.ga_np * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
+    P.partial_stride = P.region26 ? (size_t)P.rg_ng * P.rg_rsplit * (P.rg2 ? YM_R2_MAX_WPA : 1) * lc.nt * 64 * 16 : P.region ? (size_t)P.ga_ng * lc.nt * P.ga_np * 64 * 16 : (size_t)P.n_groups * lc.nt * lc.ny * P.nx_pad;
     P.cell_blocks = (lc.nx * lc.ny + YM_SCORE_THREADS - 1) / YM_SCORE_THREADS;
     P.score_blocks = P.cell_blocks * lc.nt; // block maxima per (angle, block of cells)
 
@@ -1127,7 +1138,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->qnp.ensure(B))) return rc;
     if ((rc = m->cells.ensure((size_t)B * max_base * max_n))) return rc;
     if ((rc = m->bbox.ensure((size_t)B * max_base * YM_N_BOXES(max_n)))) return rc;
-    if ((rc = m->grid.ensure((size_t)B * P.grid_stride + YM_RG_WINDOW_SLACK(g.pitch)))) return rc;
+    if ((rc = m->grid.ensure((size_t)B * P.grid_stride + std::max(YM_RG_WINDOW_SLACK(g.pitch), YM_R2_WINDOW_SLACK(g.pitch, 128))))) return rc;
     if ((rc = m->planes.ensure((size_t)B * P.grid_stride + std::max(std::max(YM_RG_PLANES_SLACK(g.pitch / 2), YM_WS_PLANES_SLACK(g.pitch / 2)), YM_GA_PLANES_SLACK(g.pitch / 2, std::max(P.ga_rows, P.ga_nry + P.ga_H), lc.ny, P.ga_P))))) return rc;
     if ((rc = m->ctrig.ensure((size_t)B * P.nt_stride))) return rc;
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
@@ -1701,6 +1712,7 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
     r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
     r.rg_h = P.rg_ws ? YM_WS_H : YM_RG_H; r.rg_cls = P.rg_ws ? YM_WS_CLS : P.rg_item ? YM_IT_CLS : YM_RG_CLS;
     r.rg_zero = P.rg_ws ? YM_WS_ZERO : P.rg_item ? YM_IT_ZERO : YM_RG_ZERO; r.pad2 = 0;
+    if (P.rg2) { r.rg_h = P.rg2_h; r.rg_cls = YM_RG_PITCH * (P.rg2_h + 26); r.rg_zero = 4 * r.rg_cls; }
     r.rg_w = 0; r.rg_pitch = YM_RG_PITCH; r.nregions = P.rg_nregions; r.pad3 = 0;
     r.walk = m->rg_walk.p; r.nitems = P.B; r.rsplit = P.rg_rsplit; r.pad4 = 0;
     // teams of `parts` blocks per XCD: two blocks per CU, no more teams than the XCD gets items
@@ -1760,6 +1772,22 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         else if ((rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts * P.rg_rsplit, P.B);
+#ifdef YM_EXPERIMENTAL
+        if (P.rg2) {
+            const size_t lds = (size_t)r.rg_zero + 26 * YM_RG_PITCH + 32 + (size_t)m->corr_region_pad_lds;
+            if (lds > m->rg2_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
+                const int want = 144 * 1024; // (the 160 KB of a CU less the kernel's static 15 KB)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::correlate_region2_kernel<80>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::correlate_region2_kernel<100>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::correlate_region2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+                m->rg2_lds_limit = (size_t)want;
+            }
+            if (P.rg2_h == 80) hipLaunchKernelGGL(ym::correlate_region2_kernel<80>, rgrid, dim3(64 * YM_R2_NW), lds, st, r);
+            else if (P.rg2_h == 100) hipLaunchKernelGGL(ym::correlate_region2_kernel<100>, rgrid, dim3(64 * YM_R2_NW), lds, st, r);
+            else hipLaunchKernelGGL(ym::correlate_region2_kernel<128>, rgrid, dim3(64 * YM_R2_NW), lds, st, r);
+            return prof_end(m, ev_k);
+        }
+#endif
 #ifdef YM_EXPERIMENTAL // (the three forms that lost to correlate_region_kernel: profiles/r04_region_study.md; option 32 refuses them otherwise)
         if (P.rg_item) {
             const size_t lds = YM_IT_ACC_BYTES(P.lc.nt);
@@ -3407,6 +3435,13 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
+    else if (option == 43) m->rg2_h = value;
+    else if (option == 44) {
+#ifndef YM_EXPERIMENTAL
+        return set_err(YM_ERR_UNSUPPORTED, "correlate_region2_kernel is compiled only into builds made with -DYM_EXPERIMENTAL");
+#endif
+        m->rg2_min_batch = value > 0 ? value : 1 << 30;
+    }
     else if (option == 32) {
 #ifndef YM_EXPERIMENTAL
         if (value >= 2) return set_err(YM_ERR_UNSUPPORTED, "correlate form %d is compiled only into builds made with -DYM_EXPERIMENTAL", value);

@@ -172,6 +172,17 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
     const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     const double2 *trig = a.ctrig + (size_t)b * a.nt_stride;
     int32_t *starts = a.starts + (size_t)qs * a.starts_stride;
+    // The query's sensor-frame points and the angle table go through LDS: pass 1 reads point i of angle k for `per` consecutive
+    // pairs per thread -- from global memory that is one dependent load per pair, 64 cache lines per wave load (the lanes are
+    // `per` points apart).  They borrow the entry list's room, which nothing writes before pass 1 is over (round 5: one query per
+    // ITEM of a batch, ym_pairs_create, made this kernel a whole launch of 4096 blocks instead of one block).
+    double2 *qls = reinterpret_cast<double2 *>(bin_smem + ((reinterpret_cast<unsigned char *>(ent) - bin_smem) + 15) / 16 * 16);
+    const bool ql_in_lds = (size_t)(nq + nt) * sizeof(double2) + 16 <= (size_t)a.entries_stride * 2;
+    double2 *trigs = qls + nq;
+    if (ql_in_lds) {
+        for (int i = tid; i < nq; i += YM_BIN_THREADS) qls[i] = ql[i];
+        if (tid < nt) trigs[tid] = trig[tid];
+    }
     for (int i = tid; i < a.nbins * 2; i += YM_BIN_THREADS) (&cnt[0][0])[i] = 0u;
     if (tid < YM_MAX_COARSE_NT) angle_tot[tid] = 0;
     if (tid < YM_RG_MAX_BINS / 32) region_bits[tid] = 0u;
@@ -207,9 +218,10 @@ __global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
         const int p = p0 + q;
         key[q] = 0xffffffffu;
         if (q < per_thread && p < total) {
-            const double2 cs = trig[k];
+            const double2 cs = ql_in_lds ? trigs[k] : trig[k];
+            const double2 pt = ql_in_lds ? qls[i] : ql[i];
             int bin, region; unsigned e, er, ex;
-            if (region_entry(a, lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, bin, e, region, er, ex)) {
+            if (region_entry(a, lookup_cell(pt, cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, bin, e, region, er, ex)) {
                 const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
                 key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
                 rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));

@@ -26,6 +26,7 @@
 #include "ym_k_correlate.hpp"
 #include "ym_k_finish.hpp"
 #include "ym_k_region.hpp"
+#include "ym_k_region2.hpp" // (its kernel is compiled only with -DYM_EXPERIMENTAL: measured slower, profiles/r05_region_study.md)
 #include "ym_k_item.hpp"
 #include "ym_k_gather.hpp"
 #include "ym_k_yagpy.hpp"
