@@ -1581,3 +1581,50 @@ def test_two_matchers_on_two_streams_with_pose_writes_between_their_enqueues():
     for i, (g, w) in enumerate(zip(got, want)):
         assert g == w, "enqueue %d (lane %d, round %d) differs from the single-matcher result" % (i, i % 2, i // 2)
     assert want[0] != want[2]  # (the writes did change results: the test compares something)
+
+
+def test_pair_lists_kept_from_call_to_call_are_invisible():
+    """A single-query batch whose query, pose, window and lattice equal those of the matcher's last list build does not build its
+    pair lists again (round 5).  One matcher through a sequence that hits and misses that cache -- the same query against other
+    chains, the query re-posed, another query, a multi-query call in between, a smaller batch that takes the direct kernel, the
+    first query again -- must give what a matcher that always builds them (option 45 = 0) gives, bit for bit."""
+    from yag_slam_amd import synth
+    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.transform import Transform
+    scene = synth.Scene()
+    q, _ = synth.single_match_scans(scene)
+    base_poses, q_truth, q_prior = synth.single_match_poses()
+    q2 = synth.resident_scan(scene.scan_ranges((3.02, 2.97, -0.03), index=77), (3.0, 3.0, 0.0))
+    exact = [scene.cast(*p) for p in base_poses]
+    chains = []
+    for c in range(130):
+        rng = np.random.default_rng(9000 + c)
+        chains.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
+    m, ref = ScanMatcher(), ScanMatcher()
+    ref.debug_option(45, 0)
+    key = lambda per: [(p.response, tuple(map(tuple, p.covariance)), p.best_pose.x, p.best_pose.y, p.best_pose.euler[-1]) for p in per]
+
+    def both(query, chs, pairs=False):
+        if pairs:
+            a, b_ = m.match_pairs(query, chs, True, True), ref.match_pairs(query, chs, True, True)
+        else:
+            a, b_ = m.match_scan_batch(query, chs, True, True)[0], ref.match_scan_batch(query, chs, True, True)[0]
+        assert key(a) == key(b_)
+        return key(a)
+    r1 = both(q, chains[:64])
+    r2 = both(q, chains[64:128])         # same query, other chains: the lists are in place
+    assert r1 != r2
+    both(q, chains[:64])
+    p = q.corrected_pose
+    q.corrected_pose = Transform(p.x + 0.013, p.y - 0.004, 0.0, p.euler[-1] + 0.006)
+    r3 = both(q, chains[:64])            # re-posed: built again
+    assert r3 != r1
+    both(q2, chains[:64])                # another query
+    both(q, chains[:64])                 # the first again: its lists were overwritten
+    both([q, q2] * 32, chains[:64], pairs=True)  # a multi-query call uses the same buffers
+    both(q, chains[:64])
+    both(q, chains[:20])                 # the direct kernel (no lists), then the region correlate again
+    both(q, chains[:64])
+    both(q, chains[:130])                # a larger batch on the same window
+    q.corrected_pose = p
+    assert both(q, chains[:64]) == r1

@@ -183,6 +183,7 @@ struct Call {
 struct CallPlan {
     int B = 0, nscans = 0, max_n = 1, max_base = 1;
     int tile_h = YM_TILE_H;            // rows per raster tile in this call
+    bool lists_cached = false;         // the matcher's list buffers already hold this call's pair lists (ym_matcher::list_key)
     bool lists_on_side_stream = false; // the region path's bin_kernel went to the matcher's second stream (join before the region kernel)
     bool yag = false;
     YmGeom g;
@@ -563,6 +564,16 @@ struct ym_matcher {
     int corr_region_pad_lds = 0; // development (option 38): dynamic LDS bytes the region correlate is launched with and does not use (fewer blocks per CU)
     int corr_region_dbg = 0;  // development (timing only): 1 = the loader waves move nothing, 2 = the gather waves gather nothing
     int corr_region_form = 0; // 2 = the wave-specialised region correlate (gather waves + loader waves) instead of correlate_region_kernel
+    // the pair lists of the last single-query call that built them: what they were built from.  A call with the same key finds them
+    // in the list buffers and builds nothing (no bin_kernel, no second stream, no join) -- they depend on the query's readings and
+    // pose, the window and the lattice alone, like the projected points the point cache keeps (round 5; option 45 = 0: off)
+    struct ListKey {
+        uint64_t qid; double pose[3]; YmGeom g; YmLattice lc;
+        int32_t nw, parts, nrx, nry, rg_h, force, nregions, ng; size_t es, ss; const void *pe, *ps, *pb;
+    };
+    ListKey list_key;
+    bool list_key_valid = false, list_cache_on = true;
+    int64_t list_cache_hits = 0;
     int rg2_min_batch = 1 << 30; // batches from this many items on take correlate_region2_kernel (option 32 = 5: always where it can)
     int rg2_h = 128;          // option 43: class rows a region of correlate_region2_kernel owns (80, 100 or 128)
     size_t rg2_lds_limit = 0;
@@ -1769,7 +1780,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     if (P.region26) {
         const ym::RegionArgs r = region_args(m, P);
         if (P.lists_on_side_stream) HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
-        else if ((rc = enqueue_region_lists(m, P, st))) return rc;
+        else if (!P.lists_cached && (rc = enqueue_region_lists(m, P, st))) return rc;
         if ((rc = prof_begin(m, 0, &ev_k))) return rc;
         const dim3 rgrid(P.rg_parts * P.rg_rsplit, P.B);
 #ifdef YM_EXPERIMENTAL
@@ -1845,8 +1856,8 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         hipLaunchKernelGGL(ym::gbin_pieces_kernel<true>, pgrid, dim3(YM_GBIN_THREADS), 0, st, r);
         if (P.ga_lds > m->ga_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
             const int want = (int)std::min<size_t>(160 * 1024, P.ga_lds);
-            const void *kernels[14] = {
-#define YM_GA_BOTH(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER>), reinterpret_cast<const void *>(ym::gather_percell_kernel<NA, NP>)
+            const void *kernels[21] = {
+#define YM_GA_BOTH(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER>), reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER, 512>), reinterpret_cast<const void *>(ym::gather_percell_kernel<NA, NP>)
                 YM_GA_BOTH(1, 1), YM_GA_BOTH(2, 1), YM_GA_BOTH(3, 1), YM_GA_BOTH(4, 1), YM_GA_BOTH(1, 2), YM_GA_BOTH(2, 2), YM_GA_BOTH(1, 3)};
 #undef YM_GA_BOTH
             for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, want));
@@ -1859,7 +1870,8 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         // items
 #define YM_GA_LAUNCH(NA, NP)                                                                                               \
     do {                                                                                                                   \
-        hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER>), rgrid, rblock, P.ga_lds, st, r);                        \
+        if (P.ga_nwv <= 8) hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER, 512>), rgrid, rblock, P.ga_lds, st, r); \
+        else hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER>), rgrid, rblock, P.ga_lds, st, r);                   \
         hipLaunchKernelGGL((ym::gather_percell_kernel<NA, NP>), rgrid, rblock, P.ga_lds, st, r);                           \
     } while (0)
         if (P.ga_np == 1) {
@@ -2002,7 +2014,25 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     // the region correlate's pair lists are built next to the raster on the matcher's second stream: the fork right behind the
     // prepare stage, the launches of that stream after the raster's -- while the host made them first, the device sat idle
     // between the prepare stage and the raster's first kernel (17 us of a 64-item enqueue's 214)
-    const bool lists_aside = P.region26 && !P.yag && m->overlap_lists && !P.stamps && P.k_end > P.k_begin;
+    if (P.region26 && !P.yag) {
+        // single-query calls (a loop closure: one query, many chains): are the lists of this very query, at this pose, in this
+        // window and lattice, still in the buffers?
+        ym_matcher::ListKey key;
+        std::memset(&key, 0, sizeof key);
+        const CallScan *q0 = P.n_qslots == 1 ? &slot.call.scans[slot.call.items[0].query] : nullptr;
+        bool keyed = q0 && q0->id != 0 && m->list_cache_on && !P.stamps && !P.rg_ws;
+        if (keyed) {
+            key.qid = q0->id; key.pose[0] = q0->pose[0]; key.pose[1] = q0->pose[1]; key.pose[2] = q0->pose[2];
+            key.g = P.g; key.lc = P.lc; key.nw = P.rg_nw; key.parts = P.rg_parts; key.nrx = P.rg_nrx; key.nry = P.rg_nry;
+            key.rg_h = P.rg2 ? P.rg2_h : YM_RG_H; key.force = m->corr_region; key.nregions = P.rg_nregions; key.ng = P.rg_ng;
+            key.es = P.rg_entries_stride; key.ss = P.rg_starts_stride;
+            key.pe = m->rg_entries.p; key.ps = m->rg_starts.p; key.pb = m->rg_rbox.p;
+            P.lists_cached = m->list_key_valid && std::memcmp(&key, &m->list_key, sizeof key) == 0;
+        }
+        if (P.lists_cached) m->list_cache_hits++;
+        else { m->list_key = key; m->list_key_valid = keyed; } // (the build is enqueued below; a failed call drops the key: launch_call)
+    }
+    const bool lists_aside = P.region26 && !P.yag && m->overlap_lists && !P.stamps && P.k_end > P.k_begin && !P.lists_cached;
     if (lists_aside && (rc = enqueue_region_lists_aside(m, P))) return rc;
     if ((rc = enqueue_select(m, P))) return rc;
     if ((rc = enqueue_raster(m, P))) return rc;
@@ -2069,6 +2099,7 @@ int launch_call(ym_matcher *m, Slot &slot) {
         slot.desc_live_bytes = 0;
         slot.call.plan_clean = false;
         slot.in_flight = false;
+        m->list_key_valid = false; // (the lists may never have been built)
     }
     return rc;
 }
@@ -3404,7 +3435,7 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
 }
 
 int ym_debug_option(ym_matcher *m, int option, int value) {
-    if (m) m->cache_gen++; // (whatever the option changes, no earlier plan is reused)
+    if (m) { m->cache_gen++; m->list_key_valid = false; } // (whatever the option changes, no earlier plan or pair list is reused)
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
     if (option == 0) return set_err(YM_ERR_INVALID, "debug option 0 (an experimental correlate form) no longer exists");
     else if (option == 2) m->full_raster = value;
@@ -3435,6 +3466,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 16) m->raster_gx = value;
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
+    else if (option == 45) { m->list_cache_on = value != 0; m->list_key_valid = false; }
     else if (option == 43) m->rg2_h = value;
     else if (option == 44) {
 #ifndef YM_EXPERIMENTAL

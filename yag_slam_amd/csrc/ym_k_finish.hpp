@@ -700,9 +700,12 @@ __global__ __launch_bounds__(YM_FINISH_THREADS) void final_kernel(FinishArgs a) 
 // batch several small blocks per CU hide each other's waits better than one large block after the other (dynamic LDS
 // = 12 bytes per fine hypothesis: the fine sums and responses)
 #define YM_FINISH1_THREADS 1024
+#ifndef YM_FINISH_OCC
+#define YM_FINISH_OCC 5 // (waves per SIMD the compiler leaves room for at 256 threads; 7 and 8 -- 68 bytes of scratch -- measured the same step)
+#endif
 #define YM_FINISH_LDS_BYTES(nh) ((size_t)(nh) * 12 + 16)
 template <int NT>
-__global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
+__global__ __launch_bounds__(NT, NT == 256 ? YM_FINISH_OCC : 4 /* NT = 256: eight blocks of four waves per CU (64 VGPRs): the kernel is a chain of short dependent phases */) void finish_kernel(FinishArgs a) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
     __shared__ double scratch[16 * 5];
@@ -760,26 +763,34 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
         const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
         const bool block3 = !a.g.kpitch && nx == 3 && ny == 3 && s_cx[1] == s_cx[0] + 1 && s_cx[2] == s_cx[0] + 2 &&
                             s_cy[1] == s_cy[0] + 1 && s_cy[2] == s_cy[0] + 2;
-        for (int k = wave; k < nt; k += NW) { // wave-uniform
-            const double cosine = s_cs[k].x, sine = s_cs[k].y;
-            if (block3) {
-                // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its beam as three
-                // 4-byte words
-                const uint32_t base0 = (uint32_t)(s_cy[0] * a.g.pitch + s_cx[0]);
+        if (block3) {
+            // Karto's fine lattice is always 3x3 cells: a lane reads the 3x3 cell block under its beam as three 4-byte words.
+            // Round 5: the four lanes of a QUAD take the same beam at four consecutive fine angles -- 0.0035 rad apart, their
+            // blocks lie a cell or two apart along the beam's arc, i.e. mostly in the same 128-byte line of a row, and the vector L1
+            // charges a quad one clock per line it touches (this loop was the kernel: 0.63 line visits per CU and clock with
+            // lane = beam, every lane its own line).  A wave takes a quarter (NW-th) of the beams through all angle groups; the
+            // lanes of one angle add their sums by butterflies over the beam index, then one LDS atomic per (wave, hypothesis).
+            const uint32_t base0 = (uint32_t)(s_cy[0] * a.g.pitch + s_cx[0]);
+            const int sub = lane & 3, bl = lane >> 2;
+            const int per_wave = (nq + NW - 1) / NW, i_lo = wave * per_wave, i_hi = min(nq, i_lo + per_wave);
+            for (int k0 = 0; k0 < nt; k0 += 4) { // block-uniform
+                const int k = k0 + sub;
+                const bool kin = k < nt;
+                const double cosine = s_cs[kin ? k : k0].x, sine = s_cs[kin ? k : k0].y;
                 unsigned acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = lane; i < nq; i += 4 * 64) {
+                for (int i0 = i_lo; i0 < i_hi; i0 += 4 * 16) { // wave-uniform
                     uint32_t w[4][3];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const int ii = i + u * 64;
-                        const int off = ii < nq ? lookup_offset(ql[ii], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch) : 0;
+                        const int ii = i0 + u * 16 + bl;
+                        const int off = (ii < i_hi && kin) ? lookup_offset(ql[ii], cosine, sine, off_x, off_y, a.g.scale, a.g.pitch) : 0;
                         const uint32_t idx = base0 + (uint32_t)off;
 #pragma unroll
                         for (int r = 0; r < 3; r++) __builtin_memcpy(&w[u][r], grid + (uint32_t)(idx + r * a.g.pitch), 4);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const uint32_t m = (i + u * 64) < nq ? 0xffu : 0u;
+                        const uint32_t m = ((i0 + u * 16 + bl) < i_hi && kin) ? 0xffu : 0u;
 #pragma unroll
                         for (int r = 0; r < 3; r++) {
                             acc[3 * r] += w[u][r] & m; acc[3 * r + 1] += (w[u][r] >> 8) & m; acc[3 * r + 2] += (w[u][r] >> 16) & m;
@@ -787,11 +798,15 @@ __global__ __launch_bounds__(NT) void finish_kernel(FinishArgs a) {
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 9; j++) acc[j] = wave_reduce(acc[j], OpAddU());
-                if (lane == 0)
-#pragma unroll
-                    for (int j = 0; j < 9; j++) s_sum[k * 9 + j] = acc[j];
-            } else {
+                for (int j = 0; j < 9; j++) {
+                    unsigned v = acc[j];
+                    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                    if (bl == 0 && kin && v) atomicAdd(&s_sum[k * 9 + j], v);
+                }
+            }
+        } else {
+            for (int k = wave; k < nt; k += NW) { // wave-uniform
+                const double cosine = s_cs[k].x, sine = s_cs[k].y;
                 // generic lattice: per beam, every (iy, ix) cell
                 for (int i = lane; i < nq; i += 64) {
                     const int off = lookup_offset(ql[i], cosine, sine, off_x, off_y, a.g.scale, lin_pitch(a.g));

@@ -35,6 +35,9 @@ namespace ym {
 #define YM_GA_FLUSH 652     // weight (patches x multiplicity) a set of 16-bit sums holds: 652 x 100 < 65536
 #define YM_GA_MULT 0x40000000 // flag on a run's first-unit entry: some unit of the run has a multiplicity above 1
 #define YM_GBIN_THREADS 256
+#ifndef YM_GA_OCC512
+#define YM_GA_OCC512 6 // waves per SIMD blocks of up to 512 threads are compiled for (6: three blocks of eight waves per CU)
+#endif
 #define YM_GA_PER 4          // 16-byte chunks of a class image a thread copies per work item
 // bytes the host keeps past the last item's planes: a staged region may start up to 2 * (H + ny) + 3 rows and P bytes past
 // the last cell of the second plane (never gathered, but read)
@@ -263,23 +266,28 @@ __device__ __forceinline__ void ga_dwords(const ga_u32x2 &p, const ga_u32x2 &q, 
     else { d[0] = p.y; d[1] = q.x; d[2] = q.y; d[3] = r.x; d[4] = r.y; }
 }
 
-// the sums of one unit into the wave's registers: E[j] holds hypotheses 4j (low 16 bits) and 4j + 2, S[j] the running sum
-// of (dword >> 8) = sum(4j + 1) + 2^8 sum(4j + 2) + 2^16 sum(4j + 3); ga_odd() separates it when the sums leave the registers
+// the sums of one unit into the wave's registers: E[j] holds hypotheses 4j (low 16 bits) and 4j + 2, S[j] hypotheses 4j + 1 and
+// 4j + 3.  Round 5: funnel and widening are ONE v_perm_b32 per pair of hypotheses, as in the region correlate since round 4 --
+// selector (shift, 0x0c, shift + 2, 0x0c) picks bytes shift and shift + 2 of the eight bytes s[j + 1] : s[j] into the low bytes of
+// the two 16-bit fields and zeroes the rest, (shift + 1, 0x0c, shift + 3, 0x0c) the odd ones: four instructions per dword
+// (2 v_perm + 2 v_add, or 2 v_mad_u32_u24 with a multiplicity) instead of five (v_alignbyte, v_and, v_add, v_lshrrev, v_add), and
+// the odd sums are clean fields (until then S held the running sum of dword >> 8, separated when the sums left the registers).
 template <bool MULT>
 __device__ __forceinline__ void ga_accumulate(uint32_t (&E)[4], uint32_t (&S)[4], const uint32_t (&s)[5], uint32_t shift, uint32_t mp) {
+    const uint32_t selE = shift * 0x00010001u + 0x0c020c00u, selO = selE + 0x00010001u;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t x = __builtin_amdgcn_alignbyte(s[j + 1], s[j], shift);
+        const uint32_t e = __builtin_amdgcn_perm(s[j + 1], s[j], selE), o = __builtin_amdgcn_perm(s[j + 1], s[j], selO);
         if (MULT) {
-            E[j] = __umul24(x & 0x00FF00FFu, mp) + E[j]; // (v_mad_u32_u24)
-            S[j] = __umul24(x >> 8, mp) + S[j];
+            E[j] = __umul24(e, mp) + E[j]; // (v_mad_u32_u24: a field is at most 200 << 16 | 200 < 2^24, times at most 4)
+            S[j] = __umul24(o, mp) + S[j];
         } else {
-            E[j] += x & 0x00FF00FFu;
-            S[j] += x >> 8;
+            E[j] += e;
+            S[j] += o;
         }
     }
 }
-__device__ __forceinline__ uint32_t ga_odd(uint32_t E, uint32_t S) { return S - ((E >> 16) << 8); } // sum(4j + 1) | sum(4j + 3) << 16
+__device__ __forceinline__ uint32_t ga_odd(uint32_t, uint32_t S) { return S; } // sum(4j + 1) | sum(4j + 3) << 16 (the identity since round 5)
 
 // Two pair units (four patches) of one alignment half Q; u0 / u1 = the units' records, the same in every lane (decoded by
 // vector instructions).  A unit's six reads are issued and waited for, then accumulated, then the next unit's (issuing all
@@ -455,8 +463,10 @@ __device__ __forceinline__ void ga_score(const GatherArgs &a, int b, int NT, int
 // class image as PER 16-byte chunks per thread, one unit and one bin-row entry per thread) are in flight in registers;
 // they go to LDS between the two barriers that end the gather.  (LDS-DMA was measured for this copy and lost: a wave
 // that issues global_load_lds is held for hundreds of cycles per instruction, profiles/r03_lds_dma_experiment.md.)
-template <int NA, int NP, int PER>
-__global__ __launch_bounds__(1024) void gather_kernel(GatherArgs a) {
+// MAXT: the largest block the instantiation is launched with: blocks of up to eight waves (the usual case: one angle per wave,
+// about eight angles per block) are compiled for three blocks per CU (80 VGPRs; round 5 -- until then 104 VGPRs left two).
+template <int NA, int NP, int PER, int MAXT = 1024>
+__global__ __launch_bounds__(MAXT, MAXT <= 512 ? YM_GA_OCC512 : 4) void gather_kernel(GatherArgs a) {
     YM_GA_SETUP((int)(blockDim.x >> 6));
     if (!(st.regular[0] && a.force_irregular != 1 && starts[2 * nbins2] >= 0)) return; // gather_percell_kernel's item
     const int NT = 64 * NWV;
@@ -654,10 +664,9 @@ __global__ __launch_bounds__(1024) void gather_percell_kernel(GatherArgs a) {
                     unsigned sum = 0;
                     for (int i = i0; i < i1; i++)
                         sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
-                    // hypothesis j of dword j >> 2: even ones in E (low / high half), odd ones -- and the even high one -- in S
-                    // exactly as the sum of (dword >> 8) would hold them
+                    // hypothesis j of dword j >> 2: even ones in E (low / high half), odd ones in S
                     if ((j & 1) == 0) E[n][p2][j >> 2] += sum << (8 * (j & 2));
-                    S[n][p2][j >> 2] += (j & 1) ? sum << (8 * (j & 2)) : (j & 2) ? sum << 8 : 0u;
+                    else S[n][p2][j >> 2] += sum << (8 * (j & 2));
                 }
             }
             if (i1 < nq) flush(n);

@@ -39,6 +39,14 @@ namespace ym {
 #define YM_RG_PH(i) do { } while (0)
 #endif
 
+// development build (-DYM_RG_ABLATE=bits, TIMING ONLY, wrong sums): 1 = the gather adds nothing (no LDS read, no vector work), 2 = no
+// staging loads, 4 = no staging stores -- what each part of a round costs the kernel (scripts/dev/r05_ablate.sh)
+#ifndef YM_RG_ABLATE
+#define YM_RG_ABLATE 0
+#endif
+#ifndef YM_RG_PRIO
+#define YM_RG_PRIO 0
+#endif
 #define YM_RG_W 64                            // region width and height in class bytes (128 x 160 window cells): what three
 #define YM_RG_H 80                            // blocks per CU leave room for in LDS
 #define YM_RG_PITCH 100                       // LDS bytes per staged row: 25 dwords, odd -> 26 rows on 26 distinct banks
@@ -65,6 +73,9 @@ static_assert(16 * YM_RG_SEGS >= YM_RG_W + 2 * YM_RG_G + 3 && YM_RG_PITCH >= 16 
 #define YM_RG_MAX_ENTRIES 28672
 #define YM_RG_FLUSH 652                       // patches per set of 16-bit sums: 652 x 100 < 65536 (a multiple of four)
 #define YM_BIN_THREADS 1024
+#ifndef YM_BIN_MIN_WAVES
+#define YM_BIN_MIN_WAVES 8 // waves per SIMD the compiler must leave room for: 8 = two blocks per CU (64 VGPRs)
+#endif
 #define YM_BIN_LDS_BYTES(nbins, entries, nboxes) ((size_t)(YM_BIN_THREADS / 64 + YM_MAX_COARSE_NT + YM_RG_MAX_BINS / 32 + 1) * 4 + (size_t)(nbins) * 8 + ((size_t)(entries) * 2 + 15) / 16 * 16 + (size_t)(nboxes) * 16)
 
 struct RegionArgs {
@@ -149,7 +160,7 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
 // never meets a ragged group.  An item whose padded list would not fit -- the buffers, one angle's share the ng sets of
 // 16-bit sums the gather may fill, or more regions with work than a correlate block can list -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
-__global__ __launch_bounds__(YM_BIN_THREADS) void bin_kernel(RegionArgs a) {
+__global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_kernel(RegionArgs a) {
     constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
     // dynamic LDS (YM_BIN_LDS_BYTES: sized by the host so that two blocks share a CU on the usual lattice):
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
@@ -344,6 +355,10 @@ __device__ __forceinline__ void rg_perm_pair(const rg_u32x2 &pa, const rg_u32x2 
 // the issuing statement or passes through the statement that waits for it ("+v") before anything else touches it.
 __device__ __forceinline__ void rg_gather4(uint32_t (&acc)[8], uint32_t lane_off, uint2 ee /* four 16-bit origins, wave-uniform */) {
     const uint32_t ad0 = lane_off + (ee.x & 0xffffu), ad1 = lane_off + (ee.x >> 16), ad2 = lane_off + (ee.y & 0xffffu), ad3 = lane_off + (ee.y >> 16);
+#if YM_RG_ABLATE & 1
+    acc[0] += ad0 ^ ad1 ^ ad2 ^ ad3; // (the entries are still read)
+    return;
+#endif
     rg_u32x2 p0, q0, p1, q1, p2, q2, p3, q3;
     asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"
                  "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"
@@ -520,14 +535,18 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             //  under a per-lane predicate costs the kernel 28 bytes of scratch per lane and is slower)
 #pragma unroll
             for (int q = 0; q < PER; q++)
+#if YM_RG_ABLATE & 2
+                v[q] = make_uint4((uint32_t)(size_t)src, seg_in, bx, q);
+#else
                 if (band_in(q, bx)) v[q] = *reinterpret_cast<const uint4 *>(src + (in_box(q, bx, seg_in) ? src0 + (uint32_t)q * src_step : 0u));
+#endif
         };
         auto stage_store = [&](uint32_t bx) {
             const bool seg_in = seg_inside(bx);
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(region + dst0 + (uint32_t)(q * RSTEP * YM_RG_PITCH)); // class images are contiguous
-                if (band_in(q, bx) && in_box(q, bx, seg_in)) {
+                if (band_in(q, bx) && in_box(q, bx, seg_in) && (!(YM_RG_ABLATE & 4) || v[q].x == 0x12345u)) {
                     if (WIN) { // even window columns -> this image, odd ones -> the next
                         d[0] = __builtin_amdgcn_perm(v[q].y, v[q].x, 0x06040200u); d[1] = __builtin_amdgcn_perm(v[q].w, v[q].z, 0x06040200u);
                         d[YM_RG_CLS / 4] = __builtin_amdgcn_perm(v[q].y, v[q].x, 0x07050301u); d[YM_RG_CLS / 4 + 1] = __builtin_amdgcn_perm(v[q].w, v[q].z, 0x07050301u);
@@ -554,6 +573,16 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         };
         auto gather = [&](int lo, int hi) { // entries [lo, hi)
             const int lds_hi = min(hi, lo + 256);
+#if YM_RG_PRIO
+            // a round lasts as long as its longest gather: the wave with many patches goes first at its SIMD's issue port
+            // (s_setprio 0 .. 3 by the number of patches; YM_RG_PRIO = the count that makes a level)
+            {
+                const int n = hi - lo;
+                if (n >= 3 * YM_RG_PRIO) __builtin_amdgcn_s_setprio(3);
+                else if (n >= 2 * YM_RG_PRIO) __builtin_amdgcn_s_setprio(2);
+                else if (n >= YM_RG_PRIO) __builtin_amdgcn_s_setprio(1);
+            }
+#endif
             if (lo < lds_hi) {
                 const uint2 *el = elist[wave];
                 const int n4 = (lds_hi - lo) >> 2;
@@ -582,6 +611,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 in_set += 4;
                 if (in_set == YM_RG_FLUSH) flush();
             }
+#if YM_RG_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         int s0 = 0, s2 = 0;
         if (nlist > 0) {
