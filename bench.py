@@ -107,7 +107,10 @@ def profile_json(name):
         return None
 
 
-def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlate_body", cus=256):
+DEVICE = {"cus": 256, "clock_hz": 2.4e9}  # MI355X; main() replaces both with what the device reports
+
+
+def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlate_body", cus=None):
     """`roofline` block of `kernel` as it ran in `workload`: its counters per launch from profiles/counters.json (rocprofv3 --pmc
     passes of that workload, scripts/profile_pmc.sh) over the kernel duration `kernel_s` (seconds; measured live where the
     caller can, else the profiled run's) against the measured peaks of profiles/issue_peaks.json.  bound = the resource with
@@ -122,7 +125,7 @@ def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlat
         kernel_s = k.get("us", 0.0) * 1e-6
     if not kernel_s or not peaks:
         return None
-    clocks = kernel_s * 2.4e9 * cus  # (cus: the CUs the launch can occupy -- 1 for a one-block kernel)
+    clocks = kernel_s * DEVICE["clock_hz"] * (cus if cus is not None else DEVICE["cus"])  # (cus = 1 for a one-block kernel)
     vp = peaks.get(valu_peak_key, {}).get("peak_per_cu_clk") or peaks["generic"]["slow_class_per_cu_clk"]
     res = {}
     if k.get("SQ_INSTS_VALU"):
@@ -132,7 +135,10 @@ def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlat
         res["lds"] = {"achieved": k["SQ_LDS_IDX_ACTIVE"] / clocks, "peak": 1.0, "unit": "LDS busy cycles per CU and clock"}
     if k.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         res["vector_l1"] = {"achieved": k["TCP_TOTAL_CACHE_ACCESSES_sum"] / clocks, "peak": 1.0, "unit": "cache-line visits per CU and clock"}
-    hbm_bytes = (k.get("FETCH_SIZE", 0.0) * 2.0 + k.get("WRITE_SIZE", 0.0)) * 1024.0  # (KiB; gfx950 counts half of a wide read stream)
+    # FETCH_SIZE is in KiB and counts HALF the bytes of the 128-byte lines a kernel's 16-byte-per-lane loads request from the fabric --
+    # calibrated on this kernel's own access pattern (192 contiguous bytes per row, rows a window pitch apart, and every other row)
+    # and on a plain stream: scripts/exp/fetch_calib.hip, profiles/r05_fetch_calibration.md (factor 2.000 in all three)
+    hbm_bytes = (k.get("FETCH_SIZE", 0.0) * 2.0 + k.get("WRITE_SIZE", 0.0)) * 1024.0
     if hbm_bytes:
         res["hbm"] = {"achieved": hbm_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "read_bytes": k.get("FETCH_SIZE", 0.0) * 2048.0,
                       "written_bytes": k.get("WRITE_SIZE", 0.0) * 1024.0}
@@ -145,6 +151,7 @@ def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlat
     return {"bound": bound, "kernel": kernel, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
             "frac": res[bound]["frac"], "traffic": hbm_bytes or None, "hbm_frac": res["hbm"]["frac"] if "hbm" in res else None,
             "resources": res, "kernel_us": kernel_s * 1e6, "kernel_us_is": "measured in this run" if live else "the profiled run's",
+            "kernel_us_in_the_counter_passes": k.get("us"),  # (under rocprofv3 the kernel runs a few per cent longer; the counts per launch are divided by the LIVE duration)
             "wave_time": {"waiting_at_waitcnt_or_barrier": k.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": k.get("SQ_WAIT_INST_ANY", 0.0) / wc,
                           "issuing": k.get("SQ_ACTIVE_INST_ANY", 0.0) / wc} if wc else None,
             "l2_hit_rate": k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if k.get("TCC_HIT_sum") else None,
@@ -535,6 +542,9 @@ def main():
     from yag_slam_amd import synth
     from yag_slam_amd.scan_matching import ScanMatcher
 
+    props = torch.cuda.get_device_properties(local_rank)
+    DEVICE["cus"] = int(props.multi_processor_count)
+    DEVICE["clock_hz"] = float(getattr(props, "clock_rate", 2400000)) * 1e3  # (kHz)
     m = ScanMatcher(None, device=local_rank)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
@@ -562,6 +572,7 @@ def main():
     line = {"metric": "pose hypotheses/sec", "value": None, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic", "config": {}, "roofline": None}
+    line["device"] = {"name": props.name, "compute_units": DEVICE["cus"], "clock_hz": DEVICE["clock_hz"]}
     by_config = {}
 
     query = chains = None

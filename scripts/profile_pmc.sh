@@ -4,12 +4,12 @@
 # stress match (cfg5: correlate_kernel<2,16,1>, select_relax_kernel) --, each counter group in its own rocprofv3 run, nothing else
 # traced, copy kernels excluded; plus one kernel-trace pass per workload for the durations.  Summarised on the box
 # (scripts/summarise_counters.py: the CSVs are too large to travel) into gpurun_out/<tag>_counters.json.
-#   scripts/profile_pmc.sh r04p
-tag=${1:-r04p}
+#   scripts/profile_pmc.sh r05p
+tag=${1:-r05p}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for wl in cfg2x cfg4 cfg5; do
-  extra=""; [ $wl = cfg2x ] && extra="--no-production-legs"
+  extra=""; [ $wl = cfg2x ] && extra="--no-production-legs --only-headline"
   rm -rf $out/${tag}_${wl}_trace
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${wl}_trace -o ${tag} -- python3 bench.py --only $wl $extra --lanes 1 --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_${wl}_trace.log
   for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum" "tcp:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" \

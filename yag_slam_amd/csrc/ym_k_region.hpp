@@ -402,7 +402,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     __shared__ int rlist[YM_RG_MAX_REGIONS];
     __shared__ uint32_t rboxl[YM_RG_MAX_REGIONS];     // per listed region: first row | last row << 8 | first segment << 16 | last << 24 to stage
     __shared__ unsigned short seginfo[NW][YM_RG_MAX_REGIONS][2]; // per wave and listed region: its first entry and the end
-    __shared__ uint2 elist[NW][64];                   // per wave: its first 256 entries of the region being gathered
+    // (until round 5 a wave's first 256 entries of the region being gathered went through LDS -- uint2 elist[NW][64], a broadcast
+    //  ds_read_b64 per four patches; the compiler, seeing a wave-uniform value, put a v_readfirstlane and with it an
+    //  s_waitcnt lgkmcnt(0) right behind every such read: one exposed LDS round trip per four patches, behind the queue of every
+    //  other wave's gather reads.  They now stay in the register pair they arrive in -- lane i = entries 4 i .. 4 i + 3 -- and
+    //  quad c comes out of it with two v_readlane)
     __shared__ int rcount;
     // Small batches (fewer blocks than the chip holds): the listed regions of an (item, angle block) are dealt out to rsplit
     // blocks, each with its own sets of partial sums -- a block's region walk is a chain of ~20 stage / gather rounds, 118 us
@@ -562,11 +566,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 t2 = __builtin_amdgcn_readfirstlane((int)seginfo[wave][ri][1]);
             }
         };
-        // The first 256 entries of a wave's segment travel like the region itself: loaded into a register while the previous
-        // region is gathered, put into LDS between the barriers, read from there (a broadcast ds_read_b64 per four patches).
+        // The first 256 entries of a wave's segment travel like the region itself: loaded into a register pair while the previous
+        // region is gathered (ev), handed over between the barriers (cev), read from there lane by lane (v_readlane).
         // No vector-memory wait inside the gather: that would also wait for the staging loads in flight.
         const uint2 *__restrict__ entries4 = reinterpret_cast<const uint2 *>(entries); // four entries per element
-        uint2 ev = make_uint2(0u, 0u);
+        uint2 ev = make_uint2(0u, 0u), cev = make_uint2(0u, 0u);
         auto entries_load = [&](int t0, int t2) {
             ev = make_uint2(0u, 0u);
             if (t0 + 4 * lane < t2) ev = entries4[(t0 >> 2) + lane];
@@ -584,24 +588,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             }
 #endif
             if (lo < lds_hi) {
-                const uint2 *el = elist[wave];
                 const int n4 = (lds_hi - lo) >> 2;
-                // two quads per trip, each read one quad ahead into its own pair of registers (a single rotating pair costs three
-                // register moves per quad, 6 % of the loop's vector instructions)
-                uint2 e0 = el[0], e1 = el[min(1, n4 - 1)];
-                int c = 0;
-                for (; c + 1 < n4; c += 2) {
-                    rg_gather4(acc, lane_off, e0);
-                    e0 = el[min(c + 2, n4 - 1)];
-                    in_set += 4;
-                    if (in_set == YM_RG_FLUSH) flush();
-                    rg_gather4(acc, lane_off, e1);
-                    e1 = el[min(c + 3, n4 - 1)];
-                    in_set += 4;
-                    if (in_set == YM_RG_FLUSH) flush();
-                }
-                if (c < n4) {
-                    rg_gather4(acc, lane_off, e0);
+                for (int c = 0; c < n4; c++) { // (c is wave-uniform: the lane select of v_readlane is a scalar register)
+                    rg_gather4(acc, lane_off, make_uint2(__builtin_amdgcn_readlane(cev.x, c), __builtin_amdgcn_readlane(cev.y, c)));
                     in_set += 4;
                     if (in_set == YM_RG_FLUSH) flush();
                 }
@@ -622,7 +611,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             entries_load(s0, s2);
             stage_load(rlist[0], bx);
             stage_store(bx);
-            elist[wave][lane] = ev;
+            cev = ev;
         }
         __syncthreads();
         YM_RG_PH(0);
@@ -646,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             YM_RG_PH(3);
             if (has_next) {
                 stage_store(nbx);
-                elist[wave][lane] = ev;
+                cev = ev;
             }
             s0 = n0; s2 = n2;
             YM_RG_PH(4);
