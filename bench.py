@@ -869,8 +869,38 @@ def main():
                     "host_pose_writes_us_per_enqueue": host / reps * 1e6,
                     "what": "every base scan re-posed (one ym_scans_set_poses call) before every enqueue: point cache misses on all of them, no plan replay"}
 
+        def leg_alternating():
+            # one matcher serving both kinds of call in turn: a single match (correlates from the column planes) between two
+            # enqueues of a large batch (window only).  Until round 5 each change of kind dropped everything the matcher knew of
+            # its windows' memory: the batch after a single match rasterised every tile of every item again.
+            n = min(LB, args.batch)
+            b1 = m.make_batch(query, chains[:n])
+            for _ in range(2):
+                b1.run_async(True, True, slot=0)
+                b1.wait(0, per_chain=False)
+                m.match_scan(query, chains[1], True, True)
+            torch.cuda.synchronize()
+            reps, tb, ts = 6, 0.0, 0.0
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                b1.run_async(True, True, slot=0)
+                b1.wait(0, per_chain=False)
+                t2 = time.perf_counter()
+                m.match_scan(query, chains[1], True, True)
+                t3 = time.perf_counter()
+                tb += t2 - t1
+                ts += t3 - t2
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                b1.run_async(True, True, slot=0)
+                b1.wait(0, per_chain=False)
+            only = (time.perf_counter() - t1) / reps
+            return {"chains_per_enqueue": n, "us_per_batch_after_a_single_match": tb / reps * 1e6, "us_per_single_match_after_a_batch": ts / reps * 1e6,
+                    "us_per_batch_alone": only * 1e6, "what": "synchronous calls on ONE matcher: enqueue of %d chains + wait, one match_scan, and again" % n}
+
         if rank == 0 and not args.no_production_legs:
-            sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold)]
+            sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold),
+                          ("cfg2x_alternating", leg_alternating)]
         else:
             sweep_legs = []
         del batches, pbatches

@@ -1187,8 +1187,12 @@ def test_window_only_calls_and_plane_calls_on_one_matcher():
     def same(a, b):
         assert a.response == b.response and a.covariance == b.covariance and a.meta == b.meta
         assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (b.best_pose.x, b.best_pose.y, b.best_pose.euler[-1])
+    # (round 5: which items' planes lag behind is kept per item -- a plane call of 12 items after a window-only call of 80 brings
+    #  items 0 .. 11 up to date and leaves 12 .. 79 behind, the plane call of 30 items after it must still refresh 12 .. 29)
     for k, (n, dx, dy, dt) in enumerate([(80, 0.0, 0.0, 0.0), (1, 0.21, -0.13, 0.03), (80, 0.21, -0.13, 0.03), (50, -0.4, 0.3, -0.06),
-                                         (1, -0.4, 0.3, -0.06), (96, 0.05, 0.02, 0.01), (1, 0.0, 0.0, 0.0)]):
+                                         (1, -0.4, 0.3, -0.06), (96, 0.05, 0.02, 0.01), (1, 0.0, 0.0, 0.0),
+                                         (80, 0.3, 0.1, 0.02), (12, -0.2, 0.25, -0.04), (30, 0.12, -0.3, 0.05), (64, 0.12, -0.3, 0.05),
+                                         (30, -0.1, -0.1, 0.0), (1, 0.02, 0.0, 0.0)]):
         base = [synth.resident_scan(r, (p[0] + dx, p[1] + dy, p[2] + dt)) for r, p in zip(ranges, base_poses)]
         fresh = ScanMatcher({"use_response_expansion": False})
         fresh.debug_option(12, 1)

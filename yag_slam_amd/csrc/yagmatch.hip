@@ -503,6 +503,7 @@ struct ym_matcher {
     bool overlap_lists = true;
     bool staged_queries = true;       // a synchronous match reads a just-created query scan from its staging slot instead of waiting
     int tile_h_forced = 0;            // tests: 32 or 64 rows per raster tile whatever the call
+    int sticky_tall_left = 0;         // small calls that still take the tall tiles of the last large batch (plan_sizes)
     int tall_tiles_min_window = 768;  // window width (cells) from which a batch of 512+ items gets 64-row tiles (256 items: 108 against 111 us of raster)
     YmGeom geom;                 // config part filled at create; window part per call
     std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)
@@ -531,6 +532,11 @@ struct ym_matcher {
     // state of the items past B must survive it.
     std::vector<std::array<int, 4>> item_dirty;
     int tz_covered = 0;
+    // Calls whose correlate stages from the row-major window write the window only (CallPlan::win_only); the column planes of the
+    // items they touch then lag behind.  The knowledge above describes WINDOW memory and stays valid through such calls; what a later
+    // call that reads the planes needs is every tile of ITS items written once more -- item by item, not the whole matcher (round 4
+    // kept the mode in the signature: one single match between two batches of 4096 cost the second a full raster of all 4096 windows)
+    std::vector<unsigned char> planes_stale;
     DevBuf<double2> ctrig;     // (cos, sin) per coarse angle
     DevBuf<int32_t> foffsets;  // fine lookup tables
     DevBuf<int32_t> hypcell;
@@ -919,7 +925,15 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if (wrap) { g.win_origin = 0; g.win_w = g.storage_w; }
     // tall tiles where the raster is throughput-bound and the window large (measured: 4096 items of the default config
     // gain 12 % of the raster, a single match loses 6 us, the loop config's 5 cm windows lose 3 %)
-    P.tile_h = m->tile_h_forced ? m->tile_h_forced : (B >= 512 && g.win_w >= m->tall_tiles_min_window) ? YM_TILE_H_TALL : YM_TILE_H;
+    // (what a matcher knows of its windows' memory is kept per tile: a change of tile height drops it all.  A matcher that serves
+    //  single matches BETWEEN large batches therefore keeps the batches' tall tiles for its next 64 small calls -- 6 us per single
+    //  match against a full raster of every window of the next batch, 2 ms per 4096 items: bench.py, cfg2x_alternating)
+    {
+        bool tall = B >= 512 && g.win_w >= m->tall_tiles_min_window;
+        if (tall) m->sticky_tall_left = 64;
+        else if (m->sticky_tall_left > 0 && g.win_w >= m->tall_tiles_min_window && !call.chain_step) { tall = true; m->sticky_tall_left--; }
+        P.tile_h = m->tile_h_forced ? m->tile_h_forced : tall ? YM_TILE_H_TALL : YM_TILE_H;
+    }
     P.tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
     P.tiles_y = (g.win_w + P.tile_h - 1) / P.tile_h;
     g.pitch = P.tiles_x * YM_TILE_W + 64;
@@ -1446,13 +1460,31 @@ int plan_raster(ym_matcher *m, Slot &slot, CallPlan &P) {
     // the tiling stay the same, otherwise they are cleared
     const size_t per_item = (size_t)tiles_x * tiles_y, ntiles = (size_t)B * per_item;
     // (+ whether the planes are written: after calls that left them out they are stale, and the knowledge below covers both copies)
-    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, (size_t)P.tile_h | (P.win_only ? 0x100u : 0u)};
+    const size_t sig[6] = {(size_t)m->grid.p, (size_t)m->planes.p, P.grid_stride, (size_t)g.pitch, (size_t)g.win_w, (size_t)P.tile_h};
     const bool tz_grow = ntiles > m->tile_zero.cap || ntiles * 8 > m->sub_zero.cap; // (the two grow at different sizes)
     if ((rc = m->tile_zero.ensure(ntiles))) return rc;
     if ((rc = m->sub_zero.ensure(ntiles * 8))) return rc;
     if (tz_grow || std::memcmp(sig, m->tz_sig, sizeof sig) != 0) {
         std::memcpy(m->tz_sig, sig, sizeof sig);
         m->tz_covered = 0;
+        m->planes_stale.clear();
+    }
+    if ((int)m->planes_stale.size() < B) m->planes_stale.resize(B, 0);
+    if (P.win_only) {
+        for (int i = 0; i < B; i++) m->planes_stale[i] = 1; // (their planes are not written by this call)
+    } else {
+        // this call reads (or at least writes) the planes: an item whose planes lag behind forgets what it knows -- every tile of
+        // it is written once, window and planes alike -- in runs of consecutive items
+        for (int i = 0; i < std::min(B, m->tz_covered);) {
+            if (!m->planes_stale[i]) { i++; continue; }
+            int j = i;
+            while (j < std::min(B, m->tz_covered) && m->planes_stale[j]) j++;
+            HIP_TRY(hipMemsetAsync(m->tile_zero.p + (size_t)i * per_item, 0, (size_t)(j - i) * per_item, m->stream));
+            HIP_TRY(hipMemsetAsync(m->sub_zero.p + (size_t)i * per_item * 8, 0, (size_t)(j - i) * per_item * 8, m->stream));
+            for (int t = i; t < j; t++) m->item_dirty[t] = {0, 0, tiles_x - 1, tiles_y - 1};
+            i = j;
+        }
+        for (int i = 0; i < B; i++) m->planes_stale[i] = 0;
     }
     if (B > m->tz_covered) { // items this geometry has not seen yet: unknown memory, every tile is launched once
         HIP_TRY(hipMemsetAsync(m->tile_zero.p + (size_t)m->tz_covered * per_item, 0, (size_t)(B - m->tz_covered) * per_item, m->stream));
@@ -1856,10 +1888,18 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         hipLaunchKernelGGL(ym::gbin_pieces_kernel<true>, pgrid, dim3(YM_GBIN_THREADS), 0, st, r);
         if (P.ga_lds > m->ga_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
             const int want = (int)std::min<size_t>(160 * 1024, P.ga_lds);
+            // (the instantiations for three blocks of eight waves per CU -- 80 VGPRs -- park the staging registers in scratch: 11 GB of
+            //  scratch traffic per launch of 4096 loop-lattice items for 4 % of the kernel's time; only in builds with -DYM_EXPERIMENTAL)
+#ifdef YM_EXPERIMENTAL
+#define YM_GA_512(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER, 512>)
+#else
+#define YM_GA_512(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER>)
+#endif
             const void *kernels[21] = {
-#define YM_GA_BOTH(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER>), reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER, 512>), reinterpret_cast<const void *>(ym::gather_percell_kernel<NA, NP>)
+#define YM_GA_BOTH(NA, NP) reinterpret_cast<const void *>(ym::gather_kernel<NA, NP, YM_GA_PER>), YM_GA_512(NA, NP), reinterpret_cast<const void *>(ym::gather_percell_kernel<NA, NP>)
                 YM_GA_BOTH(1, 1), YM_GA_BOTH(2, 1), YM_GA_BOTH(3, 1), YM_GA_BOTH(4, 1), YM_GA_BOTH(1, 2), YM_GA_BOTH(2, 2), YM_GA_BOTH(1, 3)};
 #undef YM_GA_BOTH
+#undef YM_GA_512
             for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, want));
             m->ga_lds_limit = P.ga_lds;
         }
@@ -1868,10 +1908,15 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         // gather_kernel takes the items whose lists exist and whose hypothesis cells form a lattice (all of them, but for fp
         // rounding accidents and oversized lists), gather_percell_kernel the others: each returns at once from the other's
         // items
+#ifdef YM_EXPERIMENTAL
+#define YM_GA_LAUNCH_512(NA, NP) if (P.ga_nwv <= 8 && m->corr_region_form == 6) hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER, 512>), rgrid, rblock, P.ga_lds, st, r); else
+#else
+#define YM_GA_LAUNCH_512(NA, NP)
+#endif
 #define YM_GA_LAUNCH(NA, NP)                                                                                               \
     do {                                                                                                                   \
-        if (P.ga_nwv <= 8) hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER, 512>), rgrid, rblock, P.ga_lds, st, r); \
-        else hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER>), rgrid, rblock, P.ga_lds, st, r);                   \
+        YM_GA_LAUNCH_512(NA, NP)                                                                                           \
+        hipLaunchKernelGGL((ym::gather_kernel<NA, NP, YM_GA_PER>), rgrid, rblock, P.ga_lds, st, r);                        \
         hipLaunchKernelGGL((ym::gather_percell_kernel<NA, NP>), rgrid, rblock, P.ga_lds, st, r);                           \
     } while (0)
         if (P.ga_np == 1) {
@@ -1884,6 +1929,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
             else YM_GA_LAUNCH(2, 2);
         } else YM_GA_LAUNCH(1, 3);
 #undef YM_GA_LAUNCH
+#undef YM_GA_LAUNCH_512
         return prof_end(m, ev_k);
     }
     if ((rc = prof_begin(m, 0, &ev_k))) return rc;
