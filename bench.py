@@ -414,8 +414,10 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
         loop_m.profile_read(1); loop_m.profile_read(2)
         loop_m.profile(False)
         if corr_n:
-            roof = replayed_roofline("cfg4", "ym::gather_kernel<1, 2, 4>", corr_ms / corr_n * 1e-3,
-                                     "region_correlate_body_alignbyte_form")  # (its loop still funnels with v_alignbyte: that body's peak)
+            # (round 5: the kernel funnels with v_perm like the region correlate -- that loop body's measured peak; its name carries
+            #  the launch bound since then, the tree's older counter files do not)
+            roof = (replayed_roofline("cfg4", "ym::gather_kernel<1, 2, 4, 1024>", corr_ms / corr_n * 1e-3, "region_correlate_body") or
+                    replayed_roofline("cfg4", "ym::gather_kernel<1, 2, 4>", corr_ms / corr_n * 1e-3, "region_correlate_body_alignbyte_form"))
             if roof is not None:
                 nbeams = 1081
                 roof["algorithmic_bytes_per_launch"] = float(hi - lo) * 41 * 41 * 21 * nbeams  # one byte per valid beam and hypothesis

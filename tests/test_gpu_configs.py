@@ -493,3 +493,18 @@ def test_match_pairs_argument_errors():
     per = (_capi.YmResult * 2)()
     assert m._lib.ym_match_pairs(m._m, hq, hs, co, 2, 1, 1, per) == -1  # YM_ERR_INVALID
     assert "query 1 is null" in _capi.last_error()
+
+
+def test_match_pairs_in_the_python_semantics_and_on_the_loop_lattice():
+    """ym_match_pairs outside the default Karto lattice: the reference's in-tree Python semantics (yagpy device path) and the
+    loop-closure config (41 x 41 x 21: the gather correlate, one list set per query) -- every item is its single call."""
+    from yag_slam_amd.scan_matching import ScanMatcher
+    queries, chains = _pairs_workload(72)
+    for kw, n, pen, fine in ((dict(semantics="yagpy"), 9, True, True), (dict(loop=True), 72, False, False), (dict(loop=True), 9, False, False)):
+        m, ms = ScanMatcher(None, **kw), ScanMatcher(None, **kw)
+        per = m.match_pairs(queries[:n], chains[:n], pen, fine)
+        for i in range(n):
+            s = ms.match_scan(queries[i], chains[i], pen, fine)
+            a = per[i]
+            assert a.response == s.response and a.covariance == s.covariance and a.meta == s.meta, (kw, i)
+            assert (a.best_pose.x, a.best_pose.y, a.best_pose.euler[-1]) == (s.best_pose.x, s.best_pose.y, s.best_pose.euler[-1]), (kw, i)

@@ -1756,6 +1756,7 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
     r.rg_h = P.rg_ws ? YM_WS_H : YM_RG_H; r.rg_cls = P.rg_ws ? YM_WS_CLS : P.rg_item ? YM_IT_CLS : YM_RG_CLS;
     r.rg_zero = P.rg_ws ? YM_WS_ZERO : P.rg_item ? YM_IT_ZERO : YM_RG_ZERO; r.pad2 = 0;
     if (P.rg2) { r.rg_h = P.rg2_h; r.rg_cls = YM_RG_PITCH * (P.rg2_h + 26); r.rg_zero = 4 * r.rg_cls; }
+    r.pad2 = ((1 << 21) + r.rg_h - 1) / r.rg_h; // bin_kernel: class row / region height as a multiplication (region_entry)
     r.rg_w = 0; r.rg_pitch = YM_RG_PITCH; r.nregions = P.rg_nregions; r.pad3 = 0;
     r.walk = m->rg_walk.p; r.nitems = P.B; r.rsplit = P.rg_rsplit; r.pad4 = 0;
     // teams of `parts` blocks per XCD: two blocks per CU, no more teams than the XCD gets items

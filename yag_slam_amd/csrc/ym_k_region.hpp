@@ -133,7 +133,8 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
     if (X < 0 || Y < 0) return false;
     const unsigned xc = (unsigned)X >> 1, yc = (unsigned)Y >> 1;
     const unsigned cls = (unsigned)((X & 1) | ((Y & 1) << 1));
-    if (a.rg_w) { // one class image per region
+#ifdef YM_EXPERIMENTAL
+    if (a.rg_w) { // one class image per region (the wave-specialised form)
         const unsigned rx = xc / (unsigned)a.rg_w, ry = yc / (unsigned)a.rg_h;
         if ((int)rx >= a.nrx || (int)ry >= a.nry) return false;
         region = (int)((ry * (unsigned)a.nrx + rx) * 4u + cls);
@@ -143,13 +144,19 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
         entry = er * (unsigned)a.rg_pitch + ex;
         return true;
     }
-    const unsigned rx = xc / (unsigned)YM_RG_W, ry = yc / (unsigned)a.rg_h;
+#endif
+    // (round 5: every product below is of numbers below 2^24 -- v_mul_u32_u24 at the full rate instead of v_mul_lo_u32 at a quarter --
+    //  and the division by the region height is a multiplication by pad2 = ceil(2^21 / rg_h), exact for class rows below 4096:
+    //  the error yc (pad2 rg_h - 2^21) / (2^21 rg_h) stays below 4096 / 2^21 < 1 / rg_h for rg_h <= 255; this kernel is a whole launch of
+    //  4096 blocks when every item of a batch has its own query)
+    if (yc >= 4096u) return false; // (never: a window is at most 4073 cells wide)
+    const unsigned rx = xc / (unsigned)YM_RG_W, ry = __umul24(yc, (unsigned)a.pad2) >> 21;
     if ((int)rx >= a.nrx || (int)ry >= a.nry) return false;
-    region = (int)(ry * (unsigned)a.nrx + rx);
-    bin = region * a.lat.nt + k;
-    er = yc - ry * (unsigned)a.rg_h;
+    region = (int)(__umul24(ry, (unsigned)a.nrx) + rx);
+    bin = (int)__umul24((unsigned)region, (unsigned)a.lat.nt) + k;
+    er = yc - __umul24(ry, (unsigned)a.rg_h);
     ex = xc - rx * YM_RG_W;
-    entry = cls * (unsigned)a.rg_cls + er * YM_RG_PITCH + ex;
+    entry = __umul24(cls, (unsigned)a.rg_cls) + __umul24(er, (unsigned)YM_RG_PITCH) + ex;
     return true;
 }
 
@@ -224,25 +231,31 @@ __global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_kernel(R
             atomicMin(&bx[0], r0); atomicMax(&bx[1], r1); atomicMin(&bx[2], x0); atomicMax(&bx[3], x1);
         }
     };
+    // (the same loop over the points in LDS and, for a query whose points do not fit into the borrowed room, in global memory: written
+    //  once with the source as a parameter -- a select between an LDS and a global POINTER makes every load a flat load)
+    auto pass1 = [&](auto point_of, auto trig_of) {
 #pragma unroll
-    for (int q = 0; q < MAXP; q++) {
-        const int p = p0 + q;
-        key[q] = 0xffffffffu;
-        if (q < per_thread && p < total) {
-            const double2 cs = ql_in_lds ? trigs[k] : trig[k];
-            const double2 pt = ql_in_lds ? qls[i] : ql[i];
-            int bin, region; unsigned e, er, ex;
-            if (region_entry(a, lookup_cell(pt, cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, bin, e, region, er, ex)) {
-                const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
-                key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
-                rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
-                const int bi = region * a.parts + (int)(((unsigned)k * inv_nw) >> 16);
-                if (bi != cur) { send_box(); cur = bi; r0 = r1 = er; x0 = x1 = ex; }
-                else { r0 = min(r0, er); r1 = max(r1, er); x0 = min(x0, ex); x1 = max(x1, ex); }
+        for (int q = 0; q < MAXP; q++) {
+            const int p = p0 + q;
+            key[q] = 0xffffffffu;
+            if (q < per_thread && p < total) {
+                const double2 cs = trig_of(k);
+                const double2 pt = point_of(i);
+                int bin, region; unsigned e, er, ex;
+                if (region_entry(a, lookup_cell(pt, cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, bin, e, region, er, ex)) {
+                    const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
+                    key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
+                    rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
+                    const int bi = (int)(__umul24((unsigned)region, (unsigned)a.parts) + (__umul24((unsigned)k, inv_nw) >> 16));
+                    if (bi != cur) { send_box(); cur = bi; r0 = r1 = er; x0 = x1 = ex; }
+                    else { r0 = min(r0, er); r1 = max(r1, er); x0 = min(x0, ex); x1 = max(x1, ex); }
+                }
             }
+            if (++i >= nq) { i = 0; k++; }
         }
-        if (++i >= nq) { i = 0; k++; }
-    }
+    };
+    if (ql_in_lds) pass1([&](int i_) { return qls[i_]; }, [&](int k_) { return trigs[k_]; });
+    else pass1([&](int i_) { return ql[i_]; }, [&](int k_) { return trig[k_]; });
     send_box();
     __syncthreads();
     {
