@@ -311,7 +311,11 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * from the scan's creation-time structure; 25: tiles added around the raster rectangle a device-chained step predicts
  * (1; negative values make every chained step a fault); 26: 512 = the single-item prepare kernel with 512 threads per
  * scan; 28: batch size from which BOTH LDS correlates replace the direct kernel (at least 8; 0 = the defaults again: gather correlate 64, region correlate 48); 42: the region correlate's threshold alone (0 = 48); 29: 0 = the region path's pair lists are built on the call's stream instead of next to the raster on the matcher's second stream; 31: 0 = a synchronous match waits for the creation launch of a just-created query scan instead of reading its staged readings; 30: rows per raster tile, 32 or 64, whatever the call (0 = the host's choice: 64 for 512+ items over windows of 768+ cells); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
- * (0: it scores them itself unless option 12 asks for the integer sums); 45: 0 = the pair lists of a single-query batch are built at every call (default: a call whose query, pose, window and lattice
+ * (0: it scores them itself unless option 12 asks for the integer sums); 32: form of the region correlate (0 / 1 = correlate_region_kernel; 2 = wave-specialised, 3 = one block per item, 4 = pooled, 5 = sixteen waves
+ * per block with 43 = its region height 80 / 100 / 128 and 44 = the batch size from which it is the default, 6 = the gather correlate
+ * compiled for three blocks per CU -- 2 .. 6 were measured slower or spill and exist only in builds made with -DYM_EXPERIMENTAL
+ * (`make experimental`): the product library answers YM_ERR_UNSUPPORTED);
+ * 45: 0 = the pair lists of a single-query batch are built at every call (default: a call whose query, pose, window and lattice
  * equal those of the matcher's last list build finds the lists in place); 41: items up to which the order-dependent smear
  * rule runs in its split form (8; 0 = one block per item always). */
 int ym_debug_option(ym_matcher *m, int option, int value);
