@@ -780,6 +780,24 @@ def main():
             # the whole step against the same figure: every kernel of the call, launch gaps and host work included
             "algorithmic_frac_step": step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         })
+        # the other kernels of an enqueue, from the same counter passes (durations: the kernel-trace pass of the profiled run, one
+        # enqueue at a time -- these kernels are not timed live): what each is bound by, at a glance
+        ctr = profile_json("counters.json")
+        try:
+            others = {}
+            for kn, kv in ctr["workloads"]["cfg2x"]["kernels"].items():
+                if not kn.startswith("ym::") or kn == kernel or kv.get("us", 0.0) < 30.0 or "structure_kernel" in kn or "points_kernel" in kn:
+                    continue
+                us = kv["us"] if "raster" not in kn else min(kv["us"], kv.get("min_us", kv["us"]) * 1.05)  # (the raster's mean holds a first-call outlier)
+                clk = us * 1e-6 * DEVICE["clock_hz"] * DEVICE["cus"]
+                hb = kv.get("FETCH_SIZE", 0.0) * 2048.0 + kv.get("WRITE_SIZE", 0.0) * 1024.0
+                others[kn] = {"us_in_the_profiled_run": us, "valu_per_cu_clk": kv.get("SQ_INSTS_VALU", 0.0) / clk, "lds_busy": kv.get("SQ_LDS_IDX_ACTIVE", 0.0) / clk,
+                              "vector_l1_line_visits_per_cu_clk": kv.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / clk, "hbm_GBps": hb / (us * 1e-6) / 1e9,
+                              "hbm_frac": hb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "waiting_share_of_wave_time": kv.get("SQ_WAIT_ANY", 0.0) / kv["SQ_WAVE_CYCLES"] if kv.get("SQ_WAVE_CYCLES") else None}
+            rl["other_kernels_of_an_enqueue"] = others
+        except (KeyError, TypeError):
+            pass
         line["roofline"] = rl
         line["config"]["point_cache"] = dict(zip(("hits", "misses"), m.cache_stats()))
 
