@@ -31,6 +31,8 @@ print("correlate_region_kernel, %d items: wave clocks by phase (sum over %d wave
 for n, v in zip(names, ph):
     print("  %-42s %6.1f %%   %9.0f clk per wave" % (n, 100.0 * v / max(tot, 1.0), v / (B * 3 * 8)))
 print("  total %.0f clk per wave = %.1f us at 2.4 GHz" % (tot / (B * 3 * 8), tot / (B * 3 * 8) / 2400.0))
+if st[9]:
+    print("  shader clock the waves ran at: %.3f GHz (sum of s_memtime / sum of s_memrealtime x 100 MHz over the waves' lives)" % (tot / float(st[9]) * 0.1))
 m.profile(True)
 for _ in range(5):
     b.run_async(True, True, slot=0); b.wait(0, per_chain=False)

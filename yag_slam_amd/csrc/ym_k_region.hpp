@@ -467,6 +467,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     uint32_t ph[4] = {0u, 0u, 0u, 0u};
     uint32_t pt = (uint32_t)__builtin_amdgcn_s_memtime();
     const uint32_t pt_begin = pt;
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime(); // (100 MHz: against the shader clocks of pt it gives the clock the wave ran at)
 #endif
     const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
     if (regular) {
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         if (a.stamps && lane == 0) {
             for (int i = 0; i < 4; i++) atomicAdd(a.stamps + 10 + i, (unsigned long long)ph[i]);
             atomicAdd(a.stamps + 8, (unsigned long long)(pt - pt_begin)); // the wave's whole life
+            atomicAdd(a.stamps + 9, __builtin_amdgcn_s_memrealtime() - rt_begin); // ... in 100 MHz ticks
         }
     };
 #endif
