@@ -24,7 +24,7 @@
 namespace ym {
 
 #define YM_IT_NW 16                          // waves per block
-#define YM_IT_LPS 36                         // rows the staging threads of a class image cover at once (216 of its 256 threads copy)
+#define YM_IT_LPS ((YM_RG_ROWS + 2) / 3)     // rows the staging threads of a class image cover at once (three bands; 36 rows = 216 of its 256 threads copy)
 #define YM_IT_IMG_ROWS (3 * YM_IT_LPS)       // rows of a class image in LDS: three bands, >= YM_RG_ROWS, so that no copy task leaves its image
 #define YM_IT_CLS (YM_RG_PITCH * YM_IT_IMG_ROWS)
 #define YM_IT_ZERO (4 * YM_IT_CLS)           // LDS offset of the all-zero patch

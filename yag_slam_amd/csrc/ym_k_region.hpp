@@ -48,7 +48,9 @@ namespace ym {
 #define YM_RG_PRIO 0
 #endif
 #define YM_RG_W 64                            // region width and height in class bytes (128 x 160 window cells): what three
+#ifndef YM_RG_H
 #define YM_RG_H 80                            // blocks per CU leave room for in LDS
+#endif
 #define YM_RG_PITCH 100                       // LDS bytes per staged row: 25 dwords, odd -> 26 rows on 26 distinct banks
 #define YM_RG_ROWS (YM_RG_H + 26)             // + the patch height
 #define YM_RG_SEGS 6                          // 16-byte blocks staged per row (96 >= 64 + 26 + 3)
