@@ -1638,6 +1638,6 @@ def test_pair_lists_kept_from_call_to_call_are_invisible():
 def test_long_lived_matcher_through_random_call_sequences(seed):
     """tests/soak.py: 70 random calls (single matches, one-query and multi-query batches of every size class, resident batches run
     again, pose writes in between) on ONE matcher give what a matcher that forgets everything between calls gives, bit for bit
-    (scripts/dev/soak_calls.py runs the same for many seeds: 6000 calls without a difference at the end of round 5)."""
+    (scripts/dev/soak_calls.py runs the same for many seeds: 51 000 calls over 170 seeds without a difference at the end of round 5)."""
     from tests import soak
     assert soak.run(seed, 70, NCH=320, verbose=False) == 0
