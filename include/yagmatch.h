@@ -317,8 +317,19 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  * (`make experimental`): the product library answers YM_ERR_UNSUPPORTED);
  * 45: 0 = the pair lists of a single-query batch are built at every call (default: a call whose query, pose, window and lattice
  * equal those of the matcher's last list build finds the lists in place); 41: items up to which the order-dependent smear
- * rule runs in its split form (8; 0 = one block per item always). */
+ * rule runs in its split form (8; 0 = one block per item always);
+ * 46: YM_SEM_YAGPY matchers: 0 = the coarse pass of every item is scored pair by pair (the Python rule as written); default 1 = its
+ * integer sums come from the production correlate kernels wherever the item's roundings provably form a lattice (ym_debug_counters). */
 int ym_debug_option(ym_matcher *m, int option, int value);
+
+/* counters since ym_create, out[0 .. min(count, YM_DEBUG_COUNTERS)):
+ *   [0] YM_SEM_YAGPY items whose coarse sums came from the production correlate kernels, [1] items that fell back to the pair-by-pair
+ *   kernel (a rounding tie that falls differently along the lattice, a read outside the device window, an np.arange longer than the launch
+ *   lattice), [2] (point, angle) pairs that needed the hypothesis-by-hypothesis check, [3] pairs that failed it;
+ *   [4] single-query batches that found their pair lists in place (option 45);
+ *   [5] the coarse correlate the LAST call launched: 0 correlate_kernel, 1 correlate_region_kernel, 2 gather_kernel, -1 none */
+#define YM_DEBUG_COUNTERS 8
+int ym_debug_counters(ym_matcher *m, int64_t *out, int32_t count);
 
 /* development aid: 100 MHz wall-clock stamps written by block 0 of each kernel at phase boundaries.
  * Reads the stamps of the last call into out[0..count) (count <= 32), then switches stamping on/off. */

@@ -282,6 +282,92 @@ def test_yagpy_device_matches_reference_goldens(name):
         assert np.array_equal(np.isfinite(got), np.isfinite(cov)) and np.array_equal(np.isnan(got), np.isnan(cov))
 
 
+# Round 6: the HOT correlate kernels against reference-made numbers.  In "yagpy" semantics the coarse pass's integer sums come
+# from the production correlate kernels wherever the item's roundings provably form a lattice (ym_k_yagpy.hpp, yag_lattice_kernel):
+# correlate_kernel on single matches, correlate_region_kernel on batches over lattices up to 26 x 32, gather_kernel on the others --
+# the same selection as in Karto semantics.  Every route must give the sum volume the reference's own score_world_points_on_grid
+# produced (tests/golden/make_golden.py: coarse_sums of the small cases; make_golden_sums.py: full-size volumes of both passes),
+# with no item falling back to the pair-by-pair kernel.
+SUM_CASES = ["sums_cfg2", "sums_dirty_rot", "sums_far", "sums_loop", "sums_near_threshold"]
+SUM_SMALL = ["small_pen0_fine1", "small_pen1_fine1", "small_dirty_rot"]
+YAG_ROUTES = ["pairwise", "direct", "region", "gather"]
+
+
+@pytest.mark.parametrize("route", YAG_ROUTES)
+@pytest.mark.parametrize("name", SUM_CASES + SUM_SMALL)
+def test_yagpy_coarse_sums_through_the_production_kernels(name, route):
+    from tests.util import load_case
+    from yag_slam_amd.scan_matching import ScanMatcher
+    c = load_case(name)
+    z = c["z"]
+    want = z["coarse_sums"].astype(np.int64)
+    nt, ny, nx = want.shape
+    m = ScanMatcher(c["cfg"], semantics="yagpy")
+    q, base = _mk_native(c["query"]), [_mk_native(b) for b in c["base"]]
+
+    def check_result(r):
+        assert r.meta["coarse_dims"] == (nx, ny, nt)
+        assert abs(r.response - float(z["response"])) <= 1e-12
+        bp = r.best_pose
+        np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], z["best_pose"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.array(r.covariance), z["covariance"], rtol=1e-9, atol=1e-15)
+
+    if route in ("pairwise", "direct"):
+        if route == "pairwise":
+            m.debug_option(46, 0)  # the Python rule as written: every (hypothesis, point) pair rounded on its own
+        r = m.match_scan(q, base, c["penalty"], c["do_fine"])
+        cnt = m.debug_counters()
+        assert cnt["last_correlate"] == (None if route == "pairwise" else "correlate_kernel")
+        assert (cnt["yag_fast_items"], cnt["yag_fallback_items"]) == ((0, 0) if route == "pairwise" else (1, 0))
+        assert np.array_equal(m.debug_sums(0, dims=r.meta["coarse_dims"]).astype(np.int64), want)
+        if c["do_fine"] and "fine_sums" in z.files:
+            assert np.array_equal(m.debug_sums(1, dims=r.meta["fine_dims"]).astype(np.int64), z["fine_sums"])
+        check_result(r)
+        return
+    # batches: nine items -- seven copies of the golden problem, one with a shorter chain, one copy more -- through the LDS correlates
+    m.debug_option(28, 8)  # (both LDS correlates from 8 items on; production takes them from 48 / 64)
+    if route == "gather":
+        m.debug_option(14, 4)  # the gather correlate also where the region correlate would run
+    chains = [base] * 7 + [base[:2]] + [base]
+    per, _ = m.match_scan_batch(q, chains, c["penalty"], c["do_fine"])
+    cnt = m.debug_counters()
+    fits_region = name != "sums_loop"  # (its launch lattice is 41 x 41: beyond the region correlate's 26 x 32, the gather correlate's domain)
+    assert cnt["last_correlate"] == ("correlate_region_kernel" if route == "region" and fits_region else "gather_kernel")
+    assert (cnt["yag_fast_items"], cnt["yag_fallback_items"]) == (9, 0)
+    for i in (0, 3, 6, 8):
+        assert np.array_equal(m.debug_sums(0, item=i, dims=per[i].meta["coarse_dims"]).astype(np.int64), want), i
+        check_result(per[i])
+    # the shorter chain: against the pair-by-pair kernel (a single call with the production routes off)
+    ref = ScanMatcher(c["cfg"], semantics="yagpy")
+    ref.debug_option(46, 0)
+    r7 = ref.match_scan(q, base[:2], c["penalty"], c["do_fine"])
+    assert np.array_equal(m.debug_sums(0, item=7, dims=per[7].meta["coarse_dims"]), ref.debug_sums(0, dims=r7.meta["coarse_dims"]))
+    assert per[7].response == r7.response and per[7].covariance == r7.covariance
+    assert (per[7].best_pose.x, per[7].best_pose.y, per[7].best_pose.euler[-1]) == (r7.best_pose.x, r7.best_pose.y, r7.best_pose.euler[-1])
+
+
+def test_yagpy_irregular_items_fall_back_to_the_pairwise_kernel():
+    """A reading placed so that hypothesis (0, 0) rounds a TIE (x.5 cells) cannot be proven regular by the guard; the exhaustive
+    check then decides.  Either way the results must be the pair-by-pair kernel's, and the counters must say what happened."""
+    from tests.util import load_case
+    from yag_slam_amd.scan_matching import ScanMatcher
+    c = load_case("small_pen1_fine1")
+    cfg = dict(c["cfg"], resolution=0.25, smear_deviation=0.25, search_size=1.0, range_threshold=4.0)
+    # poses and readings that are exact binary fractions: sums like 0.125 + k * 0.25 sit exactly on cell boundaries
+    mk = lambda r, p: _mk_native(PlainScan(r, 0.0, np.pi / 6, 0.05, 4.0, p))
+    base = [mk(np.full(7, 1.125), (0.0, 0.0, 0.0))]
+    q = mk(np.array([1.125, 1.0, 0.875, 1.125, 1.25, 1.125, 1.0]), (0.125, 0.0, 0.0))
+    fast, slow = ScanMatcher(cfg, semantics="yagpy"), ScanMatcher(cfg, semantics="yagpy")
+    slow.debug_option(46, 0)
+    a, b = fast.match_scan(q, base, True, True), slow.match_scan(q, base, True, True)
+    cnt = fast.debug_counters()
+    assert cnt["yag_pairs_checked"] > 0, cnt  # ties were met ...
+    assert cnt["yag_fast_items"] + cnt["yag_fallback_items"] == 1
+    assert a.meta["coarse_dims"] == b.meta["coarse_dims"]
+    assert np.array_equal(fast.debug_sums(0, dims=a.meta["coarse_dims"]), slow.debug_sums(0, dims=b.meta["coarse_dims"]))  # ... and nothing changed
+    assert a.response == b.response and a.covariance == b.covariance
+
+
 def test_yagpy_device_matches_oracle_both_passes():
     from oracle import oracle as orc
     from tests.util import load_case

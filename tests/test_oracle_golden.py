@@ -208,3 +208,29 @@ def test_guard_switch_covers_expansion_clamp_and_empty_scan():
     empty = mk(np.full(101, np.nan), (0.1, 0.0, 0.0))
     rk = orc.Oracle(cfg, delta_mask=0).match_scan(empty, base, True, False)
     assert rk["hypotheses"] == 0 and rk["cov"][0, 0] == 500.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 6: full-size sum volumes of BOTH passes from the reference's own scoring function (tests/golden/make_golden_sums.py:
+# the BASELINE default lattice 25 x 25 x 10 on 1081 beams, dirty + rotated, far from the origin, the loop-closure lattice
+# 40 x 40 x 10, a query that reaches the edge of the grid).  The oracle's all-Python setting must reproduce them bit for bit.
+SUM_CASES = ["sums_cfg2", "sums_dirty_rot", "sums_far", "sums_loop", "sums_near_threshold"]
+
+
+@pytest.mark.parametrize("name", SUM_CASES)
+def test_oracle_reproduces_the_reference_sum_volumes(name):
+    c = load_case(name)
+    z = c["z"]
+    o = orc.Oracle(c["cfg"], "yagpy")
+    r = o.match_scan(c["query"], c["base"], c["penalty"], c["do_fine"])
+    g = o.grid_f64()
+    assert g.shape[0] == int(z["grid_size"]) and int(np.count_nonzero(g)) == int(z["grid_nonzero"])
+    assert int(np.sum((100 * g).astype(np.int64))) == int(z["grid_sum100"])
+    s0 = o.sums(0)
+    assert s0.shape == z["coarse_sums"].shape and np.array_equal(s0.astype(np.int64), z["coarse_sums"])
+    if c["do_fine"]:
+        s1 = o.sums(1)
+        assert s1.shape == z["fine_sums"].shape and np.array_equal(s1.astype(np.int64), z["fine_sums"])
+    assert abs(r["response"] - float(z["response"])) <= 1e-12
+    np.testing.assert_allclose(r["pose"], z["best_pose"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r["cov"], z["covariance"], rtol=1e-9, atol=1e-15)

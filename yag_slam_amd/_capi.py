@@ -22,7 +22,7 @@ EXPORTS = (
     "ym_batch_run_async", "ym_batch_wait", "ym_debug_grid_info",
     "ym_debug_grid", "ym_debug_sums", "ym_debug_query_local", "ym_debug_cells", "ym_debug_option", "ym_debug_stamps",
     "ym_profile_enable",
-    "ym_profile_read", "ym_cache_stats",
+    "ym_profile_read", "ym_cache_stats", "ym_debug_counters",
     "ym_coarse_dims", "ym_match_slice_begin", "ym_match_slice_finish",
     "ym_occupancy_create", "ym_occupancy_get_info", "ym_occupancy_read", "ym_occupancy_destroy",
     "ym_map_from_occupancy", "ym_map_from_grid", "ym_map_size", "ym_map_read", "ym_map_destroy", "ym_match_map",
@@ -182,6 +182,7 @@ def lib():
     L.ym_profile_enable.argtypes = [vp, C.c_int]
     L.ym_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), C.c_int]
     L.ym_cache_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.ym_debug_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
     L.ym_coarse_dims.argtypes = [vp, ip]
     L.ym_scan_structure_trusted.argtypes = [vp, C.c_int]
     L.ym_process_scan.argtypes = [vp, vp, C.POINTER(vp), C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(YmResult)]

@@ -597,6 +597,11 @@ struct ym_matcher {
     DevBuf<double> resp;
     DevBuf<double> blockmax;
     DevBuf<double> probs;
+    // yagpy: the coarse pass's integer sums come from the production correlate kernels where the item's roundings provably form a
+    // lattice (ym_k_yagpy.hpp, yag_lattice_kernel); option 46 = 0: every item through yag_score_kernel, the rule as written
+    int yag_fast = 1;
+    int last_corr_form = -1; // which coarse correlate the last call launched: 0 correlate_kernel, 1 correlate_region_kernel, 2 gather_kernel, -1 none
+    DevBuf<unsigned long long> yag_counters; // [0] items through the production kernels, [1] fallbacks, [2] pairs checked exhaustively, [3] pairs that failed
     DevBuf<double> yaxes;      // yagpy: xvals, yvals, tvals per item
     DevBuf<double2> yrot;      // yagpy: points rotated per angle
     DevBuf<double> seq_pose;   // device-chained sequences: [0..2] the next step's odometry prior, [4 + 3k ..] the pose step k of the segment found
@@ -901,6 +906,16 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         lc.step_x = lc.step_y = coarse_step;
         lc.angle_res = m->cfg.coarse_angle_resolution;
         lf.fine = 1;
+        if (m->yag_fast) {
+            // the lattice the production correlate kernels are launched on: len(np.arange(-s + c, s + c, step)) = ceil(((s + c) - (-s + c)) / step)
+            // is floor(2 s / step) + 1 or -- where 2 s / step is an integer and the subtraction rounds down -- one less
+            // (/root/reference/yag_slam/helpers.py:177-179); an item whose own lengths exceed it is scored by yag_score_kernel
+            lc.nx = lc.ny = (int)std::floor(m->cfg.search_size / coarse_step + 1e-6) + 1;
+            lc.nt = (int)std::floor(m->cfg.coarse_search_angle_offset / m->cfg.coarse_angle_resolution + 1e-6) + 1;
+            lc.off_x = lc.off_y = coarse_off;
+            lc.angle_off = 0.5 * m->cfg.coarse_search_angle_offset;
+            if (lc.nx > YM_YAG_MAX_DIM || lc.nt > YM_MAX_COARSE_NT) lc.nx = lc.ny = lc.nt = 0; // (the bounds check below refuses such a matcher anyway)
+        }
     } else {
         lc = make_lattice(g, coarse_off, coarse_step, call.coarse_angle_off, m->cfg.coarse_angle_resolution, 0,
                           call.penalize);
@@ -912,7 +927,8 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
 
     // ---- device window: the central part of Karto's storage the query endpoints can reach
     const int centre = g.border + (g.roi_w - 1) / 2;
-    const double reach = rq + coarse_off + (yag ? 3 : 1) * g.res; // yagpy's fine pass reaches 2 cells past the coarse box
+    const double reach = rq + coarse_off + (yag ? 3 : 1) * g.res; // yagpy's fine pass reaches 2 cells past the coarse box (and the launch
+                                                                  // lattice of its coarse pass one step = 2 cells past the last real hypothesis)
     int wh = (int)std::ceil(reach / g.res) + 3;
     // (in steps of 64 cells: the window -- and with it the "this tile is zero" knowledge about its memory -- then stays
     //  the same from match to match while the queries' longest readings differ by less)
@@ -1022,7 +1038,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         // by the per-cell path)
         P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
         P.rg_nbins = P.rg_nregions * lc.nt;
-        P.region26 = !wrap && !yag && !P.dedup && !call.slice && P.sx == 2 && B >= m->rg_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
+        P.region26 = !wrap && (!yag || lc.nx > 0) && !P.dedup && !call.slice && P.sx == 2 && B >= m->rg_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
                      lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
         if (P.region26) {
             // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
@@ -1052,7 +1068,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         }
     }
     // Other batches on lattices of at most 48 x 64: the general form (ym_k_gather.hpp).
-    P.region = !wrap && !P.region26 && !yag && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
+    P.region = !wrap && !P.region26 && (!yag || lc.nx > 0) && !call.slice && P.sx == 2 && B >= m->lds_min_batch && m->corr_region != 1 && lc.nx <= 16 * YM_GA_MAX_SEG && lc.ny <= 64;
     if (P.region) {
         // lanes: a lane owns 16 x-adjacent hypotheses of one lattice row; a group of 32 lanes = up to 32 rows of one
         // segment (conflict-free LDS reads), or the rows past 32 of several segments; a wave = two groups
@@ -1169,9 +1185,13 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->foffsets.ensure((size_t)B * lf.nt * max_n))) return rc;
     if ((rc = m->hypcell.ensure((size_t)B * 2 * P.dim_stride))) return rc;
     if ((rc = m->partial.ensure((size_t)B * P.partial_stride + 16))) return rc;
-    if ((rc = m->sums.ensure((size_t)B * std::max(P.sums_c + P.sums_f, 2 * P.yvol)))) return rc;
+    if ((rc = m->sums.ensure((size_t)B * std::max(P.sums_c + P.sums_f, 2 * P.yvol + (yag ? P.sums_c : 0))))) return rc; // (yagpy: [pass 0][pass 1][launch lattice])
     if ((rc = m->resp.ensure((size_t)B * std::max(P.sums_c, P.yvol)))) return rc;
     if (yag) {
+        if (!m->yag_counters.p) {
+            if ((rc = m->yag_counters.ensure(8))) return rc;
+            HIP_TRY(hipMemsetAsync(m->yag_counters.p, 0, m->yag_counters.cap * sizeof(unsigned long long), m->stream));
+        }
         if ((rc = m->yaxes.ensure((size_t)B * 3 * YM_YAG_MAX_DIM))) return rc;
         if ((rc = m->yrot.ensure((size_t)B * P.ymaxt * max_n))) return rc;
     }
@@ -1179,7 +1199,7 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;
     P.resp = call.ext_resp ? call.ext_resp : m->resp.p;
     P.probs = call.ext_probs ? call.ext_probs : m->probs.p;
-    P.fuse_score = P.region26 && !P.rg_ws && P.rg_rsplit == 1 && !m->keep_sums && m->corr_fuse_score != 2;
+    P.fuse_score = P.region26 && !P.rg_ws && P.rg_rsplit == 1 && !m->keep_sums && m->corr_fuse_score != 2 && !yag; // (yagpy scores the integer sums its own way)
     P.k_begin = call.slice ? std::max(0, call.k_begin) : 0;
     P.k_end = call.slice ? std::min(lc.nt, call.k_end) : lc.nt;
     if (call.slice && (yag || B != 1)) return set_err(YM_ERR_UNSUPPORTED, "angle-sliced matches are single Karto matches");
@@ -1713,8 +1733,11 @@ int enqueue_raster(ym_matcher *m, const CallPlan &P) {
     return prof_end(m, ev_k);
 }
 
+int enqueue_correlate(ym_matcher *m, const CallPlan &P);
+void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P);
+
 // ---- the Python matcher's two find_best_pose passes (scan_matching.py:204-214)
-void enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
+int enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
     const Call &call = slot.call;
     const YmGeom &g = P.g;
     m->sums_pass_offset[0] = 0;
@@ -1737,9 +1760,22 @@ void enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
         a.grid = m->grid.p; a.grid_stride = P.grid_stride; a.vol_stride = P.yvol;
         a.max_n = P.max_n; a.maxd = P.ymaxd; a.maxt = P.ymaxt;
         hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(P.ymaxt, P.B), dim3(256), 0, m->stream, a);
+        if (pass == 0 && P.lc.nx > 0) {
+            // the coarse pass's integer sums from the production correlate kernels (the one the batch size and the lattice select, as in
+            // Karto semantics) for every item whose roundings yag_lattice_kernel proves to form a lattice; yag_score_kernel then
+            // scores those sums the Python way and computes the other items' itself
+            a.lat_nx = P.lc.nx; a.lat_ny = P.lc.ny; a.lat_nt = P.lc.nt; a.step_cells = P.sx;
+            a.nt_stride = P.nt_stride; a.dim_stride = P.dim_stride; a.ctrig = m->ctrig.p; a.hypcell = m->hypcell.p;
+            a.lsums = m->sums.p + (size_t)2 * P.B * P.yvol; a.lsums_stride = P.sums_c; a.counters = m->yag_counters.p;
+            hipLaunchKernelGGL(ym::yag_lattice_kernel, dim3(P.B), dim3(256), 0, m->stream, a);
+            int rc = enqueue_correlate(m, P);
+            if (rc) return rc;
+            enqueue_score(m, slot, P);
+        }
         hipLaunchKernelGGL(ym::yag_score_kernel, dim3((P.ymaxd * P.ymaxd + 255) / 256, P.ymaxt, P.B), dim3(256), 0, m->stream, a);
         hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(P.B), dim3(1024), 0, m->stream, a);
     }
+    return YM_OK;
 }
 
 // ---- K4 coarse correlate
@@ -1769,10 +1805,12 @@ int enqueue_region_lists(ym_matcher *m, const CallPlan &P, hipStream_t st) {
     const ym::RegionArgs r = region_args(m, P);
     const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nregions * P.rg_parts);
     if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
         m->bin_lds_limit = bin_lds;
     }
-    hipLaunchKernelGGL(ym::bin_kernel, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
+    if (P.yag) hipLaunchKernelGGL(ym::bin_kernel<true>, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
+    else hipLaunchKernelGGL(ym::bin_kernel<false>, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
 #ifdef YM_EXPERIMENTAL
     if (P.rg_ws) hipLaunchKernelGGL(ym::region_walk_kernel, dim3(P.rg_parts, P.n_qslots), dim3(64), 0, st, r);
 #endif
@@ -1810,6 +1848,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
     if (a.nk == 0) return YM_OK; // an empty angle slice
     int rc;
     hipEvent_t ev_k = nullptr;
+    m->last_corr_form = P.region26 ? 1 : P.region ? 2 : 0;
     if (P.region26) {
         const ym::RegionArgs r = region_args(m, P);
         if (P.lists_on_side_stream) HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
@@ -1879,7 +1918,7 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
         r.W = P.ga_W; r.H = P.ga_H; r.P = P.ga_P; r.rows = P.ga_rows; r.nrx = P.ga_nrx; r.nry = P.ga_nry; r.nseg = P.ga_nseg; r.NP = P.ga_np;
         r.ng = P.ga_ng; r.parts = P.ga_parts; r.kpp = P.ga_kpp; r.unit_cap = P.ga_cap;
         r.force_irregular = (m->corr_region == 2 || m->corr_region == 3) ? m->corr_region - 1 : 0; r.stamps = P.stamps;
-        r.sums = m->keep_sums ? m->sums.p : nullptr; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
+        r.sums = P.yag ? m->sums.p + (size_t)2 * P.B * P.yvol : m->keep_sums ? m->sums.p : nullptr; r.resp = P.resp; r.sums_stride = P.sums_c; r.blockmax = m->blockmax.p;
         r.probs = P.probs; r.probs_stride = (size_t)P.lc.nx * P.lc.ny; r.n_blocks = P.score_blocks;
         // the lists: once per query slot of the call (they depend on the query alone)
         HIP_TRY(hipMemsetAsync(m->ga_counters.p, 0, (size_t)P.n_qslots * 4 * P.ga_nbins2 * YM_GA_CLS * sizeof(uint32_t), st));
@@ -1960,13 +1999,16 @@ int enqueue_correlate(ym_matcher *m, const CallPlan &P) {
 void enqueue_score(ym_matcher *m, Slot &slot, const CallPlan &P) {
     hipStream_t st = m->stream;
     const YmLattice &lc = P.lc;
-    m->sums_pass_offset[0] = 0;
-    m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
+    if (!P.yag) {
+        m->sums_pass_offset[0] = 0;
+        m->sums_pass_offset[1] = (size_t)P.B * P.sums_c;
+    }
     ym::ScoreArgs a;
     a.g = P.g; a.lat = lc; a.partial = m->partial.p; a.partial_stride = P.partial_stride; a.states = m->states.p;
     // (the integer sums are kept for ym_debug_sums on a few items of an ordinary lattice; on configs[4]'s 1.86 million hypotheses
     //  they are a sixth of this stage's writes: debug option 12 keeps them there too)
     a.sums = (m->keep_sums || (P.B < 8 && P.sums_c <= 65536)) ? m->sums.p : nullptr;
+    if (P.yag) a.sums = m->sums.p + (size_t)2 * P.B * P.yvol; // (the launch lattice's sums: what yag_score_kernel scores the Python way)
     a.sums_stride = P.sums_c; a.resp = P.resp; a.blockmax = m->blockmax.p;
     a.n_chunks = P.n_groups; a.nx_pad = P.nx_pad; a.n_blocks = P.score_blocks; a.stamps = P.stamps;
     a.probs = P.probs; a.probs_stride = (size_t)lc.nx * lc.ny;
@@ -2030,6 +2072,7 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     CallPlan P;
     int rc;
     mark(0);
+    m->last_corr_form = -1;
     if ((rc = plan_sizes(m, slot, P))) return rc;
     mark(1);
     // a resident batch again, no scan moved, no cache slot changed hands, nothing was left to fill: last time's plan holds
@@ -2086,7 +2129,7 @@ int launch_call_body(ym_matcher *m, Slot &slot) {
     if (lists_aside && (rc = enqueue_region_lists_joined(m, P))) return rc;
     emark(2);
     if (P.yag) {
-        enqueue_yagpy_passes(m, slot, P);
+        if ((rc = enqueue_yagpy_passes(m, slot, P))) return rc;
         emark(3); emark(4); emark(5);
     } else {
         if ((rc = enqueue_correlate(m, P))) return rc;
@@ -2464,7 +2507,7 @@ void ym_destroy(ym_matcher *m) {
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
     m->ctrig.release(); m->foffsets.release(); m->hypcell.release(); m->partial.release(); m->sums.release();
     m->resp.release(); m->blockmax.release(); m->probs.release(); m->tmp_ranges.release();
-    m->tmp_ranges_host.release(); m->kernel_f_dev.release(); m->map_pts.release(); m->cache_arena.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
+    m->tmp_ranges_host.release(); m->kernel_f_dev.release(); m->map_pts.release(); m->yag_counters.release(); m->cache_arena.release(); m->stamps.release(); m->yaxes.release(); m->yrot.release();
     for (Slot &s : m->slots) {
         s.desc.release();
         s.desc_dev.release();
@@ -3514,6 +3557,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
     else if (option == 45) { m->list_cache_on = value != 0; m->list_key_valid = false; }
+    else if (option == 46) m->yag_fast = value != 0;
     else if (option == 43) m->rg2_h = value;
     else if (option == 44) {
 #ifndef YM_EXPERIMENTAL
@@ -3594,6 +3638,23 @@ int ym_profile_read(ym_matcher *m, int which, double *ms_total, int64_t *launche
 int ym_sequence_stats(const ym_matcher *m, int64_t *segments, int64_t *faults, int64_t *sync_steps) {
     if (!m || !segments || !faults || !sync_steps) return set_err(YM_ERR_INVALID, "null argument");
     *segments = m->seq_segments; *faults = m->seq_faults; *sync_steps = m->seq_sync_steps;
+    return YM_OK;
+}
+
+int ym_debug_counters(ym_matcher *m, int64_t *out, int32_t count) {
+    if (!m || !out || count < 0) return set_err(YM_ERR_INVALID, "bad argument");
+    int64_t v[YM_DEBUG_COUNTERS];
+    std::memset(v, 0, sizeof v);
+    if (m->yag_counters.p) {
+        DEV_GUARD(m->device);
+        unsigned long long c[4];
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        HIP_TRY(hipMemcpy(c, m->yag_counters.p, sizeof c, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; i++) v[i] = (int64_t)c[i];
+    }
+    v[4] = m->list_cache_hits;
+    v[5] = m->last_corr_form;
+    for (int i = 0; i < std::min<int>(count, YM_DEBUG_COUNTERS); i++) out[i] = v[i];
     return YM_OK;
 }
 

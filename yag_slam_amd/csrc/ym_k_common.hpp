@@ -159,6 +159,30 @@ __device__ __forceinline__ int lookup_offset(double2 p, double cosine, double si
     return gx + gy * pitch;
 }
 
+// The lookup cell of one (point, angle) pair in either semantics.
+// Karto (GridIndexLookup::ComputeOffsets): the cell displacement of the rotated point, WorldToGrid(rot + gridOffset); the hypothesis
+// cells (hyp_cell) are added to it.
+// "yagpy": the reference's Python matcher rounds every (hypothesis, point) pair on its own -- score_world_points_on_grid,
+// /root/reference/yag_slam/helpers.py:149-153: np.round(((xvals[i] + xx) - ox) / res), half to even -- so a lookup table exists only
+// where those roundings form a lattice: rint(((xvals[i] + xx) - ox) / res) == rint(((xvals[0] + xx) - ox) / res) + i * step_cells for
+// every i.  yag_lattice_kernel (ym_k_yagpy.hpp) PROVES that per (point, angle) pair before any production correlate kernel may treat
+// the item as regular; the lookup cell is then the WINDOW cell hypothesis (0, 0) reads (add = xvals[0], yvals[0]: YmItemState::ylat)
+// and the hypothesis cells are i * step_cells.  The rotation is the expression of helpers.py:76-78 (the operands of its products and
+// sums commuted, which changes no bit).
+__device__ __forceinline__ int2 lookup_cell_sem(const YmGeom &g, double2 p, double cosine, double sine, double off_x, double off_y,
+                                                double add_x, double add_y) {
+    const double ox = cosine * p.x - sine * p.y;
+    const double oy = sine * p.x + cosine * p.y;
+    if (g.semantics == 1 /* YM_SEM_YAGPY */)
+        return make_int2((int)rint(((add_x + ox) - off_x) / g.res) - g.win_origin, (int)rint(((add_y + oy) - off_y) / g.res) - g.win_origin);
+    return make_int2(world_to_grid(ox + off_x, off_x, g.scale), world_to_grid(oy + off_y, off_y, g.scale));
+}
+__device__ __forceinline__ int lookup_offset_sem(const YmGeom &g, double2 p, double cosine, double sine, double off_x, double off_y,
+                                                 double add_x, double add_y, int pitch) {
+    const int2 c = lookup_cell_sem(g, p, cosine, sine, off_x, off_y, add_x, add_y);
+    return c.x + c.y * pitch;
+}
+
 // ScanMatcher::GetResponse reads pByte[offset] after the test IsUpTo(gridPositionIndex + offset, data size) on the LINEAR
 // index: an offset that leaves the grid sideways wraps into a neighbouring row.  Inside the device window no offset of a
 // reading within the matcher's range threshold ever leaves it, so the fast kernels need no test and the per-cell paths test

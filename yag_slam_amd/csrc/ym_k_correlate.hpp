@@ -124,6 +124,9 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
     {
         const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
         const double off_x = st.off_x, off_y = st.off_y;
+        // ("yagpy" items proven regular: the lookup cell is the window cell hypothesis (0, 0) reads, ym_k_common.hpp)
+        const bool yag = a.g.semantics == 1;
+        const double add_x = yag ? st.ylat[0] : off_x, add_y = yag ? st.ylat[1] : off_y;
         const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
         const bool dedup = SX == 2 && a.dedup && regular; // (host: only with chunk == 64)
         if (dedup) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
                 const bool valid = i < nq;
                 int o = 0;
                 if (valid) {
-                    const int l = lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, a.g.pitch) + cx0;
+                    const int l = lookup_offset_sem(a.g, ql[i], cs.x, cs.y, off_x, off_y, add_x, add_y, a.g.pitch) + cx0;
                     o = (l >> 1) + (l & 1) * plane_bytes;
                 }
                 const int prev = __shfl_up(o, 1);
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(YM_CORR_THREADS) void correlate_kernel(CorrArgs a) 
         for (int e = threadIdx.x; e < cw * a.chunk; e += YM_CORR_THREADS) {
             const int ci = e / a.chunk, c = e - ci * a.chunk;
             const int i = (group * cw + ci) * a.chunk + c;
-            int o = i < nq ? lookup_offset(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale, regular ? a.g.pitch : lin_pitch(a.g)) : 0;
+            int o = i < nq ? lookup_offset_sem(a.g, ql[i], cs.x, cs.y, off_x, off_y, add_x, add_y, regular ? a.g.pitch : lin_pitch(a.g)) : 0;
             if (SX == 2 && regular) {
                 // window-linear index of hypothesis column 0 for this beam -> (plane, index in plane)
                 const int l = o + cx0;

@@ -115,14 +115,16 @@ __global__ __launch_bounds__(YM_GBIN_THREADS) void gbin_pieces_kernel(GatherArgs
     const double off_x = st.off_x, off_y = st.off_y;
     const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     const double2 cs = a.ctrig[(size_t)b * a.nt_stride + k];
-    const int2 c = lookup_cell(ql[i], cs.x, cs.y, off_x, off_y, a.g.scale);
+    const bool yag = a.g.semantics == 1; // ("yagpy" items proven regular: ym_k_common.hpp, lookup_cell_sem)
+    const double add_x = yag ? st.ylat[0] : off_x, add_y = yag ? st.ylat[1] : off_y;
+    const int2 c = lookup_cell_sem(a.g, ql[i], cs.x, cs.y, off_x, off_y, add_x, add_y);
     if (i > 0) {
-        const int2 pc = lookup_cell(ql[i - 1], cs.x, cs.y, off_x, off_y, a.g.scale);
+        const int2 pc = lookup_cell_sem(a.g, ql[i - 1], cs.x, cs.y, off_x, off_y, add_x, add_y);
         if (pc.x == c.x && pc.y == c.y) return; // inside a run
     }
     int m = 1;
     for (int j = i + 1; j < nq; j++) {
-        const int2 nc = lookup_cell(ql[j], cs.x, cs.y, off_x, off_y, a.g.scale);
+        const int2 nc = lookup_cell_sem(a.g, ql[j], cs.x, cs.y, off_x, off_y, add_x, add_y);
         if (nc.x != c.x || nc.y != c.y) break;
         m++;
     }
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(1024) void gather_percell_kernel(GatherArgs a) {
                     const int base = cy[row] * lin_pitch(a.g) + cx[ix];
                     unsigned sum = 0;
                     for (int i = i0; i < i1; i++)
-                        sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
+                        sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset_sem(a.g, ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.semantics == 1 ? st.ylat[0] : st.off_x, a.g.semantics == 1 ? st.ylat[1] : st.off_y, lin_pitch(a.g))));
                     // hypothesis j of dword j >> 2: even ones in E (low / high half), odd ones in S
                     if ((j & 1) == 0) E[n][p2][j >> 2] += sum << (8 * (j & 2));
                     else S[n][p2][j >> 2] += sum << (8 * (j & 2));

@@ -169,6 +169,9 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
 // never meets a ragged group.  An item whose padded list would not fit -- the buffers, one angle's share the ng sets of
 // 16-bit sums the gather may fill, or more regions with work than a correlate block can list -- gets starts[nbins] = -1 and is scored by the per-cell path of correlate_region_kernel.
+// YAG: the lookup cells of the reference's Python matcher (items yag_lattice_kernel proved regular; ym_k_common.hpp, lookup_cell_sem) --
+// a template parameter, so that the Karto instantiation, a whole launch of the metric workload, stays the code it was.
+template <bool YAG = false>
 __global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_kernel(RegionArgs a) {
     constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
     // dynamic LDS (YM_BIN_LDS_BYTES: sized by the host so that two blocks share a CU on the usual lattice):
@@ -244,7 +247,8 @@ __global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_kernel(R
                 const double2 cs = trig_of(k);
                 const double2 pt = point_of(i);
                 int bin, region; unsigned e, er, ex;
-                if (region_entry(a, lookup_cell(pt, cs.x, cs.y, off_x, off_y, a.g.scale), cx0, cy0, k, bin, e, region, er, ex)) {
+                const int2 lc = YAG ? lookup_cell_sem(a.g, pt, cs.x, cs.y, off_x, off_y, st.ylat[0], st.ylat[1]) : lookup_cell(pt, cs.x, cs.y, off_x, off_y, a.g.scale);
+                if (region_entry(a, lc, cx0, cy0, k, bin, e, region, er, ex)) {
                     const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
                     key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
                     rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
                 unsigned sum = 0;
                 const int i1 = min(nq, (g + 1) * YM_RG_FLUSH);
                 for (int i = g * YM_RG_FLUSH; i < i1; i++)
-                    sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
+                    sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset_sem(a.g, ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.semantics == 1 ? st.ylat[0] : st.off_x, a.g.semantics == 1 ? st.ylat[1] : st.off_y, lin_pitch(a.g))));
                 acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
             }
             flush();
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(64 * YM_WS_NG) void region_percell_kernel(RegionArg
                 unsigned sum = 0;
                 const int i1 = min(nq, (gs + 1) * YM_RG_FLUSH);
                 for (int i = gs * YM_RG_FLUSH; i < i1; i++)
-                    sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset(ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.scale, lin_pitch(a.g))));
+                    sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset_sem(a.g, ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.semantics == 1 ? st.ylat[0] : st.off_x, a.g.semantics == 1 ? st.ylat[1] : st.off_y, lin_pitch(a.g))));
                 acc[2 * (j >> 2) + (j & 1)] += sum << (16 * ((j >> 1) & 1));
             }
         rg_odd(acc);

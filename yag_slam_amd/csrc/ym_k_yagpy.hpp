@@ -7,8 +7,12 @@ namespace ym {
 // ================================================================== "yagpy" semantics
 // The reference's in-tree Python matcher (/root/reference/yag_slam/helpers.py:156-295 find_best_pose,
 // scan_matching.py:175-222).  Unlike Karto it rounds every (hypothesis, point) pair separately
-// (helpers.py:149-153), so the gather address is recomputed in fp64 per pair; this path exists for
-// parity with the reference-generated golden vectors, not for speed.
+// (helpers.py:149-153), so the gather address is a function of the pair.  yag_score_kernel recomputes it in fp64 per pair
+// (the rule as written).  Round 6: the COARSE pass's integer sums come from the production correlate kernels
+// (correlate_kernel, correlate_region_kernel, gather_kernel) wherever yag_lattice_kernel can PROVE that the item's roundings
+// form a lattice -- every hot correlate kernel is then checked bit for bit against sum volumes the reference's own
+// score_world_points_on_grid produced (tests/golden/*.npz: coarse_sums) -- and from yag_score_kernel for the items it cannot
+// (counted: ym_debug_counter).  Arg-max, tie mean and covariances stay yag_reduce_kernel's: the Python path's own rules.
 struct YagArgs {
     YmGeom g;
     int32_t pass;        // 0 coarse, 1 fine
@@ -34,6 +38,17 @@ struct YagArgs {
     // to the coarse pass whatever the map's resolution); the penalty is centred on the search centre.
     int32_t map_w, map_h;
     double map_ox, map_oy, map_res;
+    // the coarse pass through the production correlate kernels (pass 0, lat_nx > 0): the lattice those kernels are launched on
+    // (np.arange lengths vary from item to item by one: the launch lattice holds every item's, the surplus hypotheses are computed and
+    // never read), its cell step, the tables yag_lattice_kernel fills for them and the sums they leave
+    int32_t lat_nx, lat_ny, lat_nt, step_cells;
+    int32_t nt_stride, dim_stride;
+    double2 *ctrig;          // [B][nt_stride]
+    int32_t *hypcell;        // [B][2][dim_stride]
+    const uint32_t *lsums;   // [B][lat_nt][lat_ny][lat_nx] integer sums of the launch lattice (score_kernel / score_hyp_kernel / gather_kernel)
+    size_t lsums_stride;
+    unsigned long long *counters; // [0] items whose coarse pass went through the production kernels, [1] items that fell back to yag_score_kernel,
+                                  // [2] (point, angle) pairs that needed the exhaustive check, [3] pairs that failed it
 };
 
 // numpy.arange(start, stop, step) for float64: length and i-th value (DOUBLE_fill)
@@ -76,8 +91,81 @@ __global__ __launch_bounds__(256) void yag_setup_kernel(YagArgs a) {
     }
 }
 
+// When do the roundings of the coarse pass form a lattice?  (helpers.py:149-153 with x = xvals[i] + xx, helpers.py:194-196.)
+// For a (point, angle) pair with rotated coordinate r, hypothesis i of an axis reads cell
+//     c(i) = rint(u(i)),   u(i) = fl(fl(fl(xv[i] + r) - o) / res),   xv[i] = numpy.arange's i-th value (yag_arange_at).
+// The production correlate kernels need c(i) = c(0) + i * s for every i of the lattice (s = step / res cells, an integer: 2).
+// With e = 2^-53 and M >= every magnitude that occurs (|xv[i]|, |xv[i] + r|, |x - o|, the search size):
+//     xv[i] = start + i * step + delta_i, |delta_i| <= (2 i + 2) e M   (yag_arange_at: second = fl(start + step), d = fl(second - start),
+//                                                                       xv[i] = fl(start + fl(i * d)): four roundings, two of them i times)
+//     u(i)  = (xv[i] + r - o) / res up to three more roundings: e M / res each,
+// and step / res = 2 exactly (step is the doubled resolution), so |u(i) - (u(0) + i * s)| <= (2 n + 8) e M / res for every i < n.
+// Hence |u(0) - rint(u(0))| < 0.5 - guard, guard >= that bound, proves the pair for all i at once (no u(i) can reach a tie).  A pair
+// that fails the test is not irregular yet: it is then checked hypothesis by hypothesis (x and y are separable: nx + ny roundings).
+// Only a pair that fails THAT -- a genuine tie that falls differently along the axis -- makes its item irregular, and the item is
+// scored by yag_score_kernel as before.  The guard used is 8 (n + 8) e M / res + 2^-40: about four times the bound.
+// M = |ox| + |oy| + 2 G res: the search box lies within G res / 2 of the query pose = ox + (G - 1) res / 2, and a read inside the
+// window (tested first) has |x - o| <= G res.
+// Every read must also stay inside the device window for every hypothesis of the LAUNCH lattice (the production kernels test no
+// bounds; cells outside the window are provably empty, DESIGN.md section 3, but their memory is another item's).
+// grid (B), 256 threads.  Runs after yag_setup_kernel (axes, ydims, rot) of pass 0.
+__global__ __launch_bounds__(256) void yag_lattice_kernel(YagArgs a) {
+    constexpr int NT = 256;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    YmItemState &st = a.states[b];
+    const int nx = st.ydims[0][0], ny = st.ydims[0][1], nt = st.ydims[0][2], nq = st.nq;
+    const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
+    const double xv0 = ax[0], yv0 = ax[YM_YAG_MAX_DIM];
+    const double ct = st.pose[2];
+    // (cos, sin) per angle of the launch lattice: the operands yag_setup_kernel rotated the points with
+    for (int k = tid; k < a.lat_nt; k += NT) {
+        const double t = yag_arange_at(-a.search_t + ct, a.step_t, k);
+        a.ctrig[(size_t)b * a.nt_stride + k] = make_double2(cos(t), sin(t));
+    }
+    int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    int32_t *cy = cx + a.dim_stride;
+    for (int i = tid; i < a.lat_nx; i += NT) cx[i] = i * a.step_cells;
+    for (int i = tid; i < a.lat_ny; i += NT) cy[i] = i * a.step_cells;
+    int ok = nx > 0 && ny > 0 && nt > 0 && nx <= a.lat_nx && ny <= a.lat_ny && nt <= a.lat_nt;
+    const double ox = st.off_x, oy = st.off_y, res = a.g.res;
+    const double M = fabs(ox) + fabs(oy) + 2.0 * a.g.roi_w * res;
+    const double guard = 8.0 * (max(nx, ny) + 8) * M * 1.1102230246251565e-16 / res + 9.094947017729282e-13;
+    const int w0 = a.g.win_origin, ww = a.g.win_w;
+    const int span_x = (a.lat_nx - 1) * a.step_cells, span_y = (a.lat_ny - 1) * a.step_cells;
+    unsigned slow = 0, bad = 0;
+    if (ok)
+        for (int p = tid; p < nq * nt; p += NT) {
+            const int k = p / nq, l = p - k * nq;
+            const double2 r = a.rot[((size_t)b * a.maxt + k) * a.max_n + l];
+            const double ux = ((xv0 + r.x) - ox) / res, uy = ((yv0 + r.y) - oy) / res;
+            const double gx = rint(ux), gy = rint(uy);
+            // the window test in fp64 first: a cell number beyond int would be undefined behaviour below
+            if (!(gx >= (double)w0 && gx + span_x < (double)(w0 + ww) && gy >= (double)w0 && gy + span_y < (double)(w0 + ww))) { ok = 0; bad++; continue; }
+            const bool fast_x = fabs(ux - gx) < 0.5 - guard, fast_y = fabs(uy - gy) < 0.5 - guard;
+            if (fast_x && fast_y) continue;
+            slow++;
+            bool good = true;
+            if (!fast_x)
+                for (int i = 1; i < nx; i++) good = good && rint(((ax[i] + r.x) - ox) / res) == gx + (double)(i * a.step_cells);
+            if (!fast_y)
+                for (int i = 1; i < ny; i++) good = good && rint(((ax[YM_YAG_MAX_DIM + i] + r.y) - oy) / res) == gy + (double)(i * a.step_cells);
+            if (!good) { ok = 0; bad++; }
+        }
+    ok = __syncthreads_and(ok);
+    if (a.counters) {
+        if (slow) atomicAdd(&a.counters[2], (unsigned long long)slow);
+        if (bad) atomicAdd(&a.counters[3], (unsigned long long)bad);
+    }
+    if (tid == 0) {
+        st.regular[0] = ok;
+        st.ylat[0] = xv0; st.ylat[1] = yv0;
+        if (a.counters) atomicAdd(&a.counters[ok ? 0 : 1], 1ull);
+    }
+}
+
 // grid (ceil(maxd*maxd/256), maxt, B): one thread per hypothesis (ix, iy) of angle k.
 // helpers.py:134-153: per point rint((p - o)/res), bounds check, int(100*cell) accumulate.
+// (pass 0 with lsums: the items yag_lattice_kernel proved regular take their sums from the production correlate kernels' volume.)
 __global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
     const int b = blockIdx.z, k = blockIdx.y;
     const YmItemState &st = a.states[b];
@@ -96,6 +184,8 @@ __global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
     const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
     const int np = st.nq;
     unsigned sum = 0;
+    if (a.lsums && st.regular[0]) sum = a.lsums[(size_t)b * a.lsums_stride + ((size_t)k * a.lat_ny + iy) * a.lat_nx + ix];
+    else
 #pragma unroll 4
     for (int l = 0; l < np; l++) {
         const double2 p = rot[l];

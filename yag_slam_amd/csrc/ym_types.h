@@ -106,4 +106,7 @@ struct YmItemState {
     int32_t ydims[2][3];  // nx, ny, nt
     int32_t ypad[2];
     double ybest[2][8];   // response, x, y, t, xx, yy, xy, th
+    // ... and, when the coarse pass goes through the production correlate kernels (yag_lattice_kernel): xvals[0], yvals[0] of the
+    // coarse lattice -- the lookup cell of a (point, angle) pair is the cell hypothesis (0, 0) reads (ym_k_common.hpp, lookup_cell_sem)
+    double ylat[2];
 };

@@ -467,6 +467,14 @@ class ScanMatcher(object):
         _capi.check(self._lib.ym_cache_stats(self._m, C.byref(h), C.byref(ms)))
         return int(h.value), int(ms.value)
 
+    def debug_counters(self):
+        """dict of the matcher's counters since it was created (include/yagmatch.h, ym_debug_counters)"""
+        buf = (C.c_int64 * 8)()
+        _capi.check(self._lib.ym_debug_counters(self._m, buf, 8))
+        return dict(yag_fast_items=int(buf[0]), yag_fallback_items=int(buf[1]), yag_pairs_checked=int(buf[2]),
+                    yag_pairs_failed=int(buf[3]), list_cache_hits=int(buf[4]),
+                    last_correlate={-1: None, 0: "correlate_kernel", 1: "correlate_region_kernel", 2: "gather_kernel"}[int(buf[5])])
+
     def profile(self, on=True):
         _capi.check(self._lib.ym_profile_enable(self._m, int(bool(on))))
 
