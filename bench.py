@@ -313,11 +313,11 @@ def leg_cfg3(m, ranges, n):
     them to rounding (its odometry priors are composed on the device)."""
     from yag_slam_amd import synth
     from yag_slam_amd.mapping import SequentialMapper
+    from yag_slam_amd.models import native_many
     out = {}
     for driver in ("device_chain", "library_loop", "per_scan_calls"):
         truth, scans = synth.trajectory_scans(n, ranges=ranges)
-        for s in scans:
-            s.native(m.device)
+        native_many(scans, m.device)
         mapper = SequentialMapper(m)
         t0 = time.perf_counter()
         if driver == "per_scan_calls":
@@ -347,9 +347,8 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     from yag_slam_amd import synth
     lo, hi, ranges = gen["cfg4"]
     query, chains = synth.loop_batch_scans(args.cfg4_chains, lo, hi, scene=gen["scene"], ranges=ranges)
-    for ch in chains:
-        for s in ch:
-            s.native(loop_m.device)
+    from yag_slam_amd.models import native_many
+    native_many([s for ch in chains for s in ch], loop_m.device)
     sh = ymdist.ShardedLoopMatcher.from_local_shard(loop_m, query, chains, lo, args.cfg4_chains, rank, world)
     reps = 16  # (the first enqueue's host work is not hidden behind a predecessor: enough repetitions to amortise it)
     records = torch.zeros((reps, ymdist.RECORD), dtype=torch.float64, device="cuda")
@@ -542,7 +541,8 @@ def main():
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline leg: no spinning OpenMP workers
     from yag_slam_amd import dist as ymdist
     from yag_slam_amd import synth
-    from yag_slam_amd.scan_matching import ScanMatcher
+    from yag_slam_amd.models import ScanBlock, native_many
+    from yag_slam_amd.scan_matching import MatchBatch, ScanMatcher
 
     props = torch.cuda.get_device_properties(local_rank)
     DEVICE["cus"] = int(props.multi_processor_count)
@@ -582,9 +582,10 @@ def main():
         q_ranges, q_prior, base_poses, noisy = gen["cfg2"]
         query = synth.resident_scan(q_ranges, q_prior)
         chains = [[synth.resident_scan(r, p) for r, p in zip(ch, base_poses)] for ch in noisy]
-        for ch in chains:
-            for s in ch:
-                s.native(local_rank)
+        t_create = time.perf_counter()
+        native_many([s for ch in chains for s in ch], local_rank)  # (ym_scans_create: one upload and one launch per 2048 scans)
+        line["setup"] = {"scans_created": sum(len(ch) for ch in chains), "seconds": time.perf_counter() - t_create,
+                         "how": "models.native_many -> ym_scans_create (round 5: one ym_scan_create launch per scan, ~20 us each)"}
 
     # ---------------------------------------------------------------- the metric line: cfg2 x batch
     if "cfg2x" in legs:
@@ -606,8 +607,7 @@ def main():
         if "cfg2_queries" in gen:
             dq_ranges, dq_prior = gen["cfg2_queries"]
             dqueries = [synth.resident_scan(r, p) for r, p in zip(dq_ranges, dq_prior)]
-            for s_ in dqueries:
-                s_.native(local_rank)
+            native_many(dqueries, local_rank)
             pbatches = [lanes[e % NL].make_pairs_batch(dqueries[e * LB:(e + 1) * LB], chains[e * LB:(e + 1) * LB]) for e in range(E)]
         headline_distinct = args.headline == "distinct_queries" and pbatches is not None
         nslots = min(64, 2 * ((E + NL - 1) // NL))
@@ -802,7 +802,7 @@ def main():
         line["config"]["point_cache"] = dict(zip(("hits", "misses"), m.cache_stats()))
 
         # ---- what production would see of this workload (same run, after the timed region of the metric)
-        def timed_enqueues(bs, n):
+        def timed_enqueues(bs, n, m=m):
             """n back-to-back enqueues cycling over the batch objects `bs` on matcher m; seconds per enqueue, GPU ms per call"""
             for i in range(min(8, n)):  # (every result slot the timed loop uses has met a call of this size: its pinned buffers exist)
                 bs[i % len(bs)].run_async(True, True, slot=i % 8)
@@ -918,9 +918,115 @@ def main():
             return {"chains_per_enqueue": n, "us_per_batch_after_a_single_match": tb / reps * 1e6, "us_per_single_match_after_a_batch": ts / reps * 1e6,
                     "us_per_batch_alone": only * 1e6, "what": "synchronous calls on ONE matcher: enqueue of %d chains + wait, one match_scan, and again" % n}
 
+        def leg_yagpy():
+            # the metric workload in the REFERENCE'S PYTHON semantics (Scan2DMatcherPy.match_scan, /root/reference/yag_slam/scan_matching.py:175-222:
+            # coarse 25 x 25 x 10 + fine ~5 x 5 x 10): the semantics whose integer sum volumes are pinned on reference-made vectors, through the
+            # same production correlate kernel as the metric line (items whose roundings yag_lattice_kernel proves to form a lattice), beside
+            # the pair-by-pair kernel that evaluates the Python rule as written (debug option 46 = 0)
+            n = min(LB, args.batch)
+            out = {"what": "%d independent matches per enqueue (own query each), \"yagpy\" semantics; the coarse sums of every item proven regular "
+                           "come from correlate_region_kernel, of the others from yag_score_kernel" % n, "items_per_enqueue": n}
+            for label, fast in (("production_kernels", 1), ("pairwise_kernel", 0)):
+                ym = ScanMatcher(None, semantics="yagpy", device=local_rank)
+                ym.set_stream(stream.cuda_stream)
+                ym.debug_option(46, fast)
+                try:
+                    pb = ym.make_pairs_batch(dqueries[:n], chains[:n])
+                    per_, _, _ = (pb.run_async(True, True, slot=0) or pb.wait(0))
+                    hyp = int(sum(p_.meta["hypotheses"] for p_ in per_))
+                    sec, gpu_ms = timed_enqueues([pb], 10 if fast else 4, m=ym)
+                    cnt = ym.debug_counters()
+                    out[label] = {"hypotheses_per_s": hyp / sec, "us_per_enqueue": sec * 1e6, "gpu_us_per_enqueue": gpu_ms * 1e3, "hypotheses_per_enqueue": hyp,
+                                  "scan_matches_per_s": n / sec, "items_through_the_production_kernels": cnt["yag_fast_items"],
+                                  "items_that_fell_back": cnt["yag_fallback_items"], "pairs_checked_exhaustively": cnt["yag_pairs_checked"],
+                                  "coarse_correlate": cnt["last_correlate"], "first_item": {"response": per_[0].response, "coarse_dims": per_[0].meta["coarse_dims"]}}
+                finally:
+                    ym.close()
+            a_, b_ = out["production_kernels"], out["pairwise_kernel"]
+            out["identical_first_item"] = a_["first_item"] == b_["first_item"]
+            out["speedup_over_the_pairwise_kernel"] = b_["us_per_enqueue"] / a_["us_per_enqueue"]
+            return out
+
+        def leg_fresh_scans():
+            # the realistic form of the metric workload: N robots, one FRESH scan each per step.  Every enqueue creates its 4096 query
+            # scans from host arrays (ym_scans_create: host-side box / longest reading / beam spacing per scan, one upload, one launch
+            # per 2048 scans), builds the pairs batch, enqueues it, and -- once its results are in -- destroys batch and scans
+            # (ym_scans_destroy).  Creation, batch building and destruction are INSIDE the timed loop.  One Python thread per lane (ctypes
+            # releases the GIL): what a node serving many robots does.  The chains stay resident (the robots' running chains).
+            import threading
+            n = min(LB, args.batch)
+            nl = max(1, args.lanes)
+            sensor = (synth.MIN_ANGLE, synth.MAX_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, synth.MAX_RANGE, synth.RANGE_THRESHOLD)
+            R = np.ascontiguousarray(np.stack(dq_ranges[:args.batch]))
+            Pq = np.ascontiguousarray(np.asarray(dq_prior[:args.batch], dtype=np.float64))
+            groups = max(1, args.batch // n)
+            chain_h = [np.array([s_.native(local_rank) for ch in chains[g * n:(g + 1) * n] for s_ in ch], dtype=np.uint64) for g in range(groups)]
+            offs = np.arange(n + 1, dtype=np.int32) * len(chains[0])
+            lms = [ScanMatcher(None, device=local_rank) for _ in range(nl)]
+            t_create = [0.0] * nl
+            results = [None] * nl
+
+            def lane(li, reps):
+                lm = lms[li]
+                live = []
+                tc = 0.0
+                for i in range(reps):
+                    g = (li + i * nl) % groups
+                    t1 = time.perf_counter()
+                    blk = ScanBlock(R[g * n:(g + 1) * n], Pq[g * n:(g + 1) * n], sensor, device=local_rank)
+                    tc += time.perf_counter() - t1
+                    hb = MatchBatch.from_handles(lm, blk.handles, chain_h[g], offs)
+                    if len(live) == 2:  # two enqueues in flight per lane
+                        ob, oblk, osl = live.pop(0)
+                        ob.wait(osl, per_chain=False)
+                        ob.close()
+                        oblk.release()
+                    hb.run_async(True, True, slot=i % 2)
+                    live.append((hb, blk, i % 2))
+                last = None
+                for ob, oblk, osl in live:
+                    last = ob.wait(osl)[0]
+                    ob.close()
+                    oblk.release()
+                t_create[li] = tc / reps
+                results[li] = ((li + (reps - 1) * nl) % groups, last)
+
+            def run_lanes(reps):
+                threads = [threading.Thread(target=lane, args=(li, reps)) for li in range(nl)]
+                t1 = time.perf_counter()
+                for t_ in threads:
+                    t_.start()
+                for t_ in threads:
+                    t_.join()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / (reps * nl)
+
+            # untimed: every matcher sizes its workspace and meets the chains; the scan pool grows to what the lanes keep in flight (the
+            # blocks of destroyed scans come back once every stream has passed them -- the pool never synchronises the device)
+            run_lanes(4)
+            reps = 12
+            sec = run_lanes(reps)
+            # the last enqueue of lane 0 against the resident form of the same items (same readings, same priors, same chains)
+            g, last = results[0]
+            refb = m.make_pairs_batch(dqueries[g * n:(g + 1) * n], chains[g * n:(g + 1) * n])
+            refb.run_async(True, True, slot=0)
+            want = refb.wait(0)[0]
+            same = bool(np.array_equal(want.array["response"], last.array["response"]) and np.array_equal(want.array["pose"], last.array["pose"]) and
+                        np.array_equal(want.array["cov"], last.array["cov"]))
+            for lm in lms:
+                lm.close()
+            hps = hyp_per_match * n / sec
+            return {"what": "%d NEW query scans per enqueue: created (ym_scans_create), matched against resident chains (ym_pairs_create + run) and destroyed "
+                            "(ym_scans_destroy), all inside the timed loop; %d lanes, one Python thread each" % (n, nl),
+                    "scans_created_per_enqueue": n, "us_per_enqueue": sec * 1e6, "hypotheses_per_s": hps, "scan_matches_per_s": n / sec,
+                    "scan_creation_us_per_enqueue_per_thread": float(np.mean(t_create)) * 1e6, "ratio_to_metric_line": hps / line["value"] * world,
+                    "identical_to_the_resident_form": same}
+
         if rank == 0 and not args.no_production_legs:
             sweep_legs = [("cfg2x_batch_sweep", leg_sweep), ("cfg2x_fresh_query", leg_fresh_query), ("cfg2x_cold", leg_cold),
                           ("cfg2x_alternating", leg_alternating)]
+            if dqueries is not None:
+                sweep_legs += [("cfg2x_fresh_scans", leg_fresh_scans), ("cfg2x_yagpy", leg_yagpy)]
         else:
             sweep_legs = []
         del batches, pbatches

@@ -122,6 +122,13 @@ int ym_synchronize(ym_matcher *m);
  * ym_scan_create, and the pool keeps what it has allocated for the life of the process (35 KB per 1081-beam scan alive
  * at the same time). */
 ym_scan *ym_scan_create(int device, const ym_scan_desc *desc);
+/* n scans at once: what n ym_scan_create calls leave behind (the same host code per scan, the same kernel), in one pool transaction,
+ * one upload and one launch per 2048 scans -- the reference builds one C++ scan per Python scan before match_scan
+ * (/root/reference/yag_slam/models.py:25-39); a node that receives the scans of N robots per step, or a map file being loaded,
+ * builds thousands.  out receives n handles.  All or nothing: on failure nothing stays allocated.  The scans come back complete
+ * (nothing of their creation is still in flight).  ym_scans_destroy: n ym_scan_destroy calls in one pool transaction. */
+int ym_scans_create(int device, const ym_scan_desc *descs, int n, ym_scan **out);
+void ym_scans_destroy(ym_scan *const *scans, int n);
 int ym_scan_set_pose(ym_scan *s, double x, double y, double heading);
 /* n poses (x, y, heading) written to n scans in one call -- what the reference does scan by scan after every graph
  * optimisation (/root/reference/yag_slam/graph_slam.py:263-272: `vtx.obj.corrected_pose = ...` for EVERY vertex, one pybind11

@@ -1455,6 +1455,72 @@ def test_scan_pool_staging_and_recycled_blocks_are_invisible():
     assert run(scans) == first
 
 
+def test_bulk_scan_creation_equals_per_scan_creation():
+    """ym_scans_create (one pool transaction, one upload, one launch per 2048 scans) must leave behind exactly what one ym_scan_create
+    per scan does: the same structure info, the same matches -- single calls and the region-staged batch path -- for ordinary scans,
+    dirty ones, scans of other lengths, a scan without a single valid reading, an empty scan; more scans than one chunk holds; blocks
+    recycled between the two ways of creating; the array form (models.ScanBlock) and the bulk destroy."""
+    from yag_slam_amd import _capi, synth
+    from yag_slam_amd.models import LocalizedRangeScan, ScanBlock, native_many
+    from yag_slam_amd.scan_matching import MatchBatch, ScanMatcher
+    L = _capi.lib()
+    scene = synth.Scene()
+    truth, scans = synth.trajectory_scans(130)
+    odd = [synth.resident_scan(scene.scan_ranges(truth[3], index=900, dirty=True), truth[3]),
+           LocalizedRangeScan(scans[5].ranges[:300], synth.MIN_ANGLE, synth.MAX_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, synth.MAX_RANGE, 20.0, *truth[5]),
+           LocalizedRangeScan(np.full(1081, np.nan), synth.MIN_ANGLE, synth.MAX_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, synth.MAX_RANGE, 20.0, *truth[6]),
+           LocalizedRangeScan(np.zeros(0), synth.MIN_ANGLE, synth.MAX_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, synth.MAX_RANGE, 20.0, *truth[7]),
+           LocalizedRangeScan(np.full(5000, 4.0), -3.0, 3.0, 6.0 / 4999, synth.MIN_RANGE, synth.MAX_RANGE, 20.0, *truth[8])]
+    for s, t in zip(scans, truth):  # (matching needs the scans where they were taken)
+        s.corrected_pose = type(s.corrected_pose)(t[0], t[1], 0.0, t[2])
+    everything = scans + odd
+    m = ScanMatcher()
+
+    def observe(seq):
+        out = [tuple(L.ym_scan_structure_trusted(s.native(0), sem) for sem in (0, 1)) for s in seq]
+        for k in range(12, 120, 27):
+            r = m.match_scan(seq[k], seq[k - 10:k], True, True)
+            out.append((r.response, r.best_pose.x, r.best_pose.y, r.best_pose.euler[-1], r.covariance, r.meta))
+        # ragged chains with the odd scans in them, as a batch on the region-staged path (one query each: ym_pairs_create)
+        m.debug_option(28, 8)
+        qs = [seq[20 + i] for i in range(9)]
+        chains = [seq[10 + i:20 + i] for i in range(5)] + [[seq[130 + j]] + seq[15:18] for j in range(4)]
+        per = m.match_pairs(qs, chains, True, True)
+        m.debug_option(28, 0)
+        out.append([(p.response, p.best_pose.x, p.best_pose.y, p.best_pose.euler[-1], p.covariance) for p in per])
+        return out
+
+    for s in everything:
+        s.native(0)
+    one_by_one = observe(everything)
+    for s in everything:
+        s._release()
+    native_many(everything, 0)  # the same scans, in the blocks the first set has just given back
+    assert all(s._native for s in everything)
+    assert observe(everything) == one_by_one
+    # more scans than one chunk (2048) holds, through the array form: every structure word as the per-scan creation reports it
+    n = 2500
+    ranges = np.stack([scans[i % 130].ranges for i in range(n)])
+    poses = np.array([truth[i % 130] for i in range(n)])
+    sensor = (synth.MIN_ANGLE, synth.MAX_ANGLE, synth.ANGLE_INCREMENT, synth.MIN_RANGE, synth.MAX_RANGE, synth.RANGE_THRESHOLD)
+    blk = ScanBlock(ranges, poses, sensor, device=0)
+    assert len(blk) == n and np.all(blk.handles != 0)
+    for i in (0, 1, 129, 2047, 2048, 2049, n - 1):
+        assert tuple(L.ym_scan_structure_trusted(int(blk.handles[i]), sem) for sem in (0, 1)) == one_by_one[i % 130][:2]
+    # ... and matches: items of the block against chains of the block
+    qh = blk.handles[[2060 + k for k in range(8)]]            # = scans 12 .. 19 of the trajectory
+    sh = np.concatenate([blk.handles[2050 + k:2060 + k] for k in range(8)])
+    hb = MatchBatch.from_handles(m, qh, sh, np.arange(9) * 10)
+    hb.run_async(True, True, slot=0)
+    per, _, _ = hb.wait(0)
+    for k in range(8):
+        r = m.match_scan(everything[(2060 + k) % 130], [everything[(2050 + k + j) % 130] for j in range(10)], True, True)
+        assert (r.response, r.covariance) == (per[k].response, per[k].covariance), k
+    hb.close()
+    blk.release()
+    assert len(blk) == 0
+
+
 @pytest.mark.parametrize("seed", [0, 3, 5, 8, 11, 14])
 def test_raster_tile_height_is_invisible(seed):
     """Large batches over large windows rasterise in 64 x 64 tiles, everything else in 64 x 32 (a host decision per call):
@@ -1701,18 +1767,25 @@ def test_pair_lists_kept_from_call_to_call_are_invisible():
             a, b_ = m.match_scan_batch(query, chs, True, True)[0], ref.match_scan_batch(query, chs, True, True)[0]
         assert key(a) == key(b_)
         return key(a)
+    hits = lambda: m.debug_counters()["list_cache_hits"]
     r1 = both(q, chains[:64])
+    assert hits() == 0
     r2 = both(q, chains[64:128])         # same query, other chains: the lists are in place
     assert r1 != r2
+    assert hits() == 1                   # (the cache is really hit: the key compares equal, padding bytes and all)
     both(q, chains[:64])
+    assert hits() == 2
     p = q.corrected_pose
     q.corrected_pose = Transform(p.x + 0.013, p.y - 0.004, 0.0, p.euler[-1] + 0.006)
     r3 = both(q, chains[:64])            # re-posed: built again
     assert r3 != r1
+    assert hits() == 2
     both(q2, chains[:64])                # another query
     both(q, chains[:64])                 # the first again: its lists were overwritten
     both([q, q2] * 32, chains[:64], pairs=True)  # a multi-query call uses the same buffers
+    assert hits() == 2
     both(q, chains[:64])
+    assert hits() == 2                   # (a multi-query call never leaves a usable key behind)
     both(q, chains[:20])                 # the direct kernel (no lists), then the region correlate again
     both(q, chains[:64])
     both(q, chains[:130])                # a larger batch on the same window

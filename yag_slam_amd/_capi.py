@@ -15,7 +15,7 @@ SEM = {"karto": 0, "yagpy": 1}
 
 EXPORTS = (
     "ym_version", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
-    "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scan_set_pose", "ym_scans_set_poses", "ym_scan_get_pose",
+    "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scans_create", "ym_scans_destroy", "ym_scan_set_pose", "ym_scans_set_poses", "ym_scan_get_pose",
     "ym_scan_size", "ym_scan_structure_trusted", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_map_sequence", "ym_process_scan", "ym_sequence_stats", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
     "ym_match_pairs", "ym_pairs_create",
@@ -153,6 +153,9 @@ def lib():
     L.ym_scan_get_pose.argtypes = [vp, dp]
     L.ym_scan_size.argtypes = [vp]
     L.ym_scan_destroy.argtypes = [vp]
+    L.ym_scans_create.argtypes = [C.c_int, vp, C.c_int, vp]
+    L.ym_scans_destroy.argtypes = [vp, C.c_int]
+    L.ym_scans_destroy.restype = None
     L.ym_scan_destroy.restype = None
     L.ym_match.argtypes = [vp, C.POINTER(YmScanDesc), C.POINTER(YmScanDesc), C.c_int, C.c_int, C.c_int,
                            C.POINTER(YmResult)]

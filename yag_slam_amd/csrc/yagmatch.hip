@@ -11,10 +11,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <ctime>
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -136,6 +138,7 @@ struct CallScan {
     int qcache_hint = -1;           // the same three for the scan as the QUERY of a batch
     unsigned char *qcache = nullptr;
     int qstale = 0;
+    uint32_t query_uses = 1;          // batches: how often the scan has been the query of a batch before this call (0: never -- see plan_cache)
     const int32_t *gov = nullptr;     // the scan's pose-independent chain structure (trusted scans) ...
     const int32_t *cidx = nullptr;    // ... its compaction ...
     int cnp = 0;                      // ... and its number of point readings
@@ -288,6 +291,7 @@ struct ym_scan {
     double pose[3];
     double max_valid_karto, max_valid_yagpy;
     double beam_spacing; // median valid reading x angular resolution
+    mutable std::atomic<uint32_t> query_uses{0}; // batches this scan has been a query of (a matcher caches a query's projection from its second use on)
     double lbox[4]; // sensor-frame bounding box (xmin, ymin, xmax, ymax) of every reading that can become a point
     double wbox[4]; // the box at the current pose, in the world: kept with the pose so that a call need not rotate 40 000 boxes
 };
@@ -297,9 +301,12 @@ struct ym_scan {
 // structure_kernel reads them from there (that IS the upload), writes them and the scan's chain structure into a block
 // of the device's scan pool and finally its info words and a serial number into the slot.  Whoever first needs the scan
 // (a matcher building a call, ym_scan_structure_trusted, ym_scan_destroy) waits for the serial number -- normally long
-// there.  Blocks of destroyed scans are parked and become reusable after the next device-wide synchronisation, which
-// the pool performs itself once kRecycleAt blocks are parked (hipFree would synchronise at every destroy).
-// The pool keeps its memory for the life of the process (35 KB per 1081-beam scan ever alive at the same time).
+// there.  Blocks of destroyed scans are parked (hipFree would synchronise at every destroy); once kRecycleAt are parked they are
+// SEALED: an event is recorded on every stream a kernel that reads scan blocks can run on (the matchers register theirs), and when all
+// of a generation's events have completed its blocks serve new scans -- no device-wide synchronisation, so a node that creates and
+// destroys thousands of scans per step (bench.py: cfg2x_fresh_scans) never stalls the lanes that are matching.  (Round 5 synchronised the
+// device instead: every 64th destroyed scan's successor waited for everything in flight.)
+// The pool keeps its memory for the life of the process (35 KB per 1081-beam scan ever alive or parked at the same time).
 struct ScanStage {
     const ym_scan *owner = nullptr; // the scan whose launch last used the slot and has not been waited for
     uint32_t serial = 0;
@@ -324,6 +331,17 @@ struct ScanPool {
     uint32_t next_stage = 0, serial = 0;
     std::unordered_map<size_t, std::vector<void *>> free_blocks; // by block size
     std::vector<std::pair<void *, size_t>> parked;               // of destroyed scans; a kernel in flight may still read them
+    // ym_scans_create: staging buffers (pinned host + device), each [argument records][info words][readings] of one chunk of scans; a call
+    // holds one per chunk in flight (two), several threads may create scans at once
+    struct Bulk { unsigned char *host = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+    static constexpr int kBulkBuffers = 12;
+    Bulk bulk[kBulkBuffers];
+    hipStream_t bulk_streams[2] = {}; // high priority: a creation must not queue behind a lane's 3 ms correlate
+    // recycling without a device-wide synchronisation (see above)
+    struct Sealed { std::vector<hipEvent_t> events; std::vector<std::pair<void *, size_t>> blocks; };
+    std::deque<Sealed> sealed;
+    std::vector<hipStream_t> reader_streams; // the matchers' streams of this device (ym_create, ym_set_stream, the second stream)
+    std::vector<hipEvent_t> event_pool;
 };
 
 ScanPool &scan_pool(int device) {
@@ -366,13 +384,71 @@ void stage_wait(ScanPool &p, ScanStage &st) {
     st.owner = nullptr;
 }
 
-void *pool_block(ScanPool &p, size_t bytes) {
-    std::vector<void *> &f = p.free_blocks[bytes];
-    if (f.empty() && p.parked.size() >= kRecycleAt) {
-        if (hipDeviceSynchronize() == hipSuccess) { // nothing in flight can read a parked block any more
-            for (auto &b : p.parked) p.free_blocks[b.second].push_back(b.first);
-            p.parked.clear();
+// (p.mu held)  sealed generations whose events have all completed: their blocks are free
+void pool_reap(ScanPool &p) {
+    while (!p.sealed.empty()) {
+        ScanPool::Sealed &g = p.sealed.front();
+        for (hipEvent_t e : g.events) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipErrorNotReady) return;
+            if (q != hipSuccess) (void)hipGetLastError(); // (a stream that died: its work is over)
         }
+        for (auto &b : g.blocks) p.free_blocks[b.second].push_back(b.first);
+        for (hipEvent_t e : g.events) p.event_pool.push_back(e);
+        p.sealed.pop_front();
+    }
+}
+// (p.mu held, p's device current)  everything parked so far becomes a generation: free once every stream that may still read it has passed
+void pool_seal(ScanPool &p) {
+    ScanPool::Sealed g;
+    bool ok = true;
+    auto mark = [&](hipStream_t st) {
+        hipEvent_t e = nullptr;
+        if (!p.event_pool.empty()) { e = p.event_pool.back(); p.event_pool.pop_back(); }
+        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+        if (hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); p.event_pool.push_back(e); ok = false; return; }
+        g.events.push_back(e);
+    };
+    for (hipStream_t st : p.reader_streams) mark(st);
+    for (hipStream_t st : p.streams) if (st) mark(st);
+    for (hipStream_t st : p.bulk_streams) if (st) mark(st);
+    mark(nullptr); // the null stream (occupancy rendering, debug copies)
+    if (!ok && hipDeviceSynchronize() != hipSuccess) { // a stream the pool cannot mark: the blunt way -- and if even that fails, keep them parked
+        (void)hipGetLastError();
+        for (hipEvent_t e : g.events) p.event_pool.push_back(e);
+        return;
+    }
+    g.blocks.swap(p.parked);
+    p.sealed.push_back(std::move(g));
+}
+
+// (p.mu held, p's device current)  at least `count` free blocks of `bytes`: what is missing comes as ONE slab (a bulk creation that
+// found the free list short asked hipMalloc for a 4 MB slab per 117 scans: 36 calls per 4096 scans, each a millisecond under load)
+void pool_reserve(ScanPool &p, size_t bytes, size_t count) {
+    std::vector<void *> &f = p.free_blocks[bytes];
+    if (f.size() >= count) return;
+    const size_t missing = std::max(count - f.size(), std::max<size_t>(1, kSlabBytes / bytes));
+    unsigned char *slab = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&slab), missing * bytes) != hipSuccess) { (void)hipGetLastError(); return; } // (pool_block tries again, slab by slab)
+    for (size_t i = missing; i-- > 0;) f.push_back(slab + i * bytes);
+}
+
+void pool_register_stream(int device, hipStream_t st, bool add) {
+    if (!st) return;
+    ScanPool &p = scan_pool(device);
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = std::find(p.reader_streams.begin(), p.reader_streams.end(), st);
+    if (add && it == p.reader_streams.end()) p.reader_streams.push_back(st);
+    if (!add && it != p.reader_streams.end()) p.reader_streams.erase(it);
+}
+
+// (p.mu held, p's device current)  look = false: the caller has just looked for completed generations itself (a bulk creation asks once
+// for all its blocks: an event query per block would cost more than the block)
+void *pool_block(ScanPool &p, size_t bytes, bool look = true) {
+    std::vector<void *> &f = p.free_blocks[bytes];
+    if (f.empty() && look) {
+        if (p.parked.size() >= kRecycleAt) pool_seal(p);
+        pool_reap(p);
     }
     if (f.empty()) {
         const size_t count = std::max<size_t>(1, kSlabBytes / bytes);
@@ -386,19 +462,26 @@ void *pool_block(ScanPool &p, size_t bytes) {
 }
 
 // (p.mu held, p's device current)  block + staging slot + the one launch
+int pool_init(ScanPool &p, int device) {
+    if (p.ready) return YM_OK;
+    for (int i = 0; i < kPoolStreams; i++) HIP_TRY(hipStreamCreateWithFlags(&p.streams[i], hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.stage_host), kStageBytes * kScanStages, hipHostMallocMapped));
+    unsigned char *dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p.stage_host, 0));
+    std::memset(p.stage_host, 0, kStageBytes * kScanStages);
+    for (int i = 0; i < kScanStages; i++) { p.stages[i].host = p.stage_host + kStageBytes * i; p.stages[i].dev = dev + kStageBytes * i; }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_many_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
+    p.device = device;
+    p.ready = true;
+    return YM_OK;
+}
+
 int pool_create_scan(ScanPool &p, ym_scan *s, const double *ranges, size_t total, unsigned char **base_out) {
-    if (!p.ready) {
-        for (int i = 0; i < kPoolStreams; i++) HIP_TRY(hipStreamCreateWithFlags(&p.streams[i], hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.stage_host), kStageBytes * kScanStages, hipHostMallocMapped));
-        unsigned char *dev = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p.stage_host, 0));
-        std::memset(p.stage_host, 0, kStageBytes * kScanStages);
-        for (int i = 0; i < kScanStages; i++) { p.stages[i].host = p.stage_host + kStageBytes * i; p.stages[i].dev = dev + kStageBytes * i; }
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::structure_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)YM_PREP_LDS_BYTES(YM_MAX_BEAMS));
-        p.device = s->device;
-        p.ready = true;
-    }
+    int rc0 = pool_init(p, s->device);
+    if (rc0) return rc0;
     const size_t bytes = align_up(total, 1024);
     unsigned char *base = static_cast<unsigned char *>(pool_block(p, bytes));
     if (!base) return set_err(YM_ERR_HIP, "cannot allocate device ranges");
@@ -1226,7 +1309,11 @@ int plan_cache(ym_matcher *m, Slot &slot, const CallPlan &P) {
     std::vector<unsigned char> role(n, 0); // bit 0: base of some item, bit 1: query of some item (batches only)
     for (const CallItem &it : call.items) {
         for (int j = 0; j < it.base_count; j++) role[it.base_begin + j] |= 1;
-        if (P.B >= 8) role[it.query] |= 2; // a few items: the query is projected by the item's own block
+        // a few items: the query is projected by the item's own block.  A query on its FIRST use in a batch is projected into the call's
+        // own buffer and gets no slot of the point cache: a node that matches every incoming scan once and drops it (bench.py,
+        // cfg2x_fresh_scans: 4096 new scans per enqueue) would otherwise fill the cache with 70 MB of dead entries per enqueue, and every
+        // doubling of the arena costs a device synchronisation and the re-projection of every resident scan
+        if (P.B >= 8 && call.scans[it.query].query_uses > 0) role[it.query] |= 2;
     }
     struct Want { int scan, kind; };
     std::vector<Want> wants;
@@ -1821,6 +1908,7 @@ int enqueue_region_lists(ym_matcher *m, const CallPlan &P, hipStream_t st) {
 int enqueue_region_lists_aside(ym_matcher *m, CallPlan &P) {
     if (!m->side_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        pool_register_stream(m->device, m->side_stream, true);
         HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     }
@@ -2479,6 +2567,7 @@ ym_matcher *ym_create(const ym_config *cfg, int device) {
         return nullptr;
     }
     m->stream = m->own_stream;
+    pool_register_stream(device, m->own_stream, true);
     if (upload_lut(m) != YM_OK) { ym_destroy(m); return nullptr; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ym::select_relax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384);
@@ -2502,6 +2591,10 @@ void ym_destroy(ym_matcher *m) {
     if (!m) return;
     DevGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->side_stream) (void)hipStreamSynchronize(m->side_stream);
+    pool_register_stream(m->device, m->stream, false);
+    pool_register_stream(m->device, m->own_stream, false);
+    pool_register_stream(m->device, m->side_stream, false);
     m->ktab.release(); m->rowtab.release(); m->desc_dev.release(); m->states.release(); m->qlocal.release(); m->qnp.release(); m->tmp_cache.release(); m->cells.release(); m->bbox.release(); m->grid.release(); m->planes.release(); m->tile_zero.release(); m->sub_zero.release(); m->tile_list.release(); m->tile_count.release(); m->tile_max.release(); m->tile_hits.release(); m->sel_scratch.release(); m->sel_tables.release(); m->sel_rec.release(); m->sel_slot.release();
     m->rg_entries.release(); m->rg_starts.release(); m->rg_rbox.release(); m->rg_walk.release(); m->ga_units.release(); m->ga_starts.release(); m->ga_work.release(); m->ga_counters.release(); m->ga_lane_job.release();
     if (m->tile_max_host) { (void)hipHostFree(m->tile_max_host); m->tile_max_host = nullptr; }
@@ -2533,7 +2626,9 @@ int ym_set_stream(ym_matcher *m, void *hip_stream) {
     if (!m) return set_err(YM_ERR_INVALID, "null matcher");
     DEV_GUARD(m->device);
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->stream != m->own_stream) pool_register_stream(m->device, m->stream, false); // (everything on it has completed)
     m->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->own_stream;
+    pool_register_stream(m->device, m->stream, true);
     return YM_OK;
 }
 
@@ -2545,11 +2640,8 @@ int ym_synchronize(ym_matcher *m) {
 }
 
 // ---- scans
-ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
-    if (check_desc(d) != YM_OK) return nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err(YM_ERR_NO_DEVICE, "no HIP device available"); return nullptr; }
-    if (device < 0 || device >= n) { set_err(YM_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, n); return nullptr; }
+// everything of a new scan the host computes from its descriptor (no device work)
+static ym_scan *scan_host_side(int device, const ym_scan_desc *d) {
     static std::atomic<uint64_t> next_id{1};
     ym_scan *s = new ym_scan();
     s->id = next_id.fetch_add(1);
@@ -2563,12 +2655,29 @@ ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
     local_bbox(d->ranges, d->n, d->min_angle, d->angle_increment, d->range_threshold, s->lbox);
     world_bbox(s->lbox, s->pose, s->wbox);
     s->beam_spacing = median_beam_spacing(d->ranges, d->n, d->min_range, d->range_threshold, d->angle_increment);
+    return s;
+}
+// a scan's block of device memory: ranges[n], the chain structure per semantics ([2][n][2] + [2][n] ints), 16 spare bytes
+struct ScanLayout {
+    size_t ranges_bytes, gov_bytes, cidx_bytes, total;
+    explicit ScanLayout(int n) {
+        const size_t n1 = (size_t)std::max(1, n);
+        ranges_bytes = align_up(sizeof(double) * n1, 16);
+        gov_bytes = align_up(sizeof(int32_t) * 2 * n1, 16);
+        cidx_bytes = align_up(sizeof(int32_t) * n1, 16);
+        total = ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes + 16;
+    }
+};
+
+ym_scan *ym_scan_create(int device, const ym_scan_desc *d) {
+    if (check_desc(d) != YM_OK) return nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err(YM_ERR_NO_DEVICE, "no HIP device available"); return nullptr; }
+    if (device < 0 || device >= n) { set_err(YM_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, n); return nullptr; }
+    ym_scan *s = scan_host_side(device, d);
     DevGuard guard(device);
-    // one block: ranges[n], the chain structure per semantics ([2][n][2] + [2][n] ints), its info words [4]
-    const size_t n1 = (size_t)std::max(1, d->n);
-    const size_t ranges_bytes = align_up(sizeof(double) * n1, 16), gov_bytes = align_up(sizeof(int32_t) * 2 * n1, 16);
-    const size_t cidx_bytes = align_up(sizeof(int32_t) * n1, 16);
-    const size_t total = ranges_bytes + 2 * gov_bytes + 2 * cidx_bytes + 16;
+    const ScanLayout L(d->n);
+    const size_t ranges_bytes = L.ranges_bytes, gov_bytes = L.gov_bytes, cidx_bytes = L.cidx_bytes, total = L.total;
     const bool structured = d->n > 0 && d->n <= YM_MAX_BEAMS;
     if (!guard.ok) { set_err(YM_ERR_HIP, "cannot select device %d", device); delete s; return nullptr; }
     if (structured) {
@@ -2654,6 +2763,218 @@ void ym_scan_destroy(ym_scan *s) {
         (void)hipFree(s->d_ranges);
     }
     delete s;
+}
+
+// n scans at once.  The host side of every scan (bounding box, longest reading, median beam spacing, the copy of its readings into
+// pinned memory) is the same code as ym_scan_create's, spread over a few threads; the device side is ONE pool transaction, ONE upload
+// and ONE launch of structure_many_kernel per chunk of kBulkChunk scans, two chunks in flight.  The scans come back resolved (no
+// staging slot, nothing left to wait for).
+int ym_scans_create(int device, const ym_scan_desc *descs, int n, ym_scan **out) {
+    if (n < 0 || (n > 0 && (!descs || !out))) return set_err(YM_ERR_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(YM_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return set_err(YM_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, ndev);
+    for (int i = 0; i < n; i++) {
+        int rc = check_desc(&descs[i]);
+        if (rc) return rc;
+        out[i] = nullptr;
+    }
+    DEV_GUARD(device);
+    ScanPool &p = scan_pool(device);
+    constexpr int kBulkChunk = 2048;
+    auto fail = [&](int rc) { // all or nothing
+        std::string msg = g_err;
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < n; i++)
+            if (out[i]) { out[i]->stage = nullptr; ym_scan_destroy(out[i]); out[i] = nullptr; }
+        g_err = msg;
+        return rc;
+    };
+    struct Pending { int lo = 0, hi = 0, buf = -1; size_t info_off = 0; };
+    Pending pending[2];
+    auto release_buf = [&](int b) {
+        std::lock_guard<std::mutex> lk(p.mu);
+        p.bulk[b].busy = false;
+    };
+    auto finish = [&](Pending &pd) -> int { // the chunk's launch is complete: its scans' info words
+        if (pd.buf < 0) return YM_OK;
+        ScanPool::Bulk &bk = p.bulk[pd.buf];
+        const hipError_t he = hipEventSynchronize(bk.done);
+        if (he != hipSuccess) { release_buf(pd.buf); pd.buf = -1; return set_err(YM_ERR_HIP, "scan creation failed on the device: %s", hipGetErrorString(he)); }
+        const int32_t *info = reinterpret_cast<const int32_t *>(bk.host + pd.info_off);
+        int k = 0;
+        for (int i = pd.lo; i < pd.hi; i++) {
+            ym_scan *s = out[i];
+            if (!s->block_bytes) continue; // (an odd one: created the single way)
+            s->cnp[0] = info[4 * k]; s->gov_ok[0] = info[4 * k + 1] == 0;
+            s->cnp[1] = info[4 * k + 2]; s->gov_ok[1] = info[4 * k + 3] == 0;
+            k++;
+        }
+        release_buf(pd.buf);
+        pd.buf = -1;
+        return YM_OK;
+    };
+    auto fail_all = [&](int rc) {
+        for (Pending &pd : pending)
+            if (pd.buf >= 0) { (void)hipEventSynchronize(p.bulk[pd.buf].done); release_buf(pd.buf); pd.buf = -1; }
+        return fail(rc);
+    };
+    for (int lo = 0, chunk = 0; lo < n; lo += kBulkChunk, chunk++) {
+        const int hi = std::min(n, lo + kBulkChunk), m = hi - lo, slot = chunk & 1;
+        int rc;
+        if ((rc = finish(pending[slot]))) return fail_all(rc); // (the chunk before last)
+        int buf = -1;
+        // layout of the chunk's staging buffer: [StructureArgs x m][info int32[4] x m][readings, 16-byte aligned per scan]
+        std::vector<size_t> roff(m + 1);
+        const size_t table_bytes = align_up(sizeof(ym::StructureArgs) * m, 256), info_off = table_bytes, info_bytes = align_up(sizeof(int32_t) * 4 * m, 256);
+        size_t at = table_bytes + info_bytes;
+        int max_n = 1;
+        for (int i = 0; i < m; i++) {
+            roff[i] = at;
+            const int ni = descs[lo + i].n;
+            if (ni > 0 && ni <= YM_MAX_BEAMS) { at += align_up(sizeof(double) * ni, 16); max_n = std::max(max_n, ni); }
+        }
+        roff[m] = at;
+        for (int tries = 0; buf < 0; tries++) { // a staging buffer nobody holds (twelve: six creating threads at two chunks each)
+            {
+                std::lock_guard<std::mutex> lk(p.mu);
+                if ((rc = pool_init(p, device))) return fail_all(rc);
+                for (int b = 0; b < ScanPool::kBulkBuffers && buf < 0; b++)
+                    if (!p.bulk[b].busy && (p.bulk[b].cap >= at || tries > 0)) { p.bulk[b].busy = true; buf = b; } // (first one that is large enough already)
+            }
+            if (buf < 0 && tries > 0) std::this_thread::yield();
+        }
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            ScanPool::Bulk &bk = p.bulk[buf];
+            if (at > bk.cap) {
+                if (bk.host) (void)hipHostFree(bk.host);
+                if (bk.dev) (void)hipFree(bk.dev);
+                bk.host = bk.dev = nullptr; bk.cap = 0;
+                const size_t want = align_up(at + at / 4, 4096);
+                if (hipHostMalloc(reinterpret_cast<void **>(&bk.host), want, hipHostMallocDefault) != hipSuccess ||
+                    hipMalloc(reinterpret_cast<void **>(&bk.dev), want) != hipSuccess) {
+                    (void)hipGetLastError();
+                    bk.busy = false;
+                    return fail_all(set_err(YM_ERR_HIP, "cannot allocate %zu bytes of staging memory for %d scans", want, m));
+                }
+                bk.cap = want;
+            }
+            if (!bk.done && hipEventCreateWithFlags(&bk.done, hipEventDisableTiming) != hipSuccess) { bk.busy = false; return fail_all(set_err(YM_ERR_HIP, "cannot create an event")); }
+            if (!p.bulk_streams[0]) {
+                int lo_p = 0, hi_p = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p); // (numerically lowest = highest priority)
+                for (hipStream_t &bs : p.bulk_streams)
+                    if (hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, hi_p) != hipSuccess) { (void)hipGetLastError(); bs = p.streams[0]; }
+            }
+        }
+        ScanPool::Bulk &bk = p.bulk[buf];
+        // the host side of every scan, and its readings into the pinned buffer: a few threads, a contiguous share each
+        {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const int nthreads = (int)std::max(1u, std::min({hw, 16u, (unsigned)(m / 128 + 1)}));
+            auto work = [&](int t) {
+                const int a0 = (int)((int64_t)m * t / nthreads), a1 = (int)((int64_t)m * (t + 1) / nthreads);
+                for (int i = a0; i < a1; i++) {
+                    const ym_scan_desc &d = descs[lo + i];
+                    if (!(d.n > 0 && d.n <= YM_MAX_BEAMS)) continue; // (created the single way below)
+                    out[lo + i] = scan_host_side(device, &d);
+                    std::memcpy(bk.host + roff[i], d.ranges, sizeof(double) * d.n);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &t : th) t.join();
+        }
+        // one pool transaction: a block per scan, its argument record
+        ym::StructureArgs *table = reinterpret_cast<ym::StructureArgs *>(bk.host);
+        int k = 0;
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            if (p.parked.size() >= kRecycleAt) pool_seal(p);
+            pool_reap(p);
+            {
+                std::unordered_map<size_t, size_t> need; // blocks per size (one size, normally)
+                for (int i = 0; i < m; i++)
+                    if (out[lo + i]) need[align_up(ScanLayout(out[lo + i]->n).total, 1024)]++;
+                for (auto &kv : need) pool_reserve(p, kv.first, kv.second);
+            }
+            for (int i = 0; i < m; i++) {
+                ym_scan *s = out[lo + i];
+                if (!s) continue;
+                const ScanLayout L(s->n);
+                const size_t bytes = align_up(L.total, 1024);
+                unsigned char *base = static_cast<unsigned char *>(pool_block(p, bytes, false));
+                if (!base) { bk.busy = false; return fail_all(set_err(YM_ERR_HIP, "cannot allocate device ranges")); }
+                s->d_ranges = reinterpret_cast<double *>(base);
+                s->block_bytes = bytes;
+                s->d_gov[0] = reinterpret_cast<int32_t *>(base + L.ranges_bytes);
+                s->d_gov[1] = reinterpret_cast<int32_t *>(base + L.ranges_bytes + L.gov_bytes);
+                s->d_cidx[0] = reinterpret_cast<int32_t *>(base + L.ranges_bytes + 2 * L.gov_bytes);
+                s->d_cidx[1] = reinterpret_cast<int32_t *>(base + L.ranges_bytes + 2 * L.gov_bytes + L.cidx_bytes);
+                ym::StructureArgs &sa = table[k];
+                std::memset(&sa, 0, sizeof sa);
+                sa.sr.ranges = reinterpret_cast<const double *>(bk.dev + roff[i]); sa.sr.n = s->n; sa.sr.min_angle = s->min_angle; sa.sr.angle_inc = s->angle_inc;
+                sa.sr.min_range = s->min_range; sa.sr.range_threshold = s->range_threshold;
+                sa.gov[0] = s->d_gov[0]; sa.gov[1] = s->d_gov[1]; sa.cidx[0] = s->d_cidx[0]; sa.cidx[1] = s->d_cidx[1];
+                sa.info = reinterpret_cast<int32_t *>(bk.dev + info_off) + 4 * k;
+                sa.ranges_out = s->d_ranges;
+                k++;
+            }
+            if (k > 0) {
+                hipStream_t st = p.bulk_streams[slot];
+                bool ok = hipMemcpyAsync(bk.dev, bk.host, at, hipMemcpyHostToDevice, st) == hipSuccess;
+                if (ok) {
+                    hipLaunchKernelGGL(ym::structure_many_kernel<512>, dim3(2, k), dim3(512), YM_PREP_LDS_BYTES(max_n), st, reinterpret_cast<const ym::StructureArgs *>(bk.dev));
+                    ok = hipGetLastError() == hipSuccess &&
+                         hipMemcpyAsync(bk.host + info_off, bk.dev + info_off, sizeof(int32_t) * 4 * k, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipEventRecord(bk.done, st) == hipSuccess;
+                }
+                if (!ok) { bk.busy = false; return fail_all(set_err(YM_ERR_HIP, "uploading %d scans failed: %s", k, hipGetErrorString(hipGetLastError()))); }
+                pending[slot].lo = lo; pending[slot].hi = hi; pending[slot].buf = buf; pending[slot].info_off = info_off;
+            } else {
+                bk.busy = false;
+            }
+        }
+        // scans without readings, or with more than the kernels stage at once: the single way (a plain allocation)
+        for (int i = 0; i < m; i++)
+            if (!out[lo + i]) {
+                out[lo + i] = ym_scan_create(device, &descs[lo + i]);
+                if (!out[lo + i]) return fail_all(YM_ERR_HIP);
+            }
+    }
+    for (Pending &pd : pending) {
+        int rc = finish(pd);
+        if (rc) return fail_all(rc);
+    }
+    return YM_OK;
+}
+
+void ym_scans_destroy(ym_scan *const *scans, int n) {
+    if (!scans || n <= 0) return;
+    // by device (normally one): one pool transaction for all of a device's scans
+    for (int i = 0; i < n;) {
+        if (!scans[i]) { i++; continue; }
+        const int device = scans[i]->device;
+        DevGuard guard(device);
+        ScanPool &p = scan_pool(device);
+        std::vector<void *> plain;
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            int j = i;
+            for (; j < n && (!scans[j] || scans[j]->device == device); j++) {
+                ym_scan *s = scans[j];
+                if (!s) continue;
+                if (s->stage) stage_wait(p, *s->stage); // (its creation launch writes into the block)
+                if (s->block_bytes) p.parked.push_back({s->d_ranges, s->block_bytes});
+                else if (s->d_ranges) plain.push_back(s->d_ranges);
+                delete s;
+            }
+            i = j;
+        }
+        for (void *q : plain) (void)hipFree(q);
+    }
 }
 
 // ---- hot path
@@ -3040,6 +3361,7 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
             if (i + 8 < nq) touch(b->queries[i + 8]);
             if ((rc = scan_to_call(b->queries[i], m->cfg.semantics, &call.scans[i]))) return rc;
             call.scans[i].qcache_hint = b->query_hints[i];
+            call.scans[i].query_uses = b->queries[i]->query_uses.fetch_add(1, std::memory_order_relaxed);
         }
         // (tried: four threads, a quarter each -- 3.9 -> 4.4 ms, and the caller's next ym_scans_set_poses 0.75 -> 2.7 ms: the
         //  scans' cache lines then live in other cores' caches)

@@ -500,25 +500,38 @@ struct StructureArgs {
     uint32_t pad;
 };
 template <int NT>
-__global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
-    const bool yag = blockIdx.x == 1;
+__device__ __forceinline__ void structure_body(const StructureArgs &a, int sem, unsigned char *lds_raw, int *s_cnt) {
+    const bool yag = sem == 1;
     const PrepLds l = prep_lds(lds_raw, a.sr.n);
-    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt, a.cidx[blockIdx.x]);
+    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt, a.cidx[sem]);
     const int unsafe = mark_chain<NT, true>(l, np, yag);
-    int2 *gov = reinterpret_cast<int2 *>(a.gov[blockIdx.x]);
+    int2 *gov = reinterpret_cast<int2 *>(a.gov[sem]);
     for (int i = threadIdx.x; i < np; i += NT) gov[i] = gov_walk(l, i, np, yag);
-    if (a.ranges_out && blockIdx.x == 0)
+    if (a.ranges_out && sem == 0)
         for (int i = threadIdx.x; i < a.sr.n; i += NT) a.ranges_out[i] = a.sr.ranges[i];
-    if (threadIdx.x == 0) { a.info[2 * blockIdx.x] = np; a.info[2 * blockIdx.x + 1] = unsafe; }
+    if (threadIdx.x == 0) { a.info[2 * sem] = np; a.info[2 * sem + 1] = unsafe; }
     if (a.done) {
         __syncthreads(); // every lane's stores are issued and waited for ...
         if (threadIdx.x == 0) {
             __threadfence_system(); // ... and written back before the host (and the kernels it launches next) can see the word
-            __hip_atomic_store(a.done + blockIdx.x, a.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.done + sem, a.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+// one scan (ym_scan_create): grid (2) = one block per semantics
+template <int NT>
+__global__ __launch_bounds__(NT) void structure_kernel(StructureArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
+    structure_body<NT>(a, (int)blockIdx.x, lds_raw, s_cnt);
+}
+// many scans (ym_scans_create): grid (2, scans), the argument records in device memory; completion by stream order (done == null)
+template <int NT>
+__global__ __launch_bounds__(NT) void structure_many_kernel(const StructureArgs *table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_cnt[(YM_MAX_BEAMS / NT + 1) * (NT / 64)];
+    const StructureArgs a = table[blockIdx.y];
+    structure_body<NT>(a, (int)blockIdx.x, lds_raw, s_cnt);
 }
 
 // ---- K1 for batches, first half: the heavy, query-independent work ONCE per distinct scan of the call.

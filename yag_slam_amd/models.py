@@ -51,6 +51,75 @@ def set_corrected_poses(scans, poses):
             s.corrected_pose = tf       # any other scan type: its own setter
 
 
+# ym_scan_desc (include/yagmatch.h) as a numpy record: descriptor arrays for ym_scans_create are filled column by column
+_DESC_DTYPE = np.dtype([("ranges", "<u8"), ("n", "<i4"), ("reserved", "<i4"), ("min_angle", "<f8"), ("max_angle", "<f8"),
+                        ("angle_increment", "<f8"), ("min_range", "<f8"), ("max_range", "<f8"), ("range_threshold", "<f8"),
+                        ("pose", "<f8", (3,))])
+assert _DESC_DTYPE.itemsize == C.sizeof(_capi.YmScanDesc)
+
+
+def _create_many(device, descs):
+    """ym_scans_create over a record array of descriptors -> numpy array of handles (uint64)"""
+    handles = np.zeros(len(descs), dtype=np.uint64)
+    if len(descs):
+        _capi.check(_capi.lib().ym_scans_create(int(device), descs.ctypes.data_as(C.c_void_p), len(descs), handles.ctypes.data_as(C.c_void_p)))
+    return handles
+
+
+def native_many(scans, device=0):
+    """Device twins for many LocalizedRangeScan objects in ONE ym_scans_create call (one pool transaction, one upload and one launch per
+    2048 scans instead of a launch per scan): what `for s in scans: s.native(device)` leaves behind, bit for bit.  Scans that already
+    have a twin on `device` keep it."""
+    todo = [s for s in scans if not (s._native is not None and s._native_device == device)]
+    if not todo:
+        return
+    keep = []  # (the readings must stay where the descriptors point until the call returns)
+    d = np.zeros(len(todo), dtype=_DESC_DTYPE)
+    for i, s in enumerate(todo):
+        s._release()
+        r = np.ascontiguousarray(s.ranges, dtype=np.float64)
+        keep.append(r)
+        p = s._corrected_pose
+        d[i] = (r.ctypes.data, r.shape[0], 0, s.min_angle, s.max_angle, s.angle_increment, s.min_range, s.max_range, s.range_threshold,
+                (p.x, p.y, p.euler[-1]))
+    handles = _create_many(device, d)
+    for s, h in zip(todo, handles):
+        s._native, s._native_device = int(h), device
+
+
+class ScanBlock(object):
+    """n scans of ONE sensor created from arrays, without a Python object per scan: `ranges` [n][beams] float64, `poses` [n][3]
+    (x, y, heading), `sensor` = (min_angle, max_angle, angle_increment, min_range, max_range, range_threshold).  For callers that
+    receive thousands of scans per step (N robots, a log replayed in parallel segments): one ym_scans_create, one ym_scans_destroy.
+    `.handles` (numpy uint64) are the ym_scan* the batch entry points take."""
+
+    def __init__(self, ranges, poses, sensor, device=0):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        xyz = np.ascontiguousarray(poses, dtype=np.float64).reshape(r.shape[0], 3)
+        d = np.zeros(r.shape[0], dtype=_DESC_DTYPE)
+        d["ranges"] = r.ctypes.data + np.arange(r.shape[0], dtype=np.uint64) * np.uint64(r.strides[0])
+        d["n"] = r.shape[1]
+        for k, v in zip(("min_angle", "max_angle", "angle_increment", "min_range", "max_range", "range_threshold"), sensor):
+            d[k] = v
+        d["pose"] = xyz
+        self.device = int(device)
+        self.handles = _create_many(device, d)
+
+    def __len__(self):
+        return int(self.handles.shape[0])
+
+    def release(self):
+        if getattr(self, "handles", None) is not None and len(self.handles):
+            _capi.lib().ym_scans_destroy(self.handles.ctypes.data_as(C.c_void_p), len(self.handles))
+        self.handles = np.zeros(0, dtype=np.uint64)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class LocalizedRangeScan:
     def __init__(self, ranges, min_angle, max_angle, angle_increment, min_range, max_range, range_threshold,
                  x, y, t):

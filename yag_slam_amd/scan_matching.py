@@ -541,13 +541,34 @@ class MatchBatch(object):
             raise _capi.YmError(-1, _capi.last_error())
         self.n = len(self.chains)
 
-    def __del__(self):
+    @classmethod
+    def from_handles(cls, matcher, query_handles, scan_handles, offsets):
+        """A pairs batch over raw ym_scan* arrays (numpy uint64; models.ScanBlock.handles): item i = query_handles[i] against
+        scan_handles[offsets[i]:offsets[i + 1]].  No Python object per scan; the caller keeps the scans alive while the batch is used."""
+        self = cls.__new__(cls)
+        self.m, self.query, self.chains, self._queries, self._flat = matcher, None, None, None, None
+        qh = np.ascontiguousarray(query_handles, dtype=np.uint64)
+        sh = np.ascontiguousarray(scan_handles, dtype=np.uint64)
+        co = np.ascontiguousarray(offsets, dtype=np.int32)
+        if co.shape[0] != qh.shape[0] + 1:
+            raise ValueError("a pairs batch needs one chain per query")
+        self._h = matcher._lib.ym_pairs_create(matcher._m, qh.ctypes.data_as(C.POINTER(C.c_void_p)), sh.ctypes.data_as(C.POINTER(C.c_void_p)),
+                                               co.ctypes.data_as(C.POINTER(C.c_int32)), int(qh.shape[0]))
+        if not self._h:
+            raise _capi.YmError(-1, _capi.last_error())
+        self.n = int(qh.shape[0])
+        return self
+
+    def close(self):
         if getattr(self, "_h", None):
             try:
                 self.m._lib.ym_batch_destroy(self._h)
             except Exception:
                 pass
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     def push_poses(self):
         """Write the scans' current corrected poses through to their device twins."""
