@@ -209,7 +209,8 @@ struct CallPlan {
     bool rg_ws = false; // the wave-specialised region correlate (gather waves + loader waves, regions of YM_WS_H rows)
     bool rg2 = false;   // correlate_region2_kernel (round 5): sixteen waves per block, several waves per angle, regions rg2_h rows high
     int rg2_h = 0;
-    size_t rg_entries_stride = 0, rg_starts_stride = 0;
+    size_t rg_entries_stride = 0, rg_starts_stride = 0, rg_entries_pstride = 0;
+    int rg_lnw = 0, rg_lparts = 1; // the pair lists are built per block of rg_lnw angles (ym_k_region.hpp, bin_kernel); the experimental forms: one part of all
     // batches on other lattices up to 48 x 64, or with merged offsets: the LDS gather correlate (ym_k_gather.hpp), which
     // always scores its sums
     bool region = false;
@@ -629,7 +630,8 @@ struct ym_matcher {
     DevBuf<uint32_t> rg_rbox;    // per query slot, region and angle block: the box its patches read of the region
     DevBuf<uint32_t> rg_walk;    // per query slot and angle block: the walk of the wave-specialised region correlate (region_walk_kernel)
     int n_cus = 0;               // compute units of the device
-    size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_kernel may use so far
+    size_t bin_lds_limit = 64 * 1024; // dynamic LDS bin_whole_kernel may use so far (experimental builds)
+    size_t binp_lds_limit = 64 * 1024; // ... and bin_kernel
     int chain_margin = 1;        // tiles (64 cells) added around the predicted raster rectangle of a chained step
     uint64_t cache_gen = 1;      // bumped whenever the point cache changes (entries created, re-posed, dropped) or an option is set
     int64_t seq_segments = 0, seq_faults = 0, seq_sync_steps = 0; // ym_map_sequence: chained segments, those cut short, synchronous steps
@@ -1146,8 +1148,14 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             // (+ the padding of the bins that hold work; a query whose list still does not fit takes the per-cell path)
             // 10 % over the pairs themselves (measured on the bench scans: 5 %)
             // (the wave-specialised form's bins are a third more and hold less each: 20 %)
-            P.rg_entries_stride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)lc.nt * max_n * 11 / 10 + 63) / 64 * 64);
-            P.rg_starts_stride = ((size_t)P.rg_nbins + 1 + 15) / 16 * 16;
+            // the lists: one part per angle block of the correlate (the experimental forms read one list of all angles)
+            const bool whole = P.rg_ws || P.rg2 || P.rg_item || P.rg_pool;
+            P.rg_lnw = whole ? lc.nt : P.rg_nw;
+            P.rg_lparts = whole ? 1 : P.rg_parts;
+            P.rg_nbins = P.rg_nregions * P.rg_lnw;
+            P.rg_entries_pstride = std::min((size_t)YM_RG_MAX_ENTRIES, ((size_t)P.rg_lnw * max_n * 11 / 10 + 63) / 64 * 64);
+            P.rg_entries_stride = P.rg_entries_pstride * P.rg_lparts; // (positions are 16-bit in the correlate: checked on the device per part)
+            P.rg_starts_stride = ((size_t)P.rg_lparts * (P.rg_nbins + 1) + P.rg_lparts + 15) / 16 * 16;
         }
     }
     // Other batches on lattices of at most 48 x 64: the general form (ym_k_gather.hpp).
@@ -1882,6 +1890,7 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
     r.pad2 = ((1 << 21) + r.rg_h - 1) / r.rg_h; // bin_kernel: class row / region height as a multiplication (region_entry)
     r.rg_w = 0; r.rg_pitch = YM_RG_PITCH; r.nregions = P.rg_nregions; r.pad3 = 0;
     r.walk = m->rg_walk.p; r.nitems = P.B; r.rsplit = P.rg_rsplit; r.pad4 = 0;
+    r.lnw = P.rg_lnw; r.lparts = P.rg_lparts; r.entries_pstride = P.rg_entries_pstride;
     // teams of `parts` blocks per XCD: two blocks per CU, no more teams than the XCD gets items
     r.gpx = std::max(1, std::min((2 * std::max(m->n_cus, 8) / 8) / std::max(1, P.rg_parts), (P.B + 7) / 8));
     return r;
@@ -1890,17 +1899,32 @@ ym::RegionArgs region_args(ym_matcher *m, const CallPlan &P) {
 // bin_kernel, once per query slot of the call: after the prepare stage (item states, hypothesis cells, angle tables)
 int enqueue_region_lists(ym_matcher *m, const CallPlan &P, hipStream_t st) {
     const ym::RegionArgs r = region_args(m, P);
-    const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nregions * P.rg_parts);
-    if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
-        m->bin_lds_limit = bin_lds;
-    }
-    if (P.yag) hipLaunchKernelGGL(ym::bin_kernel<true>, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
-    else hipLaunchKernelGGL(ym::bin_kernel<false>, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
 #ifdef YM_EXPERIMENTAL
-    if (P.rg_ws) hipLaunchKernelGGL(ym::region_walk_kernel, dim3(P.rg_parts, P.n_qslots), dim3(64), 0, st, r);
+    if (P.rg_lparts == 1 && P.rg_lnw == P.lc.nt && (P.rg_ws || P.rg2 || P.rg_item || P.rg_pool)) { // the round-5 layout: one list of all angles
+        const size_t bin_lds = YM_BIN_LDS_BYTES(P.rg_nbins, P.rg_entries_stride, P.rg_nregions * P.rg_parts);
+        if (bin_lds > m->bin_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_whole_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+            m->bin_lds_limit = bin_lds;
+        }
+        hipLaunchKernelGGL(ym::bin_whole_kernel<false>, dim3(P.n_qslots), dim3(YM_BIN_THREADS), bin_lds, st, r);
+        if (P.rg_ws) hipLaunchKernelGGL(ym::region_walk_kernel, dim3(P.rg_parts, P.n_qslots), dim3(64), 0, st, r);
+        return YM_OK;
+    }
 #endif
+    const size_t bin_lds = YM_BINP_LDS_BYTES(P.rg_nbins, P.rg_entries_pstride, P.rg_nregions);
+    if (bin_lds > m->binp_lds_limit) { // (more than the default 64 KB of dynamic LDS has to be asked for)
+#define YM_BINP_ATTR(Y, M) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ym::bin_kernel<Y, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds))
+        YM_BINP_ATTR(false, 18); YM_BINP_ATTR(false, 32); YM_BINP_ATTR(false, 64); YM_BINP_ATTR(true, 18); YM_BINP_ATTR(true, 32); YM_BINP_ATTR(true, 64);
+#undef YM_BINP_ATTR
+        m->binp_lds_limit = bin_lds;
+    }
+    // pairs per thread: the instantiation with registers for them (18: scans of up to 1152 readings at eight angles per part)
+    const int per_thread = (P.rg_lnw * P.max_n + YM_BINP_THREADS - 1) / YM_BINP_THREADS;
+    const dim3 bgrid(P.rg_lparts, P.n_qslots);
+#define YM_BINP_LAUNCH(Y, M) hipLaunchKernelGGL((ym::bin_kernel<Y, M>), bgrid, dim3(YM_BINP_THREADS), bin_lds, st, r)
+    if (P.yag) { if (per_thread <= 18) YM_BINP_LAUNCH(true, 18); else if (per_thread <= 32) YM_BINP_LAUNCH(true, 32); else YM_BINP_LAUNCH(true, 64); }
+    else { if (per_thread <= 18) YM_BINP_LAUNCH(false, 18); else if (per_thread <= 32) YM_BINP_LAUNCH(false, 32); else YM_BINP_LAUNCH(false, 64); }
+#undef YM_BINP_LAUNCH
     return YM_OK;
 }
 

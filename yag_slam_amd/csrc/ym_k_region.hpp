@@ -123,14 +123,30 @@ struct RegionArgs {
     int32_t nitems, gpx;
     int32_t rsplit, pad4;    // correlate_region_kernel: blocks that share the regions of an (item, angle block); <= 1: one
     unsigned long long *stamps;
+    // Round 6: the lists of a query are built PER ANGLE BLOCK (lparts blocks of lnw angles, by one bin_kernel block each: a third of the
+    // pairs, 25 KB of LDS, eight waves -- such a block sits beside two region-correlate blocks of another lane, where the round-5 block
+    // (all 21 angles: 65 KB, sixteen waves) pushed two of three off its CU).  starts: [Q][lparts][nbins + 1] first entry of bin
+    // (region * lnw + angle - part * lnw), positions in the query's entry array (part p's entries start at p * entries_pstride);
+    // then [lparts] flags: total of the part, or -1 = no list (that block's angles take the per-cell path).  nbins = regions * lnw.
+    // (lparts = 1, lnw = nt is the round-5 layout: what the experimental forms read, built by bin_whole_kernel.)
+    int32_t lnw, lparts;
+    size_t entries_pstride;
 };
+// the starts row of list part p, and whether the part has a list
+__device__ __forceinline__ const int32_t *rg_part_starts(const RegionArgs &a, int qslot, int p) {
+    return a.starts + (size_t)qslot * a.starts_stride + (size_t)p * (a.nbins + 1);
+}
+__device__ __forceinline__ bool rg_part_listed(const RegionArgs &a, int qslot, int p) {
+    return a.starts[(size_t)qslot * a.starts_stride + (size_t)a.lparts * (a.nbins + 1) + p] >= 0;
+}
 
 // the bin of one (beam, angle) pair and its entry = the LDS offset of the patch's first byte once the region is staged;
 // false if the patch origin is outside the regions (never for a patch the window holds; kept so that nothing is ever
 // written out of bounds)
 // (region = its index, er / ex = the patch origin's class row and byte inside the region)
+// (bin_nw: angles per region in the bin numbering -- all of them, or those of one list part; k counts from the part's first angle then)
 __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int cx0, int cy0, int k, int &bin, unsigned &entry, int &region,
-                                             unsigned &er, unsigned &ex) {
+                                             unsigned &er, unsigned &ex, int bin_nw = -1) {
     const int X = cx0 + cell.x, Y = cy0 + cell.y;
     if (X < 0 || Y < 0) return false;
     const unsigned xc = (unsigned)X >> 1, yc = (unsigned)Y >> 1;
@@ -155,13 +171,199 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
     const unsigned rx = xc / (unsigned)YM_RG_W, ry = __umul24(yc, (unsigned)a.pad2) >> 21;
     if ((int)rx >= a.nrx || (int)ry >= a.nry) return false;
     region = (int)(__umul24(ry, (unsigned)a.nrx) + rx);
-    bin = (int)__umul24((unsigned)region, (unsigned)a.lat.nt) + k;
+    bin = (int)__umul24((unsigned)region, (unsigned)(bin_nw < 0 ? a.lat.nt : bin_nw)) + k;
     er = yc - __umul24(ry, (unsigned)a.rg_h);
     ex = xc - rx * YM_RG_W;
     entry = __umul24(cls, (unsigned)a.rg_cls) + __umul24(er, (unsigned)YM_RG_PITCH) + ex;
     return true;
 }
 
+// ---- the pair lists, per angle block (round 6).  grid (lparts, Q): block (p, q) sorts the (beam, angle) pairs of query slot q
+// whose angle lies in [p * lnw, (p + 1) * lnw) by (region, angle); YM_BINP_THREADS threads.  Counting sort in LDS: count, scan, place (the order
+// inside a bin is arbitrary: the sums are integers).  GridIndexLookup::ComputeOffsets for the part's coarse angles happens here.
+// Inside a bin the entries are sorted by their byte misalignment (entry & 3; class images and rows are multiples of 4
+// bytes), every run of equal misalignment is padded to an even length and the bin to a multiple of four with entries
+// that point at the all-zero patch: the gather then adds the raw dwords of a PAIR of patches before one byte funnel, and
+// never meets a ragged group.  A part whose padded list would not fit -- its share of the buffer, one angle's share of the ng sets of
+// 16-bit sums the gather may fill, or more regions with work than a correlate block can list -- gets its flag = -1 and the
+// correlate block of those angles takes the per-cell path.
+// YAG: the lookup cells of the reference's Python matcher (items yag_lattice_kernel proved regular; ym_k_common.hpp, lookup_cell_sem).
+// MAXP: pairs per thread the instantiation has registers for (18: scans of up to 1152 readings at eight angles per part; 32: up to 2047).
+#define YM_BINP_THREADS 512
+#define YM_BINP_LDS_BYTES(nbins, entries, nboxes) ((size_t)(YM_BINP_THREADS / 64 + 16 + YM_RG_MAX_BINS / 32 + 1) * 4 + (size_t)(nbins) * 8 + ((size_t)(entries) * 2 + 15) / 16 * 16 + (size_t)(nboxes) * 16)
+template <bool YAG, int MAXP>
+__global__ __launch_bounds__(YM_BINP_THREADS, MAXP <= 18 ? 4 : 2) void bin_kernel(RegionArgs a) {
+    constexpr int NT = YM_BINP_THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
+    int *wave_tot = reinterpret_cast<int *>(bin_smem);                                   // [NT / 64]
+    int *angle_tot = wave_tot + NT / 64;                                                 // [16] padded entries per angle of the part
+    unsigned *region_bits = reinterpret_cast<unsigned *>(angle_tot + 16);                // [YM_RG_MAX_BINS / 32] regions that hold a patch
+    int *regions_used = reinterpret_cast<int *>(region_bits + YM_RG_MAX_BINS / 32);
+    unsigned (*cnt)[2] = reinterpret_cast<unsigned (*)[2]>(regions_used + 1);             // [nbins] four 16-bit counters (one per
+                                                                                         // misalignment), later the runs' first positions
+    unsigned short *ent = reinterpret_cast<unsigned short *>(cnt + a.nbins);             // [entries_pstride]
+    const int nboxes = a.nregions;
+    unsigned (*box)[4] = reinterpret_cast<unsigned (*)[4]>(bin_smem + ((reinterpret_cast<unsigned char *>(ent + a.entries_pstride) - bin_smem) + 15) / 16 * 16); // [nregions] rmin, rmax, xmin, xmax
+    const int part = blockIdx.x, qs = blockIdx.y, b = a.qrep[qs], tid = threadIdx.x, lane = tid & 63;
+    const YmItemState &st = a.states[b];
+    const int nw = a.lnw, k_lo = part * nw, nk = min(a.lat.nt, k_lo + nw) - k_lo;
+    const int nq = st.nq;
+    const int total = nq * nk;
+    const int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
+    const int cx0 = cx[0], cy0 = cx[a.dim_stride];
+    const double off_x = st.off_x, off_y = st.off_y;
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
+    const double2 *trig = a.ctrig + (size_t)b * a.nt_stride + k_lo;
+    int32_t *starts = a.starts + (size_t)qs * a.starts_stride + (size_t)part * (a.nbins + 1);
+    int32_t *flag = a.starts + (size_t)qs * a.starts_stride + (size_t)a.lparts * (a.nbins + 1) + part;
+    const int pos0 = part * (int)a.entries_pstride; // the part's first position in the query's entry array
+    // the query's sensor-frame points and the part's angle table go through LDS (they borrow the entry list's room, which nothing
+    // writes before pass 1 is over): pass 1 reads point i of angle k for `per` consecutive pairs per thread
+    double2 *qls = reinterpret_cast<double2 *>(bin_smem + ((reinterpret_cast<unsigned char *>(ent) - bin_smem) + 15) / 16 * 16);
+    const bool ql_in_lds = (size_t)(nq + nk) * sizeof(double2) + 16 <= (size_t)a.entries_pstride * 2;
+    double2 *trigs = qls + nq;
+    if (ql_in_lds) {
+        for (int i = tid; i < nq; i += NT) qls[i] = ql[i];
+        if (tid < nk) trigs[tid] = trig[tid];
+    }
+    for (int i = tid; i < a.nbins * 2; i += NT) (&cnt[0][0])[i] = 0u;
+    if (tid < 16) angle_tot[tid] = 0;
+    if (tid < YM_RG_MAX_BINS / 32) region_bits[tid] = 0u;
+    if (tid == 0) *regions_used = 0;
+    for (int i = tid; i < nboxes; i += NT) { box[i][0] = 255u; box[i][1] = 0u; box[i][2] = 255u; box[i][3] = 0u; }
+    __syncthreads();
+    // Pass 1: bin, entry and RANK inside (bin, misalignment) of every pair, kept in registers (the rank is what the
+    // counting atomic returns), so that pass 2 neither recomputes the cells nor needs a second atomic.
+    unsigned key[MAXP];          // rank & 7 << 29 | bin << 16 | entry; 0xffffffff = no pair
+    unsigned rank_hi[(MAXP + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (MAXP + 3) / 4; q++) rank_hi[q] = 0u;
+    // A thread takes `per` CONSECUTIVE pairs (beam i of angle k, stepped from one pair to the next): neighbouring beams of one
+    // angle mostly share their bin and nearly always their box, so the lanes of a wave -- `per` beams apart -- spread over
+    // the counters, and a thread keeps the box of its run of pairs in registers and sends it when the box changes.
+    const int per_thread = (total + NT - 1) / NT;
+    const int p0 = tid * per_thread;
+    int k = p0 / max(nq, 1), i = p0 - k * nq; // (k counts from the part's first angle)
+    int cur = -1;                                 // the box the thread is collecting, and its extent so far
+    unsigned r0 = 255u, r1 = 0u, x0 = 255u, x1 = 0u;
+    auto send_box = [&]() {
+        if (cur >= 0) {
+            unsigned *bx = box[cur];
+            atomicMin(&bx[0], r0); atomicMax(&bx[1], r1); atomicMin(&bx[2], x0); atomicMax(&bx[3], x1);
+        }
+    };
+    bool overflow = per_thread > MAXP; // (the host picks the instantiation by the longest scan: never)
+    auto pass1 = [&](auto point_of, auto trig_of) {
+#pragma unroll
+        for (int q = 0; q < MAXP; q++) {
+            const int pp = p0 + q;
+            key[q] = 0xffffffffu;
+            if (q < per_thread && pp < total) {
+                const double2 cs = trig_of(k);
+                const double2 pt = point_of(i);
+                int bin, region; unsigned e, er, ex;
+                const int2 lc = YAG ? lookup_cell_sem(a.g, pt, cs.x, cs.y, off_x, off_y, st.ylat[0], st.ylat[1]) : lookup_cell(pt, cs.x, cs.y, off_x, off_y, a.g.scale);
+                if (region_entry(a, lc, cx0, cy0, k, bin, e, region, er, ex, nw)) {
+                    const unsigned rank = (atomicAdd(&cnt[bin][(e >> 1) & 1u], 1u << (16 * (e & 1u))) >> (16 * (e & 1u))) & 0xffffu;
+                    key[q] = (rank & 7u) << 29 | (unsigned)bin << 16 | e;
+                    rank_hi[q >> 2] |= ((rank >> 3) & 0xffu) << (8 * (q & 3));
+                    if (region != cur) { send_box(); cur = region; r0 = r1 = er; x0 = x1 = ex; }
+                    else { r0 = min(r0, er); r1 = max(r1, er); x0 = min(x0, ex); x1 = max(x1, ex); }
+                }
+            }
+            if (++i >= nq) { i = 0; k++; }
+        }
+    };
+    if (ql_in_lds) pass1([&](int i_) { return qls[i_]; }, [&](int k_) { return trigs[k_]; });
+    else pass1([&](int i_) { return ql[i_]; }, [&](int k_) { return trig[k_]; });
+    send_box();
+    __syncthreads();
+    {
+        uint32_t *rb = a.rbox + (size_t)qs * a.rbox_stride;
+        for (int r = tid; r < nboxes; r += NT) rb[(size_t)r * a.lparts + part] = box[r][0] | box[r][1] << 8 | box[r][2] << 16 | box[r][3] << 24;
+    }
+    // exclusive scan of the padded bin sizes: thread t owns the bins [t * per, (t + 1) * per)
+    const int per = (a.nbins + NT - 1) / NT;
+    const int first = tid * per;
+    int padded_total;
+    {
+        int local = 0;
+        for (int j = 0; j < per; j++)
+            if (first + j < a.nbins) {
+                const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
+                const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
+                const int padded = (((c[0] + 1) & ~1) + ((c[1] + 1) & ~1) + ((c[2] + 1) & ~1) + ((c[3] + 1) & ~1) + 3) & ~3;
+                local += padded;
+                if (padded) {
+                    atomicAdd(&angle_tot[(first + j) % nw], padded);
+                    const int R = (first + j) / nw;
+                    atomicOr(&region_bits[R >> 5], 1u << (R & 31));
+                }
+            }
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        if (tid < YM_RG_MAX_BINS / 32 && region_bits[tid]) atomicAdd(regions_used, __popc(region_bits[tid]));
+        __syncthreads();
+        int base = 0, all = 0;
+        for (int w = 0; w < NT / 64; w++) {
+            if (w < (tid >> 6)) base += wave_tot[w];
+            all += wave_tot[w];
+        }
+        padded_total = all;
+        bool fits = all <= (int)a.entries_pstride && pos0 + all <= 65532 && a.force_irregular != 2 && !overflow;
+        for (int kk = 0; kk < nk; kk++) fits = fits && angle_tot[kk] <= a.ng * YM_RG_FLUSH;
+        fits = fits && *regions_used <= YM_RG_MAX_REGIONS; // (what a block of correlate_region_kernel can list)
+        int run = base + incl - local;
+        for (int j = 0; j < per; j++)
+            if (first + j < a.nbins) {
+                const unsigned c01 = cnt[first + j][0], c23 = cnt[first + j][1];
+                const int c[4] = {(int)(c01 & 0xffffu), (int)(c01 >> 16), (int)(c23 & 0xffffu), (int)(c23 >> 16)};
+                starts[first + j] = pos0 + run;
+                int pos = run;
+                unsigned fill[4];
+                for (int r = 0; r < 4; r++) { // run r: its entries from pos on (placed below), then the padding
+                    fill[r] = (unsigned)pos;
+                    if (fits && (c[r] & 1)) ent[pos + c[r]] = (unsigned short)(a.rg_zero + r);
+                    pos += (c[r] + 1) & ~1;
+                }
+                if (fits && ((pos - run) & 3)) { ent[pos] = (unsigned short)a.rg_zero; ent[pos + 1] = (unsigned short)a.rg_zero; }
+                pos = run + ((pos - run + 3) & ~3);
+                cnt[first + j][0] = fill[0] | fill[1] << 16;
+                cnt[first + j][1] = fill[2] | fill[3] << 16;
+                run = pos;
+            }
+        if (tid == 0) {
+            starts[a.nbins] = pos0 + all;
+            *flag = fits ? all : -1;
+            if (a.stamps && qs == 0 && part == 0) a.stamps[26] = (unsigned long long)all;
+        }
+        if (!fits) return; // (block-uniform)
+    }
+    __syncthreads();
+    // Pass 2: every pair to its run's first position + its rank
+#pragma unroll
+    for (int q = 0; q < MAXP; q++) {
+        if (key[q] == 0xffffffffu) continue;
+        const unsigned bin = (key[q] >> 16) & 0x1fffu, e = key[q] & 0xffffu;
+        const unsigned rank = key[q] >> 29 | ((rank_hi[q >> 2] >> (8 * (q & 3))) & 0xffu) << 3;
+        const unsigned f = cnt[bin][(e >> 1) & 1u];
+        ent[((e & 1u) ? f >> 16 : f & 0xffffu) + rank] = (unsigned short)e;
+    }
+    __syncthreads();
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.entries + (size_t)qs * a.entries_stride + pos0);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ent);
+    for (int i2 = tid; i2 < (padded_total + 1) / 2; i2 += NT) out[i2] = src[i2];
+}
+
+#ifdef YM_EXPERIMENTAL
+// ---- the round-5 form: ONE block per query slot sorts the pairs of all angles (lparts = 1, lnw = nt).  What the experimental correlate
+// forms read; the product library builds its lists per angle block (bin_kernel above).
 // grid (Q): one block per query slot of the call.  YM_BIN_THREADS threads.  Counting sort in LDS: count, scan, place (the order inside a bin is arbitrary: the
 // sums are integers).  GridIndexLookup::ComputeOffsets for every coarse angle happens here.
 // Inside a bin the entries are sorted by their byte misalignment (entry & 3; class images and rows are multiples of 4
@@ -172,7 +374,7 @@ __device__ __forceinline__ bool region_entry(const RegionArgs &a, int2 cell, int
 // YAG: the lookup cells of the reference's Python matcher (items yag_lattice_kernel proved regular; ym_k_common.hpp, lookup_cell_sem) --
 // a template parameter, so that the Karto instantiation, a whole launch of the metric workload, stays the code it was.
 template <bool YAG = false>
-__global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_kernel(RegionArgs a) {
+__global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_whole_kernel(RegionArgs a) {
     constexpr int MAXP = (YM_RG_MAX_ENTRIES + YM_BIN_THREADS - 1) / YM_BIN_THREADS; // pairs per thread
     // dynamic LDS (YM_BIN_LDS_BYTES: sized by the host so that two blocks share a CU on the usual lattice):
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
@@ -343,6 +545,8 @@ __global__ __launch_bounds__(YM_BIN_THREADS, YM_BIN_MIN_WAVES) void bin_kernel(R
     for (int i = tid; i < (padded_total + 1) / 2; i += YM_BIN_THREADS) out[i] = src[i];
 }
 
+#endif // YM_EXPERIMENTAL
+
 // The 16 bytes at LDS byte address `addr` (any alignment): two ds_read2_b32 at the dword below + a byte funnel.
 // (A ds_read_b128 at a 4-byte-aligned address is legal on gfx950 but takes 64 clk per wave, lds_gather.hip.)
 // The registers an asm statement that only ISSUES a read names as outputs are not written when the statement ends, and
@@ -444,7 +648,8 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     const int half_pitch = a.g.pitch / 2;
     const int plane_bytes = half_pitch * a.g.win_w;
     const uint8_t *__restrict__ planes = a.planes + (size_t)b * a.grid_stride;
-    const int32_t *__restrict__ starts = a.starts + (size_t)st.qslot * a.starts_stride;
+    // (the lists of this block's angles: list part p -- the host builds them with lnw = NW, lparts = parts)
+    const int32_t *__restrict__ starts = rg_part_starts(a, st.qslot, p);
     const uint16_t *__restrict__ entries = a.entries + (size_t)st.qslot * a.entries_stride;
     const uint32_t lds0 = (uint32_t)(size_t)region;
     // idle lanes read what lane (row 0, same half) reads: the same address is a broadcast, any other address could share a
@@ -475,7 +680,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
     const uint32_t pt_begin = pt;
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime(); // (100 MHz: against the shader clocks of pt it gives the clock the wave ran at)
 #endif
-    const bool regular = st.regular[0] && a.force_irregular != 1 && starts[a.nbins] >= 0;
+    const bool regular = st.regular[0] && a.force_irregular != 1 && rg_part_listed(a, st.qslot, p);
     if (regular) {
         const int k_lo = p * NW, k_hi = min(nt, k_lo + NW);
         const int nreg = a.nrx * a.nry;
@@ -485,7 +690,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
             int n = 0;
             for (int R0 = 0; R0 < nreg; R0 += 64) {
                 const int R = R0 + lane;
-                const bool has = R < nreg && starts[(size_t)R * nt + k_lo] != starts[(size_t)R * nt + k_hi];
+                const bool has = R < nreg && starts[(size_t)R * NW] != starts[(size_t)R * NW + (k_hi - k_lo)];
                 const unsigned long long mask = __ballot(has);
                 const int at = n + __popcll(mask & ((1ull << lane) - 1ull)); // (its place among the regions with work)
                 if (has && at % rsplit == rsi) rlist[at / rsplit] = R;
@@ -509,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? (3 * NW + 3) / 4 : 1 /* three bl
         }
         if (kvalid)
             for (int i = lane; i < nlist; i += 64) {
-                const int32_t *srow = starts + (size_t)rlist[i] * nt + k;
+                const int32_t *srow = starts + (size_t)rlist[i] * NW + wave;
                 seginfo[wave][i][0] = (unsigned short)srow[0]; seginfo[wave][i][1] = (unsigned short)srow[1];
             }
         __syncthreads();
