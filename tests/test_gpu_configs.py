@@ -478,6 +478,56 @@ def test_match_pairs_every_item_is_its_single_call(n, opts):
             assert per1[i].response == per[i].response and per1[i].covariance == per[i].covariance, i
 
 
+def test_headline_workload_at_full_size():
+    """The enqueue bench.py's metric line times, at its full size: 4096 INDEPENDENT cfg2 problems (every item its own 1081-beam query
+    with its own readings and prior, its own 10-scan chain with its own noise; bench.py generate_inputs, rank 0's seeds), one
+    ym_pairs_create batch, run twice (the second run replays the plan, as every timed step does).  EVERY item must be its single
+    call's result bit for bit, and 32 seeded items the oracle's."""
+    from oracle import oracle as orc
+    from yag_slam_amd import synth
+    from yag_slam_amd.models import native_many
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n = 4096
+    scene = synth.Scene()
+    base_poses, q_truth, q_prior = synth.single_match_poses()
+    exact = [scene.cast(*p) for p in base_poses]
+    chains = []
+    for c in range(n):
+        rng = np.random.default_rng(100000 + c)
+        chains.append([synth.resident_scan(e + rng.normal(0.0, synth.SIGMA_RANGE, size=e.shape), p) for e, p in zip(exact, base_poses)])
+    rng = np.random.default_rng(424242)
+    dq_truth = np.array(q_truth) + np.concatenate([rng.uniform(-0.05, 0.05, size=(16384, 2)), rng.uniform(-0.03, 0.03, size=(16384, 1))], axis=1)
+    dq_prior = np.array(q_prior) + np.concatenate([rng.uniform(-0.02, 0.02, size=(16384, 2)), rng.uniform(-0.01, 0.01, size=(16384, 1))], axis=1)
+    ranges = synth.scan_ranges_many([(tuple(dq_truth[c]), 200000 + c) for c in range(n)], scene)
+    queries = [synth.resident_scan(r, p) for r, p in zip(ranges, dq_prior[:n])]
+    native_many(queries + [s for ch in chains for s in ch], 0)
+    m = ScanMatcher()
+    b = m.make_pairs_batch(queries, chains)
+    b.run_async(True, True, slot=0)
+    per, _, _ = b.wait(0)
+    assert m.debug_counters()["last_correlate"] == "correlate_region_kernel"
+    b.run_async(True, True, slot=1)
+    again, _, _ = b.wait(1)
+    for f in ("response", "pose", "cov", "hypotheses"):
+        assert np.array_equal(per.array[f], again.array[f]), f
+    assert len(per) == n and int(per.array["hypotheses"].min()) == 26 * 26 * 21 + 3 * 3 * 11
+    ms = ScanMatcher()
+    for i in range(n):
+        s = ms.match_scan(queries[i], chains[i], True, True)
+        r = per.array[i]
+        assert s.response == r["response"] and np.array_equal(np.array(s.covariance).ravel(), r["cov"]), i
+        assert (s.best_pose.x, s.best_pose.y, s.best_pose.euler[-1]) == tuple(r["pose"].tolist()), i
+    o = orc.Oracle(None, "karto")
+    for i in sorted(np.random.default_rng(4096).choice(n, size=32, replace=False).tolist()):
+        ro = o.match_scan(_plain(queries[i]), [_plain(s) for s in chains[i]], True, True)
+        r = per[i]
+        assert abs(r.response - ro["response"]) <= 1e-12, (i, r.response, ro["response"])
+        bp = r.best_pose
+        np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], ro["pose"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
+        assert r.meta["hypotheses"] == ro["hypotheses"] and r.meta["expansions"] == ro["expansions"]
+
+
 def test_match_pairs_argument_errors():
     from yag_slam_amd import _capi
     from yag_slam_amd.scan_matching import ScanMatcher

@@ -37,6 +37,14 @@ def pick_best(records):
     return best
 
 
+def _staged_through_host(tensor, group=None):
+    """True when the collective has to run on a host copy: a device tensor under a backend that moves host memory ("gloo").
+    That is how two ranks share ONE GPU in the tests (RCCL refuses two ranks on one device); on a node with a GPU per rank the
+    backend is "nccl" (= RCCL) and the tensors never leave the device."""
+    import torch.distributed as dist
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_best(local_record, group=None):
     """local_record: torch tensor (RECORD,) float64 on the rank's device (cuda for nccl, cpu for gloo).
     Returns (winner_record_tensor, gathered (world, RECORD) tensor)."""
@@ -45,6 +53,8 @@ def all_gather_best(local_record, group=None):
     if not (dist.is_available() and dist.is_initialized()):  # a single process: its record is the winner
         out = local_record.contiguous().view(1, RECORD)
         return out[0], out
+    if _staged_through_host(local_record, group):
+        local_record = local_record.cpu()  # (waits for the current stream: the arg-best kernel has written the record)
     world = dist.get_world_size(group)
     flat = torch.empty(world * RECORD, dtype=torch.float64, device=local_record.device)
     dist.all_gather_into_tensor(flat, local_record.contiguous().view(-1), group=group)
@@ -173,6 +183,13 @@ class AngleSplitMatcher(object):
             if self.world > 1:
                 chunk = self.per * self.nxy
                 mine = self.resp[self.rank * chunk:(self.rank + 1) * chunk]
-                dist.all_gather_into_tensor(self.resp, mine, group=self.group)           # in place: slice r lands at r * chunk
-                dist.all_reduce(self.probs, op=dist.ReduceOp.MAX, group=self.group)
+                if _staged_through_host(self.resp, self.group):  # (two ranks on one GPU over gloo: the tests)
+                    whole, probs = torch.empty(self.resp.shape, dtype=torch.float64), self.probs.cpu()
+                    dist.all_gather_into_tensor(whole, mine.cpu(), group=self.group)
+                    dist.all_reduce(probs, op=dist.ReduceOp.MAX, group=self.group)
+                    self.resp.copy_(whole)
+                    self.probs.copy_(probs)
+                else:
+                    dist.all_gather_into_tensor(self.resp, mine, group=self.group)       # in place: slice r lands at r * chunk
+                    dist.all_reduce(self.probs, op=dist.ReduceOp.MAX, group=self.group)
         return self.matcher.slice_finish()
