@@ -50,7 +50,7 @@ CFG4_CHAINS = 4096
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (60 x 17.4 ms: a timed region of a second)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16384, help="independent cfg2 matches per step per GPU")
     ap.add_argument("--launch-batch", type=int, default=4096, help="matches per enqueue (workspace size)")
@@ -148,7 +148,17 @@ def replayed_roofline(workload, kernel, kernel_s, valu_peak_key="region_correlat
         return None
     bound = max(res, key=lambda k_: res[k_]["frac"])
     wc = k.get("SQ_WAVE_CYCLES", 0.0)
-    return {"bound": bound, "kernel": kernel, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
+    # the counters describe the library they were collected on: its build id (a hash of the kernel sources, compiled into the library) must
+    # be that of the library that runs now, else the utilisations are another kernel's -- `stale`, and no fraction is claimed
+    from yag_slam_amd import _capi
+    running = _capi.build_id()
+    stale = ctr.get("build_id") != running
+    if stale:
+        return {"bound": bound, "kernel": kernel, "achieved": None, "peak": res[bound]["peak"], "unit": res[bound]["unit"], "frac": None, "traffic": None,
+                "stale": True, "stale_because": "profiles/counters.json was collected on build %s, this run's library is build %s: re-run scripts/profile_pmc.sh" % (
+                    ctr.get("build_id"), running), "kernel_us": kernel_s * 1e6, "kernel_us_is": "measured in this run" if live else "the profiled run's",
+                "replayed_from": None}
+    return {"bound": bound, "stale": False, "build_id": running, "grid_in_the_counter_passes": k.get("grid"), "kernel": kernel, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
             "frac": res[bound]["frac"], "traffic": hbm_bytes or None, "hbm_frac": res["hbm"]["frac"] if "hbm" in res else None,
             "resources": res, "kernel_us": kernel_s * 1e6, "kernel_us_is": "measured in this run" if live else "the profiled run's",
             "kernel_us_in_the_counter_passes": k.get("us"),  # (under rocprofv3 the kernel runs a few per cent longer; the counts per launch are divided by the LIVE duration)
@@ -270,6 +280,9 @@ def generate_inputs(args, rank, world, legs):
             dq_truth = np.array(q_truth) + np.concatenate([rng.uniform(-0.05, 0.05, size=(n, 2)), rng.uniform(-0.03, 0.03, size=(n, 1))], axis=1)
             dq_prior = np.array(q_prior) + np.concatenate([rng.uniform(-0.02, 0.02, size=(n, 2)), rng.uniform(-0.01, 0.01, size=(n, 1))], axis=1)
             out["cfg2_queries"] = (synth.scan_ranges_many([(tuple(dq_truth[c]), 200000 + c) for c in range(n)], scene, workers), dq_prior)
+    if "cfg2x" in legs and not args.only_headline and not args.no_distinct_queries:
+        # cfg2x_trajectory: batch (query, chain) pairs along the cfg3 trajectory -- heterogeneous poses and headings
+        out["traj"] = synth.scan_ranges_many(synth.trajectory_jobs(args.batch + 10), scene, workers)
     if "cfg3" in legs and rank == 0:
         out["cfg3"] = synth.scan_ranges_many(synth.trajectory_jobs(args.cfg3_scans), scene, workers)
     if "cfg4" in legs:
@@ -403,6 +416,26 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     # call for each: 2-4 ms, next to 5 ms of GPU); second pass: every slot replays its plan (0.13 ms of host per enqueue)
     dt_first = timed_pass()
     dt = timed_pass()
+    # the per-GPU share of the 8-GPU run: this rank's first 512 chains alone (strong scaling predicted from one GPU: t(4096) / (8 t(512)))
+    shard = None
+    if world == 1 and len(chains) >= 4096:
+        sb = loop_m.make_batch(query, chains[:512])
+        srec = torch.zeros((reps, ymdist.RECORD), dtype=torch.float64, device="cuda")
+        for r in range(reps):
+            sb.run_async(False, False, slot=r, chain_id_base=0, dev_best_out=srec[r].data_ptr())
+        for r in range(reps):
+            sb.wait(r, per_chain=False)
+        sync()
+        t0 = time.perf_counter()
+        for r in range(reps):
+            sb.run_async(False, False, slot=r, chain_id_base=0, dev_best_out=srec[r].data_ptr())
+        sync()
+        sdt = (time.perf_counter() - t0) / reps
+        for r in range(reps):
+            sb.wait(r, per_chain=False)
+        shard = {"chains": 512, "ms_per_query": sdt * 1e3, "predicted_strong_scaling_efficiency_at_8_gpus": dt / (8.0 * sdt),
+                 "what": "one rank's shard of the 8-GPU run (512 of the 4096 chains) on this GPU, enqueues back to back; the prediction leaves out the "
+                         "all-gather of eight 64-byte records.  No multi-GPU run was measured"}
     # the dominant kernel of this config (the gather correlate) against its counters: duration measured here (HIP events on
     # the matcher's stream around the correlate stage, lists excluded), counters replayed from profiles/counters.json
     roof = None
@@ -438,7 +471,7 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     return {"chains": args.cfg4_chains, "chains_per_gpu": hi - lo, "lattice": "41x41x21", "scaling": "strong",
             "ms_per_query": dt * 1e3, "ms_per_query_first_use_of_the_slots": dt_first * 1e3, "one_shot_ms_incl_results": one_shot * 1e3,
             "chain_matches_per_s": args.cfg4_chains / dt, "hypotheses_per_s": hyp_total / dt,
-            "hypotheses": hyp_total, "winner": winner, "roofline": roof,
+            "hypotheses": hyp_total, "winner": winner, "roofline": roof, "cfg4_shard_512": shard,
             "collective": "all_gather of one 64-byte best record per rank" if dist is not None else "none"}
 
 
@@ -573,7 +606,10 @@ def main():
 
     line = {"metric": "pose hypotheses/sec", "value": None, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic", "config": {}, "roofline": None}
+            "dtype": "u8", "data": "synthetic", "config": {}, "roofline": None,
+            # which form of the cfg2 x batch workload `value` is measured on (rounds 2 - 4: "one_query"; from round 5 on every item has
+            # its own query: not like for like with the earlier rounds' values -- the old form is config.by_config.cfg2x_one_query)
+            "headline_workload": args.headline}
     line["device"] = {"name": props.name, "compute_units": DEVICE["cus"], "clock_hz": DEVICE["clock_hz"]}
     by_config = {}
 
@@ -762,6 +798,43 @@ def main():
                 "ms_per_step_spread": spread(oper), "hypotheses_per_s": hyp_step * world * osteps / odt,
                 "scan_matches_per_s": args.batch * world * osteps / odt,
                 "ratio_to_metric_line": (hyp_step * world * osteps / odt) / line["value"]}
+        # the same step function on HETEROGENEOUS problems: (query, chain) pairs along the cfg3 trajectory -- query i = scan 10 + i at its
+        # odometry prior, chain i = the ten scans before it at their true poses: every item its own pose, heading, window contents,
+        # region lists and patch counts (the metric's items all sit within 5 cm of ONE pose, as SURVEY 8(d) specifies them)
+        if "traj" in gen and pbatches is not None:
+            t_truth, t_prior = synth.loop_trajectory(args.batch + 10)
+            tscans = [synth.resident_scan(r_, p_) for r_, p_ in zip(gen["traj"], t_truth)]
+            tq = [synth.resident_scan(gen["traj"][10 + i_], t_prior[10 + i_]) for i_ in range(args.batch)]
+            native_many(tscans + tq, local_rank)
+            tb = [lanes[e % NL].make_pairs_batch(tq[e * LB:(e + 1) * LB], [tscans[i_:i_ + 10] for i_ in range(e * LB, (e + 1) * LB)]) for e in range(E)]
+            tper, _, _ = (tb[0].run_async(True, True, slot=0) or tb[0].wait(0))
+            for i_ in (0, LB // 3, LB - 1):  # (what is timed is right: three items against their single calls)
+                ref = m.match_scan(tq[i_], tscans[i_:i_ + 10], True, True)
+                assert not checked or (ref.response == tper[i_].response and ref.covariance == tper[i_].covariance), i_
+            tsteps = max(4, args.steps // 2)
+            tdt, tps = timed_steps(tb, tsteps, 2)
+            thyp = float(tper.array["hypotheses"].sum()) / LB * args.batch
+            for lm in lanes:
+                lm.profile(True)
+            for i in range(2):
+                step(i, tb, one_at_a_time=NL > 1)
+            drain()
+            tk = [0.0] * 6
+            for lm in lanes:
+                for w_ in range(3):
+                    a_, b_ = lm.profile_read(w_)
+                    tk[2 * w_] += a_
+                    tk[2 * w_ + 1] += b_
+                lm.profile(False)
+            by_config["cfg2x_trajectory"] = {
+                "what": "%d (query, chain) pairs per step along the cfg3 trajectory (query i = scan 10 + i at its odometry prior against the ten scans "
+                        "before it at their true poses): heterogeneous poses, headings and windows; same lanes and step function as the metric line" % args.batch,
+                "steps": tsteps, "ms_per_step": tdt / tsteps * 1e3, "ms_per_step_spread": spread(tps), "hypotheses_per_s": thyp * world * tsteps / tdt,
+                "scan_matches_per_s": args.batch * world * tsteps / tdt, "ratio_to_metric_line": (thyp * world * tsteps / tdt) / line["value"],
+                "region_correlate_us": tk[0] / max(tk[1], 1) * 1e3, "raster_us": tk[2] / max(tk[3], 1) * 1e3, "call_us_gpu": tk[4] / max(tk[5], 1) * 1e3,
+                "metric_line_region_correlate_us": corr_s * 1e6, "metric_line_call_us_gpu": call_ms / max(call_n, 1) * 1e3,
+                "mean_response": float(tper.array["response"].mean())}
+            del tb
         region = LB >= 8 and args.corr_region != 1
         # (the default region correlate of a large batch stages from the row-major window: template argument WIN = true)
         kernel = "ym::correlate_region_kernel<8, true>" if region else "ym::correlate_kernel<2, 16, 4>"
@@ -1121,6 +1194,10 @@ def main():
                                     "stay serial as in Karto (serial_fraction = their share of the wall time), host has "
                                     "%d logical cpus" % (cb["all"]["matches"], cb["all"]["seconds"], os.cpu_count() or 1)},
         }
+        # (BASELINE.md holds no published number for this metric: vs_baseline stays null; against this run's own CPU figures:)
+        if line["value"] and ct.get("hyp_per_s"):
+            line["vs_cpu_baseline"] = {"all_physical_cores": line["value"] / ct["hyp_per_s"], "one_thread": line["value"] / cb["single"]["hyp_per_s"],
+                                       "what": "value / cpu_baseline.throughput.value and / cpu_baseline.value: context, not credit (a CPU port of the oracle, not the reference's wheel)"}
         by_config["cfg1_cpu_single_match"] = {
             "ms_per_match": cb["single"]["ms_per_match"], "scan_matches_per_s": 1e3 / cb["single"]["ms_per_match"],
             "hypotheses_per_s": cb["single"]["hyp_per_s"], "what": "oracle/ym_oracle.c, karto semantics, 1 thread"}

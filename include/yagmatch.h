@@ -103,6 +103,8 @@ typedef struct ym_scan ym_scan;
 
 /* ---- library / device ---- */
 int ym_version(void);
+/* first 16 hex digits of the SHA-256 of the sources this library was built from (csrc/Makefile): ties a profile to a build */
+const char *ym_build_id(void);
 int ym_device_count(void);
 const char *ym_last_error(void);
 

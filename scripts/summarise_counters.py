@@ -18,16 +18,22 @@ def short(name):
 
 def main():
     tag = sys.argv[1]
-    out = {"tag": tag, "how": "rocprofv3 --pmc <one group per pass> (nothing else traced) + one --kernel-trace --stats pass, per workload; "
+    sys.path.insert(0, REPO)
+    from yag_slam_amd import _capi
+    out = {"tag": tag, "build_id": _capi.build_id(),  # (the library the passes ran on: bench.py replays the counters only on the same build)
+           "how": "rocprofv3 --pmc <one group per pass> (nothing else traced) + one --kernel-trace --stats pass, per workload; "
                               "scripts/profile_pmc.sh; FETCH_SIZE in KiB as reported (x 1024 x 2 = bytes on gfx950, MI355X_MICROARCH.md)",
            "workloads": {}}
     for wl, cmd in WORKLOADS.items():
         kern = collections.defaultdict(lambda: collections.defaultdict(list))
+        grids = collections.defaultdict(collections.Counter)
         for f in glob.glob(os.path.join(REPO, "gpurun_out", "%s_%s_*" % (tag, wl), "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if "ym::" in k:
                     kern[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    if r.get("Grid_Size"):
+                        grids[k][(int(r["Grid_Size"]), int(r.get("Workgroup_Size") or 0))] += 1
         stats = {}
         for f in glob.glob(os.path.join(REPO, "gpurun_out", "%s_%s_trace" % (tag, wl), "**", "*kernel_stats.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
@@ -40,6 +46,9 @@ def main():
                 v = sorted(v)
                 v = v[len(v) // 4:] if len(v) > 3 else v
                 d[c] = sum(v) / len(v)
+            if grids.get(k):  # the LARGEST launch of the kernel in the counter passes: work-items and work-group size
+                g = max(grids[k])
+                d["grid"] = {"work_items": g[0], "workgroup": g[1], "blocks": g[0] // g[1] if g[1] else None}
             ks[k] = d
         if ks:
             out["workloads"][wl] = {"command": cmd, "kernels": ks}

@@ -14,7 +14,7 @@ YM_OK = 0
 SEM = {"karto": 0, "yagpy": 1}
 
 EXPORTS = (
-    "ym_version", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
+    "ym_version", "ym_build_id", "ym_device_count", "ym_last_error", "ym_create", "ym_destroy", "ym_get_config",
     "ym_set_stream", "ym_synchronize", "ym_scan_create", "ym_scans_create", "ym_scans_destroy", "ym_scan_set_pose", "ym_scans_set_poses", "ym_scan_get_pose",
     "ym_scan_size", "ym_scan_structure_trusted", "ym_scan_destroy", "ym_match", "ym_match_scans", "ym_map_sequence", "ym_process_scan", "ym_sequence_stats", "ym_async_slots",
     "ym_match_scans_async", "ym_wait", "ym_match_batch", "ym_batch_create", "ym_batch_destroy", "ym_batch_size",
@@ -139,6 +139,7 @@ def lib():
     L.ym_version.restype = C.c_int
     L.ym_device_count.restype = C.c_int
     L.ym_last_error.restype = C.c_char_p
+    L.ym_build_id.restype = C.c_char_p
     L.ym_create.restype = vp
     L.ym_create.argtypes = [C.POINTER(YmConfig), C.c_int]
     L.ym_destroy.argtypes = [vp]
@@ -211,6 +212,11 @@ def lib():
                                C.POINTER(YmResult)]
     _lib = L
     return L
+
+
+def build_id():
+    """the library's build id: a hash of the sources it was built from (include/yagmatch.h, ym_build_id)"""
+    return lib().ym_build_id().decode()
 
 
 def check(rc):

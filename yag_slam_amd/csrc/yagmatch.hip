@@ -2558,6 +2558,11 @@ extern "C" {
 
 int ym_version(void) { return YM_VERSION; }
 
+#ifndef YM_BUILD_ID
+#define YM_BUILD_ID "unknown"
+#endif
+const char *ym_build_id(void) { return YM_BUILD_ID; }
+
 int ym_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
