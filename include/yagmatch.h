@@ -298,37 +298,49 @@ int ym_debug_query_local(ym_matcher *m, int item, double *out_xy, int32_t cap, i
  * out[(slot*max_n + i)*2 + {0,1}] = wx, wy  or (INT32_MIN, INT32_MIN) for filtered points */
 int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int32_t *max_n);
 
-/* development aid.  (option 0 no longer exists.)
- * 2: rasterise every tile of the window; 3: beams in flight per lane in the correlate kernel (16 / 32);
- * 4: extra LDS bytes per correlate block; 5: beam chunks per angle; 6: finish stage (0 = by batch size,
- * 1 = fine + final kernels, 2 = one-block finish kernel); 7: point cache of resident base scans (0 = on, 1 = off,
- * 2 = drop every entry); 8: point cache limit in KiB; 9: chunk-waves per correlate block; 10: order-dependent smear rule
- * always through the global-memory kernel; 11: threads per finish block (256 / 1024, 0 = by batch size);
- * 12: keep the coarse integer sums for ym_debug_sums whatever the call (by default: fewer than 8 items on a lattice of at most
- *     65536 hypotheses);
- * 13: merging of consecutive beams with the same lookup offset in the correlate kernel (0 = by grid coarseness, 1 = always,
- * 2 = never); 14: coarse correlate of batches (0 = the region correlate on lattices up to 26 x 32, the gather correlate on
- * others up to 48 x 64, else the direct kernel; 1 = always the direct kernel, 2 = the LDS correlates' per-cell path, 3 = their
- * "lists do not fit" path, 4 = the gather correlate also where the region correlate would run); 15: waves per
- * region-correlate block / angles per wave of the gather correlate; 16: raster blocks per item on batches (0 = sized by the
- * previous call's longest tile list; the rest of a list is walked by a second, small launch); 17: blocks per item of the gather
- * correlate (each takes a share of the angles); 18: room in the raster's per-tile hit lists on batches, in entries per tile
- * (0 = 32; -1 = no lists: every raster block scans the item's chunk boxes, as it does for an item whose lists do not fit);
- * 19: units per LDS buffer of the gather correlate (small values cut regions into chunks); 20: LDS bytes a gather block may
- * use (small values make the regions small); 23: 0 = single matches wait for a stream event instead
- * of polling the completion word; 24: 0 = the trigger chains of base scans are recomputed at every pose instead of taken
- * from the scan's creation-time structure; 25: tiles added around the raster rectangle a device-chained step predicts
- * (1; negative values make every chained step a fault); 26: 512 = the single-item prepare kernel with 512 threads per
- * scan; 28: batch size from which BOTH LDS correlates replace the direct kernel (at least 8; 0 = the defaults again: gather correlate 64, region correlate 48); 42: the region correlate's threshold alone (0 = 48); 29: 0 = the region path's pair lists are built on the call's stream instead of next to the raster on the matcher's second stream; 31: 0 = a synchronous match waits for the creation launch of a just-created query scan instead of reading its staged readings; 30: rows per raster tile, 32 or 64, whatever the call (0 = the host's choice: 64 for 512+ items over windows of 768+ cells); 21: 2 = the region correlate leaves the scoring of its sums to the score kernel
- * (0: it scores them itself unless option 12 asks for the integer sums); 32: form of the region correlate (0 / 1 = correlate_region_kernel; 2 = wave-specialised, 3 = one block per item, 4 = pooled, 5 = sixteen waves
- * per block with 43 = its region height 80 / 100 / 128 and 44 = the batch size from which it is the default, 6 = the gather correlate
- * compiled for three blocks per CU -- 2 .. 6 were measured slower or spill and exist only in builds made with -DYM_EXPERIMENTAL
- * (`make experimental`): the product library answers YM_ERR_UNSUPPORTED);
- * 45: 0 = the pair lists of a single-query batch are built at every call (default: a call whose query, pose, window and lattice
- * equal those of the matcher's last list build finds the lists in place); 41: items up to which the order-dependent smear
- * rule runs in its split form (8; 0 = one block per item always);
- * 46: YM_SEM_YAGPY matchers: 0 = the coarse pass of every item is scored pair by pair (the Python rule as written); default 1 = its
- * integer sums come from the production correlate kernels wherever the item's roundings provably form a lattice (ym_debug_counters). */
+/* Switches of the parity tests: every row names a path the tests force so that each kernel and each host decision is compared with
+ * the oracle (or with the default path) bit for bit.  None changes a result.  Development and timing switches that no test uses
+ * (2 - 5, 9, 23, 26, 29, 33 - 36, 38, 40, 42, 44) are described where they are implemented, yag_slam_amd/csrc/ym_abi_debug.hpp.
+ *
+ *   option  value                          effect
+ *   ------  -----------------------------  ------------------------------------------------------------------------------------------
+ *    6      0 / 1 / 2                      finish stage: by batch size / fine + final kernels / the one-block finish kernel
+ *    7      0 / 1 / 2                      point cache of resident base scans: on / off / drop every entry now
+ *    8      KiB                            point cache limit (small values force the start-over path)
+ *   10      1                              order-dependent smear rule always through the global-memory kernel
+ *   11      256 / 1024 / 0                 threads per finish block (0 = by batch size)
+ *   12      1                              keep the coarse integer sums for ym_debug_sums whatever the call (default: fewer than 8
+ *                                          items on a lattice of at most 65536 hypotheses)
+ *   13      0 / 1 / 2                      merging of consecutive beams with equal lookup offsets in the direct correlate: by grid
+ *                                          coarseness / always / never
+ *   14      0 / 1 / 2 / 3 / 4              coarse correlate of batches: region correlate on lattices up to 26 x 32 and gather correlate
+ *                                          on others up to 48 x 64 / always the direct kernel / the LDS correlates' per-cell path / their
+ *                                          "lists do not fit" path / the gather correlate also where the region correlate would run
+ *   15      n                              waves per region-correlate block / angles per wave of the gather correlate
+ *   16      n                              raster blocks per item on batches (0 = sized by the previous call's longest tile list)
+ *   17      n                              blocks per item of the gather correlate (each takes a share of the angles)
+ *   18      n / -1                         hit slots per entry of the raster's work list / no hit lists
+ *   19      n                              units per LDS buffer of the gather correlate (small values cut regions into chunks)
+ *   20      bytes                          LDS a gather block may use (small values make the regions small)
+ *   21      2                              the region correlate leaves the scoring of its sums to the score kernel
+ *   24      0                              trigger chains of base scans recomputed at every pose (not from the creation-time structure)
+ *   25      tiles                          margin around the raster rectangle a device-chained step predicts (negative: every step faults)
+ *   28      n / 0                          batch size from which BOTH LDS correlates replace the direct kernel (>= 8) / the defaults
+ *                                          (gather correlate 64, region correlate 48)
+ *   30      32 / 64 / 0                    rows per raster tile whatever the call / the host's choice
+ *   31      0                              a synchronous match waits for the creation launch of a just-created query scan
+ *   32      0 / 1, 2 .. 6                  form of the region correlate: correlate_region_kernel / the forms that lost (scripts/exp/forms),
+ *                                          only in builds made with `make experimental`: the product library answers YM_ERR_UNSUPPORTED
+ *   37      1                              the raster's row pass by bit scans instead of its tables
+ *   39      1                              every call writes the column planes and the region correlate stages from them
+ *   41      n                              items up to which the order-dependent smear rule runs in its split form (8; 0 = never)
+ *   43      80 / 100 / 128                 region height of experimental form 5
+ *   45      0                              the pair lists of a single-query batch are built at every call (default: a call whose query,
+ *                                          pose, window and lattice equal those of the last list build finds them in place)
+ *   46      0                              YM_SEM_YAGPY: every item's coarse pass scored pair by pair, the Python rule as written (default:
+ *                                          its integer sums come from the production correlate kernels wherever the item's roundings
+ *                                          provably form a lattice: ym_debug_counters)
+ */
 int ym_debug_option(ym_matcher *m, int option, int value);
 
 /* counters since ym_create, out[0 .. min(count, YM_DEBUG_COUNTERS)):

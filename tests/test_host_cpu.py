@@ -526,3 +526,38 @@ def test_oracle_under_sanitizers():
                        cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+
+
+def test_kernels_have_no_scratch_and_the_dominant_kernel_keeps_three_blocks_per_cu(tmp_path):
+    """The product library, compiled here for gfx950 with -Rpass-analysis=kernel-resource-usage (hipcc cross-compiles without a GPU):
+    no kernel may spill into scratch memory (a spill is 10 - 20 % of a latency-bound kernel: round 4 had four), and
+    correlate_region_kernel<8, true> -- 60 % of the metric's step -- must stay within the 80 VGPRs that three blocks of eight waves
+    per CU allow.  The lists' builder must keep the 64 VGPRs that let its block sit beside two region-correlate blocks."""
+    import re
+    import shutil
+    import subprocess
+    csrc = os.path.join(REPO, "yag_slam_amd", "csrc")
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this host")
+    out = str(tmp_path / "libyagmatch_check.so")
+    p = subprocess.run(["make", "-s", "-C", csrc, "OUT=" + out, "FLAGS_EXTRA=-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    kernels = {}
+    name = None
+    for line in p.stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip() or m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    assert len(kernels) >= 60, len(kernels)
+    spills = {k: v["ScratchSize"] for k, v in kernels.items() if v.get("ScratchSize", 0) > 0}
+    assert not spills, "kernels with scratch: %s" % spills
+    dom = [v for k, v in kernels.items() if k.startswith("void ym::correlate_region_kernel<8, true>")]
+    assert len(dom) == 1 and dom[0]["VGPRs"] <= 80 and dom[0]["Occupancy"] >= 6, dom
+    binp = [v for k, v in kernels.items() if k.startswith("void ym::bin_kernel<false, 18>")]
+    assert len(binp) == 1 and binp[0]["VGPRs"] <= 64, binp

@@ -38,7 +38,9 @@ namespace ym {
 #ifndef YM_GA_OCC512
 #define YM_GA_OCC512 6 // waves per SIMD blocks of up to 512 threads are compiled for (6: three blocks of eight waves per CU)
 #endif
+#ifndef YM_GA_PER
 #define YM_GA_PER 4          // 16-byte chunks of a class image a thread copies per work item
+#endif
 // bytes the host keeps past the last item's planes: a staged region may start up to 2 * (H + ny) + 3 rows and P bytes past
 // the last cell of the second plane (never gathered, but read)
 #define YM_GA_PLANES_SLACK(half_pitch, H, ny, P) ((size_t)(2 * ((H) + (ny)) + 4) * (size_t)(half_pitch) + (size_t)(P) + 256)
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(1024) void gather_percell_kernel(GatherArgs a) {
     const int32_t *cy = cx + a.dim_stride;
     const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     const int nq = st.nq;
+    const double add_x = a.g.semantics == 1 ? st.ylat[0] : st.off_x, add_y = a.g.semantics == 1 ? st.ylat[1] : st.off_y; // (ym_k_common.hpp, lookup_cell_sem)
 #pragma unroll
     for (int n = 0; n < NA; n++) {
         if (jk[n] < 0) continue;
@@ -659,13 +662,14 @@ __global__ __launch_bounds__(1024) void gather_percell_kernel(GatherArgs a) {
                 const uint32_t lj = a.lane_job[p2 * 64 + lane];
                 if (!(lj >> 16)) continue;
                 const int row = lj & 0xff, seg = (lj >> 8) & 0xff;
+#pragma unroll // (E / S are indexed by j: a loop the compiler leaves rolled puts them into scratch memory)
                 for (int j = 0; j < YM_GA_G; j++) {
                     const int ix = seg * YM_GA_G + j;
                     if (ix >= nx) break;
                     const int base = cy[row] * lin_pitch(a.g) + cx[ix];
                     unsigned sum = 0;
                     for (int i = i0; i < i1; i++)
-                        sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset_sem(a.g, ql[i], cs.x, cs.y, st.off_x, st.off_y, a.g.semantics == 1 ? st.ylat[0] : st.off_x, a.g.semantics == 1 ? st.ylat[1] : st.off_y, lin_pitch(a.g))));
+                        sum += cell_value(a.g, grid, limit, (unsigned)(base + lookup_offset_sem(a.g, ql[i], cs.x, cs.y, st.off_x, st.off_y, add_x, add_y, lin_pitch(a.g))));
                     // hypothesis j of dword j >> 2: even ones in E (low / high half), odd ones in S
                     if ((j & 1) == 0) E[n][p2][j >> 2] += sum << (8 * (j & 2));
                     else S[n][p2][j >> 2] += sum << (8 * (j & 2));

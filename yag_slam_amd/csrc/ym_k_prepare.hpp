@@ -503,9 +503,10 @@ template <int NT>
 __device__ __forceinline__ void structure_body(const StructureArgs &a, int sem, unsigned char *lds_raw, int *s_cnt) {
     const bool yag = sem == 1;
     const PrepLds l = prep_lds(lds_raw, a.sr.n);
-    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt, a.cidx[sem]);
+    // (no array of the argument record is indexed by a run-time value: that would put the record into scratch memory)
+    const int np = project_points<NT>(a.sr, 0.0, 0.0, 0.0, yag, l.sx, l.sy, s_cnt, yag ? a.cidx[1] : a.cidx[0]);
     const int unsafe = mark_chain<NT, true>(l, np, yag);
-    int2 *gov = reinterpret_cast<int2 *>(a.gov[sem]);
+    int2 *gov = reinterpret_cast<int2 *>(yag ? a.gov[1] : a.gov[0]);
     for (int i = threadIdx.x; i < np; i += NT) gov[i] = gov_walk(l, i, np, yag);
     if (a.ranges_out && sem == 0)
         for (int i = threadIdx.x; i < a.sr.n; i += NT) a.ranges_out[i] = a.sr.ranges[i];

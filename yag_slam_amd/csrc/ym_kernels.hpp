@@ -26,8 +26,9 @@
 #include "ym_k_correlate.hpp"
 #include "ym_k_finish.hpp"
 #include "ym_k_region.hpp"
-#include "ym_k_region2.hpp" // (its kernel is compiled only with -DYM_EXPERIMENTAL: measured slower, profiles/r05_region_study.md)
-#include "ym_k_item.hpp"
+#ifdef YM_EXPERIMENTAL // the correlate forms that lost (scripts/exp/forms; `make experimental` puts that directory on the include path)
+#include "ym_exp_forms.hpp"
+#endif
 #include "ym_k_gather.hpp"
 #include "ym_k_yagpy.hpp"
 #include "ym_k_occupancy.hpp"
