@@ -17,7 +17,7 @@ for w in 0 1 2; do
     timeout 120 rocprofv3 --pmc $ctr --output-format csv -d $out/${tag}_calib_${w}_$ctr -o calib -- ./scripts/exp/fetch_calib $w > $out/${tag}_calib_${w}_$ctr.log 2>&1
   done
 done
-python3 - <<'PY'
+TAG=$tag python3 - <<'PY'
 import csv, glob, os
 tag = os.environ.get("TAG", "r05a")
 for w in (0, 1, 2):

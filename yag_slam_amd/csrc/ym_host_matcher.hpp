@@ -35,6 +35,8 @@ struct ym_matcher {
     bool staged_queries = true;       // a synchronous match reads a just-created query scan from its staging slot instead of waiting
     int tile_h_forced = 0;            // tests: 32 or 64 rows per raster tile whatever the call
     int sticky_tall_left = 0;         // small calls that still take the tall tiles of the last large batch (plan_sizes)
+    int tall_pattern = 0;             // 0: no large batch yet, 1: the last call of a large window was a large batch, 2: a small call followed it
+    bool tall_alternates = false;     // the matcher has served a small call between two large batches
     int tall_tiles_min_window = 768;  // window width (cells) from which a batch of 512+ items gets 64-row tiles (256 items: 108 against 111 us of raster)
     YmGeom geom;                 // config part filled at create; window part per call
     std::vector<uint8_t> kernel; // Karto smear kernel (ksize x ksize)

@@ -75,9 +75,18 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
     //  single matches BETWEEN large batches therefore keeps the batches' tall tiles for its next 64 small calls -- 6 us per single
     //  match against a full raster of every window of the next batch, 2 ms per 4096 items: bench.py, cfg2x_alternating)
     {
+        // (round 6: only a matcher that has SHOWN the pattern -- a small call between two large batches -- keeps the tall tiles for its small
+        //  calls: the first small call after a large batch pays one reset of the window knowledge, and a matcher that never runs a large
+        //  batch again is not taxed 6 us per single match for its next 64 calls)
         bool tall = B >= 512 && g.win_w >= m->tall_tiles_min_window;
-        if (tall) m->sticky_tall_left = 64;
-        else if (m->sticky_tall_left > 0 && g.win_w >= m->tall_tiles_min_window && !call.chain_step) { tall = true; m->sticky_tall_left--; }
+        if (tall) {
+            if (m->tall_pattern == 2) m->tall_alternates = true; // large, small, large: it alternates
+            m->tall_pattern = 1;
+            m->sticky_tall_left = m->tall_alternates ? 64 : 0;
+        } else if (g.win_w >= m->tall_tiles_min_window && !call.chain_step) {
+            if (m->tall_pattern == 1) m->tall_pattern = 2;
+            if (m->sticky_tall_left > 0) { tall = true; m->sticky_tall_left--; }
+        }
         P.tile_h = m->tile_h_forced ? m->tile_h_forced : tall ? YM_TILE_H_TALL : YM_TILE_H;
     }
     P.tiles_x = (g.win_w + YM_TILE_W - 1) / YM_TILE_W;
@@ -172,7 +181,8 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
         P.rg_ng = ((max_n * 23 + 19) / 20 + YM_RG_FLUSH - 1) / YM_RG_FLUSH;
         P.rg_nbins = P.rg_nregions * lc.nt;
         P.region26 = !wrap && (!yag || lc.nx > 0) && !P.dedup && !call.slice && P.sx == 2 && B >= m->rg_min_batch && m->corr_region != 1 && m->corr_region != 4 && lc.nx <= 2 * YM_RG_G &&
-                     lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048;
+                     lc.ny <= 32 && P.rg_ng <= 8 && (int64_t)lc.nt * max_n <= YM_RG_MAX_ENTRIES && P.rg_nbins < YM_RG_MAX_BINS && max_n < 2048 &&
+                     half_w <= 4096; // (region_entry divides a class row below 4096 by the region height as a multiplication: a taller window takes the gather or the direct path)
         if (P.region26) {
             // fewer blocks than three per CU: deal every (item, angle block)'s regions out to several blocks (64 chains: the
             // kernel 121 -> 65 us with four, the enqueue 236 -> 205 us; 128 chains 317 -> 295 with two; scripts/dev/rsplit_time.py)
