@@ -418,7 +418,7 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     dt = timed_pass()
     # the per-GPU share of the 8-GPU run: this rank's first 512 chains alone (strong scaling predicted from one GPU: t(4096) / (8 t(512)))
     shard = None
-    if world == 1 and len(chains) >= 4096:
+    if world == 1 and len(chains) >= 4096 and not args.no_production_legs:  # (profiling runs: only launches of the config's own size)
         sb = loop_m.make_batch(query, chains[:512])
         srec = torch.zeros((reps, ymdist.RECORD), dtype=torch.float64, device="cuda")
         for r in range(reps):

@@ -9,15 +9,16 @@ tag=${1:-r05p}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for wl in cfg2x cfg4 cfg5; do
-  extra=""; [ $wl = cfg2x ] && extra="--no-production-legs --only-headline"
+  extra=""; [ $wl = cfg2x ] && extra="--no-production-legs --only-headline"; [ $wl = cfg4 ] && extra="--no-production-legs"
+  only=${2:-}; [ -n "$only" ] && [ "$only" != $wl ] && continue   # (second argument: one workload only)
   rm -rf $out/${tag}_${wl}_trace
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${wl}_trace -o ${tag} -- python3 bench.py --only $wl $extra --lanes 1 --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_${wl}_trace.log
+  timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${wl}_trace -o ${tag} -- python3 bench.py --only $wl $extra --lanes 1 --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_${wl}_trace.log
   for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum" "tcp:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" \
               "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
               "sq2:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"; do
     name=${spec%%:*}; ctr=${spec#*:}
     rm -rf $out/${tag}_${wl}_$name
-    timeout 300 rocprofv3 --pmc $ctr --kernel-exclude-regex "rocclr|at::native" --output-format csv -d $out/${tag}_${wl}_$name -o ${tag} -- python3 bench.py --only $wl $extra --lanes 1 --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_${wl}_$name.log
+    timeout 420 rocprofv3 --pmc $ctr --kernel-exclude-regex "rocclr|at::native" --output-format csv -d $out/${tag}_${wl}_$name -o ${tag} -- python3 bench.py --only $wl $extra --lanes 1 --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_${wl}_$name.log
   done
 done
 python3 scripts/summarise_counters.py ${tag} > $out/${tag}_counters.log 2>&1

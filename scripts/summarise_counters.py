@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKLOADS = {"cfg2x": "python3 bench.py --only cfg2x --no-production-legs --only-headline --lanes 1 --steps 2 --warmup 1",
-             "cfg4": "python3 bench.py --only cfg4 --lanes 1 --steps 2 --warmup 1",
+             "cfg4": "python3 bench.py --only cfg4 --no-production-legs --lanes 1 --steps 2 --warmup 1",
              "cfg5": "python3 bench.py --only cfg5 --lanes 1 --steps 2 --warmup 1"}
 
 
