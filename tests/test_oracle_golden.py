@@ -234,3 +234,20 @@ def test_oracle_reproduces_the_reference_sum_volumes(name):
     assert abs(r["response"] - float(z["response"])) <= 1e-12
     np.testing.assert_allclose(r["pose"], z["best_pose"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(r["cov"], z["covariance"], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference") and os.environ.get("YM_REGENERATE_GOLDENS") == "1"),
+                    reason="opt-in (YM_REGENERATE_GOLDENS=1, two minutes) and only where the reference is: the build container")
+def test_goldens_regenerate_bit_identically_from_the_reference():
+    """Every fixture under tests/golden/ is the output of a committed script that imports the reference (/root/reference); running
+    the five scripts again must leave the files as they are, byte for byte."""
+    import hashlib
+    import subprocess
+    import sys
+    gdir = GOLDEN
+    digest = lambda: {f: hashlib.sha256(open(os.path.join(gdir, f), "rb").read()).hexdigest()
+                      for f in sorted(os.listdir(gdir)) if f.endswith((".npz", ".bin"))}
+    before = digest()
+    for script in ("make_golden.py", "make_golden_chains.py", "make_golden_map.py", "make_golden_mapfile.py", "make_golden_sums.py"):
+        subprocess.check_call([sys.executable, os.path.join(gdir, script)], stdout=subprocess.DEVNULL)
+    assert digest() == before
