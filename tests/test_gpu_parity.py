@@ -368,6 +368,32 @@ def test_yagpy_irregular_items_fall_back_to_the_pairwise_kernel():
     assert a.response == b.response and a.covariance == b.covariance
 
 
+def test_yagpy_batch_with_regular_and_tie_items_side_by_side():
+    """One enqueue through the LDS correlates that holds items the lattice proof accepts at once, items with exact rounding ties that only
+    the exhaustive check can decide, and -- whatever that check says -- the same results as the pair-by-pair kernel for every item."""
+    from tests.util import load_case
+    from yag_slam_amd.scan_matching import ScanMatcher
+    c = load_case("small_pen1_fine1")
+    cfg = dict(c["cfg"], resolution=0.25, smear_deviation=0.25, search_size=1.0, range_threshold=4.0)
+    mk = lambda r, p: _mk_native(PlainScan(r, 0.0, np.pi / 6, 0.05, 4.0, p))
+    base = [mk(np.full(7, 1.125), (0.0, 0.0, 0.0)), mk(np.full(7, 1.3), (0.1, 0.05, 0.02))]
+    ties = mk(np.array([1.125, 1.0, 0.875, 1.125, 1.25, 1.125, 1.0]), (0.125, 0.0, 0.0))   # binary fractions: sums on cell boundaries
+    plain = mk(np.array([1.13, 1.02, 0.91, 1.17, 1.21, 1.09, 1.04]), (0.113, 0.021, 0.013))
+    queries = [ties, plain] * 5
+    chains = [base, base[:1]] * 5
+    fast, slow = ScanMatcher(cfg, semantics="yagpy"), ScanMatcher(cfg, semantics="yagpy")
+    fast.debug_option(28, 8)
+    slow.debug_option(46, 0)
+    a, b = fast.match_pairs(queries, chains, True, True), slow.match_pairs(queries, chains, True, True)
+    cnt = fast.debug_counters()
+    assert cnt["last_correlate"] in ("correlate_region_kernel", "gather_kernel")
+    assert cnt["yag_fast_items"] + cnt["yag_fallback_items"] == 10 and cnt["yag_fast_items"] >= 5 and cnt["yag_pairs_checked"] > 0, cnt
+    for i in range(10):
+        assert a[i].meta["coarse_dims"] == b[i].meta["coarse_dims"]
+        assert np.array_equal(fast.debug_sums(0, item=i, dims=a[i].meta["coarse_dims"]), slow.debug_sums(0, item=i, dims=b[i].meta["coarse_dims"])), i
+        assert (a[i].response, a[i].covariance) == (b[i].response, b[i].covariance), i
+
+
 def test_yagpy_device_matches_oracle_both_passes():
     from oracle import oracle as orc
     from tests.util import load_case

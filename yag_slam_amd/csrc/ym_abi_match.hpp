@@ -396,6 +396,14 @@ int ym_batch_run_async(ym_matcher *m, const ym_batch *b, int penalize, int refin
         call.batch_uid = b->uid;
         call.pose_epoch = epoch;
     }
+    if (same) {
+        // the batch is run AGAIN through a Call that was built on its queries' first use (no slot of the point cache then, see plan_cache):
+        // this is their second use -- they get their slots now, which takes one more planning of the call instead of a replay
+        bool first_use_plan = false;
+        for (int i = 0; i < nq; i++)
+            if (call.scans[i].query_uses == 0) { call.scans[i].query_uses = 1; first_use_plan = true; }
+        if (first_use_plan) call.plan_clean = false;
+    }
     call.coarse_angle_off = m->cfg.coarse_search_angle_offset;
     slot.chain_id_base = chain_id_base;
     slot.dev_best_out = dev_best_out;
