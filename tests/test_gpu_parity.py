@@ -394,6 +394,17 @@ def test_yagpy_batch_with_regular_and_tie_items_side_by_side():
         assert (a[i].response, a[i].covariance) == (b[i].response, b[i].covariance), i
 
 
+@pytest.mark.parametrize("seed", [1, 3])
+def test_yagpy_production_routes_on_random_problems(seed):
+    """tests/yag_soak.py: random problems (poses along a trajectory, a third of the seeds kilometres from the origin, dirty readings, three
+    configurations, single matches and batches through every correlate) solved with the coarse sums from the production kernels and pair
+    by pair: identical results and sum volumes, and the proof accepted every item (scripts/dev/r06_yag_soak.py runs many seeds)."""
+    from tests import yag_soak
+    bad, totals = yag_soak.run(seed, 24, verbose=False)
+    assert bad == 0
+    assert totals["yag_fast_items"] > 0 and totals["yag_fallback_items"] == 0, totals
+
+
 def test_yagpy_device_matches_oracle_both_passes():
     from oracle import oracle as orc
     from tests.util import load_case

@@ -1,0 +1,63 @@
+"""Random differential test of the "yagpy" coarse pass on the production correlate kernels (test infrastructure: tests/test_gpu_parity.py and
+scripts/dev/r06_yag_soak.py): random problems -- poses along the trajectory and far from the origin, random priors, chain lengths, dirty
+readings, three configurations, single matches and batches through every correlate -- each solved twice: by a matcher that takes the coarse
+sums of proven items from the production kernels, and by one that scores every (hypothesis, point) pair the Python way (option 46 = 0).
+Results and both sum volumes must be identical; returns (differences, counters of the fast matcher)."""
+import numpy as np
+
+
+def run(seed, ncalls, verbose=True):
+    from yag_slam_amd import synth
+    from yag_slam_amd.models import native_many
+    from yag_slam_amd.scan_matching import ScanMatcher
+    rng = np.random.default_rng(seed)
+    scene = synth.Scene()
+    n = 160
+    truth, prior = synth.loop_trajectory(n + 10)
+    ranges = synth.scan_ranges_many([(tuple(truth[i]), 7000 + i) for i in range(n + 10)], scene)
+    dirty = [scene.scan_ranges(tuple(truth[i]), index=8000 + i, dirty=True) for i in range(0, n + 10, 7)]
+    shift = (float(rng.uniform(-3000, 3000)), float(rng.uniform(-3000, 3000))) if seed % 3 == 0 else (0.0, 0.0)
+    base = [synth.resident_scan(ranges[i] if i % 7 else dirty[i // 7], (truth[i][0] + shift[0], truth[i][1] + shift[1], truth[i][2])) for i in range(n + 10)]
+    queries = [synth.resident_scan(ranges[10 + i], (prior[10 + i][0] + shift[0] + rng.uniform(-0.02, 0.02), prior[10 + i][1] + shift[1] + rng.uniform(-0.02, 0.02),
+                                                   prior[10 + i][2] + rng.uniform(-0.02, 0.02))) for i in range(n)]
+    native_many(base + queries, 0)
+    configs = [None, dict(resolution=0.05, search_size=4.0, smear_deviation=0.05), dict(search_size=0.3, resolution=0.02, smear_deviation=0.04, coarse_search_angle_offset=0.2, coarse_angle_resolution=0.05)]
+    pairs = []
+    for cfg in configs:
+        fast, slow = ScanMatcher(cfg, semantics="yagpy"), ScanMatcher(cfg, semantics="yagpy")
+        slow.debug_option(46, 0)
+        pairs.append((fast, slow))
+    key = lambda p: (p.response, p.best_pose.x, p.best_pose.y, p.best_pose.euler[-1], tuple(map(tuple, p.covariance)), p.meta["coarse_dims"], p.meta["fine_dims"])
+    bad = 0
+    totals = dict(yag_fast_items=0, yag_fallback_items=0, yag_pairs_checked=0, yag_pairs_failed=0)
+    for call in range(ncalls):
+        ci = int(rng.integers(0, len(configs)))
+        fast, slow = pairs[ci]
+        nb = int(rng.choice([1, 1, 3, 9, 20, 64]))
+        lo = int(rng.integers(0, n - nb))
+        clen = int(rng.integers(1, 11))
+        pen, fine = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        route = int(rng.integers(0, 3))
+        fast.debug_option(28, 8 if route else 0)
+        fast.debug_option(14, 4 if route == 2 else 0)
+        qs = queries[lo:lo + nb]
+        chains = [base[lo + i + 10 - clen:lo + i + 10] for i in range(nb)]
+        if nb == 1:
+            a, b = [fast.match_scan(qs[0], chains[0], pen, fine)], [slow.match_scan(qs[0], chains[0], pen, fine)]
+        else:
+            a, b = fast.match_pairs(qs, chains, pen, fine), slow.match_pairs(qs, chains, pen, fine)
+        same = all(key(x) == key(y) for x, y in zip(a, b))
+        for i in (0, nb - 1):
+            same = same and np.array_equal(fast.debug_sums(0, item=i, dims=a[i].meta["coarse_dims"]), slow.debug_sums(0, item=i, dims=b[i].meta["coarse_dims"]))
+        if not same:
+            bad += 1
+            print("call %d (config %d, %d items from %d, chain %d, pen %d fine %d, route %d) DIFFERS" % (call, ci, nb, lo, clen, pen, fine, route))
+    for fast, slow in pairs:
+        c = fast.debug_counters()
+        for k in totals:
+            totals[k] += c[k]
+        fast.close()
+        slow.close()
+    if verbose:
+        print("seed %d: %d calls, %d differed; %s" % (seed, ncalls, bad, totals))
+    return bad, totals
