@@ -367,9 +367,19 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
     records = torch.zeros((reps, ymdist.RECORD), dtype=torch.float64, device="cuda")
     gathered = torch.zeros((reps, world * ymdist.RECORD), dtype=torch.float64, device="cuda")
 
+    class _Done(object):
+        def wait(self):
+            return True
+
     def once(r):
         sh.run_async(records[r], False, False, slot=r)
         if dist is not None:
+            if ymdist._staged_through_host(records[r]):  # (the one-GPU dry run over gloo: through host copies, on the matcher's stream)
+                with torch.cuda.stream(sh.torch_stream):
+                    h = torch.empty(gathered[r].shape, dtype=torch.float64)
+                    dist.all_gather_into_tensor(h, records[r].cpu())
+                    gathered[r].copy_(h)
+                return _Done()
             return dist.all_gather_into_tensor(gathered[r], records[r], async_op=True)
         gathered[r].copy_(records[r])
         return None
@@ -438,13 +448,15 @@ def leg_cfg4(loop_m, gen, args, rank, world, torch, dist):
                          "all-gather of eight 64-byte records.  No multi-GPU run was measured"}
     # the dominant kernel of this config (the gather correlate) against its counters: duration measured here (HIP events on
     # the matcher's stream around the correlate stage, lists excluded), counters replayed from profiles/counters.json
+    # (EVERY rank runs the pass: it holds the all-gathers of its enqueues.  Until round 6 only rank 0 did -- sixteen collectives the other ranks
+    #  never entered: the N > 1 path would have hung here; found by the two-rank dry run on one GPU, scripts/dev/r06_two_ranks_bench.sh)
     roof = None
+    loop_m.profile(True)
+    timed_pass()
+    corr_ms, corr_n = loop_m.profile_read(0)
+    loop_m.profile_read(1); loop_m.profile_read(2)
+    loop_m.profile(False)
     if rank == 0:
-        loop_m.profile(True)
-        timed_pass()
-        corr_ms, corr_n = loop_m.profile_read(0)
-        loop_m.profile_read(1); loop_m.profile_read(2)
-        loop_m.profile(False)
         if corr_n:
             # (round 5: the kernel funnels with v_perm like the region correlate -- that loop body's measured peak; its name carries
             #  the launch bound since then, the tree's older counter files do not)
@@ -544,11 +556,20 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if os.environ.get("YM_BENCH_WATCHDOG"):  # development: after that many seconds every thread's stack goes to stderr and the rank exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["YM_BENCH_WATCHDOG"]), exit=True)
     # stdout carries exactly ONE line, the JSON; libraries that print there (RCCL's version banner) go to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development: YM_BENCH_ONE_GPU=1 puts every rank on device 0 and moves the collectives over gloo (records staged through the host) --
+    # the code path of --gpus N with N real ranks on a box with ONE GPU (RCCL refuses two ranks on one device).  A dry run of the
+    # N > 1 logic (sharding, aggregation, barriers), not a scaling measurement: the ranks share the device.
+    one_gpu = os.environ.get("YM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -569,7 +590,23 @@ def main():
     dist = None
     if world > 1 or os.environ.get("YM_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path with one rank
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    class _Done(object):  # (what an async collective returns, for the host-staged form)
+        def wait(self):
+            return True
+
+    def all_gather_records(out, mine):
+        """all_gather_into_tensor of device tensors: RCCL, asynchronous -- or, in the one-GPU dry run, through host copies over gloo"""
+        if not one_gpu:
+            return dist.all_gather_into_tensor(out, mine, async_op=True)
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, mine.cpu())
+        out.copy_(h)
+        return _Done()
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline leg: no spinning OpenMP workers
     from yag_slam_amd import dist as ymdist
@@ -681,7 +718,7 @@ def main():
                 # step's records (on every lane's stream), the launch streams go straight on to the next step
                 for ls in lane_streams[1:]:
                     lane_streams[0].wait_stream(ls)
-                works[b] = dist.all_gather_into_tensor(gathered[b], records[b].view(-1), async_op=True)
+                works[b] = all_gather_records(gathered[b], records[b].view(-1))
 
         def drain():
             for ln in range(NL):
