@@ -65,6 +65,7 @@ def parse_args(argv=None):
                     help="which cfg2x workload the metric line times: every item against the SAME query object, or every item with its own query")
     ap.add_argument("--no-production-legs", action="store_true",
                     help="skip cfg2x_batch_sweep / _fresh_query / _cold (profiling runs: only launches of the metric's batch size)")
+    ap.add_argument("--legs", default="", help="development: comma list of production legs of cfg2x to run (cfg2x_yagpy, cfg2x_fresh_scans, ...); default all")
     ap.add_argument("--cfg4-chains", type=int, default=CFG4_CHAINS)
     ap.add_argument("--cfg3-scans", type=int, default=CFG3_SCANS)
     ap.add_argument("--corr-u", type=int, default=0, help="development: beams in flight per lane in the correlate kernel")
@@ -1139,6 +1140,8 @@ def main():
                 sweep_legs += [("cfg2x_fresh_scans", leg_fresh_scans), ("cfg2x_yagpy", leg_yagpy)]
         else:
             sweep_legs = []
+        if args.legs:
+            sweep_legs = [(k_, f_) for k_, f_ in sweep_legs if k_ in args.legs.split(",")]
         del batches, pbatches
         for lm in lanes[1:]:
             lm.close()

@@ -336,6 +336,8 @@ def test_yagpy_coarse_sums_through_the_production_kernels(name, route):
     assert (cnt["yag_fast_items"], cnt["yag_fallback_items"]) == (9, 0)
     for i in (0, 3, 6, 8):
         assert np.array_equal(m.debug_sums(0, item=i, dims=per[i].meta["coarse_dims"]).astype(np.int64), want), i
+        if c["do_fine"] and "fine_sums" in z.files:  # (yag_fine_kernel inside a batch, against the reference's own fine volume)
+            assert np.array_equal(m.debug_sums(1, item=i, dims=per[i].meta["fine_dims"]).astype(np.int64), z["fine_sums"]), i
         check_result(per[i])
     # the shorter chain: against the pair-by-pair kernel (a single call with the production routes off)
     ref = ScanMatcher(c["cfg"], semantics="yagpy")
@@ -365,6 +367,8 @@ def test_yagpy_irregular_items_fall_back_to_the_pairwise_kernel():
     assert cnt["yag_fast_items"] + cnt["yag_fallback_items"] == 1
     assert a.meta["coarse_dims"] == b.meta["coarse_dims"]
     assert np.array_equal(fast.debug_sums(0, dims=a.meta["coarse_dims"]), slow.debug_sums(0, dims=b.meta["coarse_dims"]))  # ... and nothing changed
+    assert a.meta["fine_dims"] == b.meta["fine_dims"]  # the fine pass by rows meets the same ties (its step is one cell of 0.25)
+    assert np.array_equal(fast.debug_sums(1, dims=a.meta["fine_dims"]), slow.debug_sums(1, dims=b.meta["fine_dims"]))
     assert a.response == b.response and a.covariance == b.covariance
 
 
@@ -391,6 +395,8 @@ def test_yagpy_batch_with_regular_and_tie_items_side_by_side():
     for i in range(10):
         assert a[i].meta["coarse_dims"] == b[i].meta["coarse_dims"]
         assert np.array_equal(fast.debug_sums(0, item=i, dims=a[i].meta["coarse_dims"]), slow.debug_sums(0, item=i, dims=b[i].meta["coarse_dims"])), i
+        assert a[i].meta["fine_dims"] == b[i].meta["fine_dims"]
+        assert np.array_equal(fast.debug_sums(1, item=i, dims=a[i].meta["fine_dims"]), slow.debug_sums(1, item=i, dims=b[i].meta["fine_dims"])), i
         assert (a[i].response, a[i].covariance) == (b[i].response, b[i].covariance), i
 
 

@@ -49,6 +49,8 @@ def run(seed, ncalls, verbose=True):
         same = all(key(x) == key(y) for x, y in zip(a, b))
         for i in (0, nb - 1):
             same = same and np.array_equal(fast.debug_sums(0, item=i, dims=a[i].meta["coarse_dims"]), slow.debug_sums(0, item=i, dims=b[i].meta["coarse_dims"]))
+            if fine and same:  # the fine pass by rows (yag_fine_kernel) against the pair-by-pair kernel
+                same = np.array_equal(fast.debug_sums(1, item=i, dims=a[i].meta["fine_dims"]), slow.debug_sums(1, item=i, dims=b[i].meta["fine_dims"]))
         if not same:
             bad += 1
             print("call %d (config %d, %d items from %d, chain %d, pen %d fine %d, route %d) DIFFERS" % (call, ci, nb, lo, clen, pen, fine, route))

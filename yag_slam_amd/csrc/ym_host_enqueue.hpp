@@ -155,11 +155,11 @@ int enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
         }
         a.coarse_angle_res = m->cfg.coarse_angle_resolution;
         a.states = m->states.p; a.host_out = reinterpret_cast<YmItemState *>(slot.result.dp);
-        a.qlocal = m->qlocal.p; a.axes = m->yaxes.p; a.rot = m->yrot.p;
+        a.qlocal = m->qlocal.p; a.axes = m->yaxes.p; a.rot = nullptr; // (the kernels rotate the points themselves)
         a.sums = m->sums.p + m->sums_pass_offset[pass]; a.out = m->resp.p;
         a.grid = m->grid.p; a.grid_stride = P.grid_stride; a.vol_stride = P.yvol;
         a.max_n = P.max_n; a.maxd = P.ymaxd; a.maxt = P.ymaxt;
-        hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(P.ymaxt, P.B), dim3(256), 0, m->stream, a);
+        hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(1, P.B), dim3(256), 0, m->stream, a);
         if (pass == 0 && P.lc.nx > 0) {
             // the coarse pass's integer sums from the production correlate kernels (the one the batch size and the lattice select, as in
             // Karto semantics) for every item whose roundings yag_lattice_kernel proves to form a lattice; yag_score_kernel then
@@ -171,6 +171,11 @@ int enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
             int rc = enqueue_correlate(m, P);
             if (rc) return rc;
             enqueue_score(m, slot, P);
+        }
+        if (pass == 1 && m->yag_fast) {
+            // the fine pass by rows (ym_k_yagpy.hpp, yag_fine_kernel); yag_score_kernel then only takes the items it left (a wider fine lattice: none)
+            a.fine_rows = 1;
+            hipLaunchKernelGGL(ym::yag_fine_kernel, dim3(P.ymaxt, P.B), dim3(256), 0, m->stream, a);
         }
         hipLaunchKernelGGL(ym::yag_score_kernel, dim3((P.ymaxd * P.ymaxd + 255) / 256, P.ymaxt, P.B), dim3(256), 0, m->stream, a);
         hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(P.B), dim3(1024), 0, m->stream, a);

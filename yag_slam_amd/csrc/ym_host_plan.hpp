@@ -350,7 +350,6 @@ int plan_sizes(ym_matcher *m, Slot &slot, CallPlan &P) {
             HIP_TRY(hipMemsetAsync(m->yag_counters.p, 0, m->yag_counters.cap * sizeof(unsigned long long), m->stream));
         }
         if ((rc = m->yaxes.ensure((size_t)B * 3 * YM_YAG_MAX_DIM))) return rc;
-        if ((rc = m->yrot.ensure((size_t)B * P.ymaxt * max_n))) return rc;
     }
     if ((rc = m->blockmax.ensure((size_t)B * P.score_blocks))) return rc;
     if ((rc = m->probs.ensure((size_t)B * lc.nx * lc.ny))) return rc;

@@ -13,6 +13,7 @@ namespace ym {
 // form a lattice -- every hot correlate kernel is then checked bit for bit against sum volumes the reference's own
 // score_world_points_on_grid produced (tests/golden/*.npz: coarse_sums) -- and from yag_score_kernel for the items it cannot
 // (counted: ym_debug_counter).  Arg-max, tie mean and covariances stay yag_reduce_kernel's: the Python path's own rules.
+#define YM_YAG_FINE_DIM 5 // positions per axis of the fine pass that yag_fine_kernel keeps in registers (numpy.arange(-2 res, 2 res, res): 4 or 5)
 struct YagArgs {
     YmGeom g;
     int32_t pass;        // 0 coarse, 1 fine
@@ -25,7 +26,8 @@ struct YagArgs {
     YmItemState *host_out;
     const double2 *qlocal;
     double *axes;        // [B][3][YM_YAG_MAX_DIM] xvals, yvals, tvals
-    double2 *rot;        // [B][maxt][max_n] points rotated by tvals[k]
+    double2 *rot;        // [B][maxt][max_n] points rotated by tvals[k] (prebuilt maps); nullptr: the kernels rotate the points themselves
+                         // (the same two products and one sum per coordinate: 0.9 GB less to write and read per pass of 4096 matches)
     uint32_t *sums;      // [B][maxt][maxd][maxd] -> stored dense as [k][iy][ix] with the pass's nx, ny
     double *out;         // same shape, fp64 scores
     const uint8_t *grid;
@@ -47,6 +49,7 @@ struct YagArgs {
     int32_t *hypcell;        // [B][2][dim_stride]
     const uint32_t *lsums;   // [B][lat_nt][lat_ny][lat_nx] integer sums of the launch lattice (score_kernel / score_hyp_kernel / gather_kernel)
     size_t lsums_stride;
+    int32_t fine_rows, pad_f;     // pass 1: yag_fine_kernel scores the items whose fine lattice is at most YM_YAG_FINE_DIM wide (all of them)
     unsigned long long *counters; // [0] items whose coarse pass went through the production kernels, [1] items that fell back to yag_score_kernel,
                                   // [2] (point, angle) pairs that needed the exhaustive check, [3] pairs that failed it
 };
@@ -63,7 +66,10 @@ __device__ __forceinline__ double yag_arange_at(double start, double step, int i
     return start + i * (second - start);
 }
 
-// grid (maxt, B), 256 threads: block k rotates the points by tvals[k]; block 0 also writes the axes.
+// helpers.py:76-78 _rotate_points
+__device__ __forceinline__ double2 yag_rotate(double2 p, double c, double s) { return make_double2(p.x * c - p.y * s, p.y * c + p.x * s); }
+
+// grid (maxt, B), 256 threads: block k rotates the points by tvals[k]; block 0 also writes the axes.  (rot == nullptr: grid (1, B), the axes only.)
 __global__ __launch_bounds__(256) void yag_setup_kernel(YagArgs a) {
     const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
     YmItemState &st = a.states[b];
@@ -80,15 +86,12 @@ __global__ __launch_bounds__(256) void yag_setup_kernel(YagArgs a) {
         for (int i = tid; i < ny; i += 256) ax[YM_YAG_MAX_DIM + i] = yag_arange_at(-a.search_xy + cy, a.step_xy, i);
         for (int i = tid; i < nt; i += 256) ax[2 * YM_YAG_MAX_DIM + i] = yag_arange_at(-a.search_t + ct, a.step_t, i);
     }
-    if (k >= nt) return;
+    if (k >= nt || !a.rot) return;
     const double t = yag_arange_at(-a.search_t + ct, a.step_t, k);
     const double c = cos(t), s = sin(t);
     const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     double2 *rot = a.rot + ((size_t)b * a.maxt + k) * a.max_n;
-    for (int l = tid; l < st.nq; l += 256) { // helpers.py:76-78 _rotate_points
-        const double2 p = ql[l];
-        rot[l] = make_double2(p.x * c - p.y * s, p.y * c + p.x * s);
-    }
+    for (int l = tid; l < st.nq; l += 256) rot[l] = yag_rotate(ql[l], c, s);
 }
 
 // When do the roundings of the coarse pass form a lattice?  (helpers.py:149-153 with x = xvals[i] + xx, helpers.py:194-196.)
@@ -117,16 +120,21 @@ __global__ __launch_bounds__(256) void yag_lattice_kernel(YagArgs a) {
     const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
     const double xv0 = ax[0], yv0 = ax[YM_YAG_MAX_DIM];
     const double ct = st.pose[2];
-    // (cos, sin) per angle of the launch lattice: the operands yag_setup_kernel rotated the points with
+    // (cos, sin) per angle of the launch lattice: the operands the Python rule rotates the points with (tvals[k] = numpy.arange's k-th value)
+    __shared__ double2 s_trig[YM_YAG_MAX_NT];
     for (int k = tid; k < a.lat_nt; k += NT) {
         const double t = yag_arange_at(-a.search_t + ct, a.step_t, k);
-        a.ctrig[(size_t)b * a.nt_stride + k] = make_double2(cos(t), sin(t));
+        const double2 cs = make_double2(cos(t), sin(t));
+        a.ctrig[(size_t)b * a.nt_stride + k] = cs;
+        if (k < YM_YAG_MAX_NT) s_trig[k] = cs;
     }
+    __syncthreads();
+    const double2 *ql = reinterpret_cast<const double2 *>(st.ql);
     int32_t *cx = a.hypcell + (size_t)b * 2 * a.dim_stride;
     int32_t *cy = cx + a.dim_stride;
     for (int i = tid; i < a.lat_nx; i += NT) cx[i] = i * a.step_cells;
     for (int i = tid; i < a.lat_ny; i += NT) cy[i] = i * a.step_cells;
-    int ok = nx > 0 && ny > 0 && nt > 0 && nx <= a.lat_nx && ny <= a.lat_ny && nt <= a.lat_nt;
+    int ok = nx > 0 && ny > 0 && nt > 0 && nx <= a.lat_nx && ny <= a.lat_ny && nt <= a.lat_nt && nt <= YM_YAG_MAX_NT;
     const double ox = st.off_x, oy = st.off_y, res = a.g.res;
     const double M = fabs(ox) + fabs(oy) + 2.0 * a.g.roi_w * res;
     const double guard = 8.0 * (max(nx, ny) + 8) * M * 1.1102230246251565e-16 / res + 9.094947017729282e-13;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void yag_lattice_kernel(YagArgs a) {
     if (ok)
         for (int p = tid; p < nq * nt; p += NT) {
             const int k = p / nq, l = p - k * nq;
-            const double2 r = a.rot[((size_t)b * a.maxt + k) * a.max_n + l];
+            const double2 r = a.rot ? a.rot[((size_t)b * a.maxt + k) * a.max_n + l] : yag_rotate(ql[l], s_trig[k].x, s_trig[k].y);
             const double ux = ((xv0 + r.x) - ox) / res, uy = ((yv0 + r.y) - oy) / res;
             const double gx = rint(ux), gy = rint(uy);
             // the window test in fp64 first: a cell number beyond int would be undefined behaviour below
@@ -163,41 +171,9 @@ __global__ __launch_bounds__(256) void yag_lattice_kernel(YagArgs a) {
     }
 }
 
-// grid (ceil(maxd*maxd/256), maxt, B): one thread per hypothesis (ix, iy) of angle k.
-// helpers.py:134-153: per point rint((p - o)/res), bounds check, int(100*cell) accumulate.
-// (pass 0 with lsums: the items yag_lattice_kernel proved regular take their sums from the production correlate kernels' volume.)
-__global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
-    const int b = blockIdx.z, k = blockIdx.y;
-    const YmItemState &st = a.states[b];
-    const int nx = st.ydims[a.pass][0], ny = st.ydims[a.pass][1], nt = st.ydims[a.pass][2];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nt || c >= nx * ny) return;
-    const int iy = c / nx, ix = c - iy * nx;
-    const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
-    const double xv = ax[ix], yv = ax[YM_YAG_MAX_DIM + iy], tv = ax[2 * YM_YAG_MAX_DIM + k];
-    const bool map = a.map_w > 0;
-    const double ox = map ? a.map_ox : st.off_x, oy = map ? a.map_oy : st.off_y, res = map ? a.map_res : a.g.res;
-    const int GW = map ? a.map_w : a.g.roi_w, GH = map ? a.map_h : a.g.roi_w;
-    const int w0 = map ? 0 : a.g.win_origin, ww = map ? a.map_w : a.g.win_w, wh = map ? a.map_h : a.g.win_w;
-    const int pitch = map ? a.map_w : a.g.pitch;
-    const double2 *__restrict__ rot = a.rot + ((size_t)b * a.maxt + k) * a.max_n;
-    const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
-    const int np = st.nq;
-    unsigned sum = 0;
-    if (a.lsums && st.regular[0]) sum = a.lsums[(size_t)b * a.lsums_stride + ((size_t)k * a.lat_ny + iy) * a.lat_nx + ix];
-    else
-#pragma unroll 4
-    for (int l = 0; l < np; l++) {
-        const double2 p = rot[l];
-        const double x = xv + p.x, y = yv + p.y;
-        const double gx = rint((x - ox) / res), gy = rint((y - oy) / res);
-        const int _x = (int)gx, _y = (int)gy;
-        if (_x >= 0 && _x < GW && _y >= 0 && _y < GH) {
-            const int wx = _x - w0, wy = _y - w0;
-            // cells outside the device window are provably empty (DESIGN.md section 3)
-            if (wx >= 0 && wx < ww && wy >= 0 && wy < wh) sum += grid[(size_t)wy * pitch + wx];
-        }
-    }
+// score of one hypothesis from its integer sum (helpers.py:165-196: the mean of int(100 * cell) over the points, times the penalties), stored
+__device__ __forceinline__ void yag_store_score(const YagArgs &a, const YmItemState &st, int b, int k, int iy, int ix, int nx, int ny, unsigned sum, int np,
+                                                double xv, double yv, double tv, double ox, double oy, double res, int GW, bool map) {
     double penalty_val = 1.0;
     if (a.penalize) {
         const double ct = a.pass ? st.ybest[0][3] : st.pose[2];
@@ -213,6 +189,134 @@ __global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
     const size_t at = (size_t)b * a.vol_stride + ((size_t)k * ny + iy) * nx + ix;
     a.sums[at] = sum;
     a.out[at] = (double)sum / np * penalty_val / 100.0;
+}
+
+// grid (ceil(maxd*maxd/256), maxt, B): one thread per hypothesis (ix, iy) of angle k.
+// helpers.py:134-153: per point rint((p - o)/res), bounds check, int(100*cell) accumulate.
+// (pass 0 with lsums: the items yag_lattice_kernel proved regular take their sums from the production correlate kernels' volume.)
+__global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
+    const int b = blockIdx.z, k = blockIdx.y;
+    const YmItemState &st = a.states[b];
+    const int nx = st.ydims[a.pass][0], ny = st.ydims[a.pass][1], nt = st.ydims[a.pass][2];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nt || c >= nx * ny) return;
+    if (a.fine_rows && nx <= YM_YAG_FINE_DIM && ny <= YM_YAG_FINE_DIM) return; // (pass 1: yag_fine_kernel has scored this item)
+    const int iy = c / nx, ix = c - iy * nx;
+    const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
+    const double xv = ax[ix], yv = ax[YM_YAG_MAX_DIM + iy], tv = ax[2 * YM_YAG_MAX_DIM + k];
+    const bool map = a.map_w > 0;
+    const double ox = map ? a.map_ox : st.off_x, oy = map ? a.map_oy : st.off_y, res = map ? a.map_res : a.g.res;
+    const int GW = map ? a.map_w : a.g.roi_w, GH = map ? a.map_h : a.g.roi_w;
+    const int w0 = map ? 0 : a.g.win_origin, ww = map ? a.map_w : a.g.win_w, wh = map ? a.map_h : a.g.win_w;
+    const int pitch = map ? a.map_w : a.g.pitch;
+    const double2 *__restrict__ rot = a.rot ? a.rot + ((size_t)b * a.maxt + k) * a.max_n : nullptr;
+    const double2 *__restrict__ ql = reinterpret_cast<const double2 *>(st.ql);
+    const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+    const int np = st.nq;
+    unsigned sum = 0;
+    if (a.lsums && st.regular[0]) sum = a.lsums[(size_t)b * a.lsums_stride + ((size_t)k * a.lat_ny + iy) * a.lat_nx + ix];
+    else {
+    const double rc = rot ? 0.0 : cos(tv), rs = rot ? 0.0 : sin(tv);
+#pragma unroll 4
+    for (int l = 0; l < np; l++) {
+        const double2 p = rot ? rot[l] : yag_rotate(ql[l], rc, rs);
+        const double x = xv + p.x, y = yv + p.y;
+        const double gx = rint((x - ox) / res), gy = rint((y - oy) / res);
+        const int _x = (int)gx, _y = (int)gy;
+        if (_x >= 0 && _x < GW && _y >= 0 && _y < GH) {
+            const int wx = _x - w0, wy = _y - w0;
+            // cells outside the device window are provably empty (DESIGN.md section 3)
+            if (wx >= 0 && wx < ww && wy >= 0 && wy < wh) sum += grid[(size_t)wy * pitch + wx];
+        }
+    }
+    }
+    yag_store_score(a, st, b, k, iy, ix, nx, ny, sum, np, xv, yv, tv, ox, oy, res, GW, map);
+}
+
+// The fine pass (pass 1: search +-2 cells at a step of one cell -- numpy.arange gives 4 or 5 positions per axis), exactly and without a
+// proof.  The cell hypothesis (ix, iy) reads for a point is (rint(((xv[ix] + r.x) - ox) / res), rint(((yv[iy] + r.y) - oy) / res)): its
+// column depends on ix alone and its row on iy alone (helpers.py:149-153), so a (point, angle) pair costs nx + ny roundings -- the same
+// operations on the same operands as yag_score_kernel's, 2 nx ny of them there -- and its nx ny reads are ny rows of nx neighbouring
+// bytes: one 8-byte read per row (two aligned dwords and a shift; a row whose columns do not fit the eight bytes -- a tie that falls
+// to the far side next to a misaligned start -- is read byte by byte).  yag_score_kernel, with a thread per hypothesis, runs this
+// pass on 25 lanes per (item, angle): 7 of the 12 ms of an enqueue of 4096 matches.  Here: grid (maxt, B), 256 threads; block (k, b)
+// walks the points of item b at fine angle k, a thread keeps its 25 sums in registers, the block adds them up and scores them.
+// Items with a wider fine lattice (none: the search is the reference's constant) are left to yag_score_kernel.
+__global__ __launch_bounds__(256) void yag_fine_kernel(YagArgs a) {
+    constexpr int NT = 256, D = YM_YAG_FINE_DIM;
+    __shared__ unsigned s_part[NT / 64][D * D];
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    const YmItemState &st = a.states[b];
+    const int nx = st.ydims[1][0], ny = st.ydims[1][1], nt = st.ydims[1][2];
+    if (k >= nt || nx > D || ny > D || nx * ny == 0) return; // (block-uniform)
+    const double *ax = a.axes + (size_t)b * 3 * YM_YAG_MAX_DIM;
+    double xv[D], yv[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) { xv[i] = i < nx ? ax[i] : 0.0; yv[i] = i < ny ? ax[YM_YAG_MAX_DIM + i] : 0.0; }
+    const double ox = st.off_x, oy = st.off_y, res = a.g.res;
+    const int GW = a.g.roi_w, w0 = a.g.win_origin, ww = a.g.win_w, pitch = a.g.pitch;
+    const double2 *__restrict__ rot = a.rot ? a.rot + ((size_t)b * a.maxt + k) * a.max_n : nullptr;
+    const double2 *__restrict__ ql = reinterpret_cast<const double2 *>(st.ql);
+    const uint8_t *__restrict__ grid = a.grid + (size_t)b * a.grid_stride;
+    const int np = st.nq;
+    __shared__ double2 s_cs;
+    if (tid == 0 && !rot) { const double t = ax[2 * YM_YAG_MAX_DIM + k]; s_cs = make_double2(cos(t), sin(t)); } // (tvals[k], written by yag_setup_kernel)
+    __syncthreads();
+    const double rc = rot ? 0.0 : s_cs.x, rs = rot ? 0.0 : s_cs.y;
+    unsigned sum[D * D];
+#pragma unroll
+    for (int h = 0; h < D * D; h++) sum[h] = 0u;
+    for (int l = tid; l < np; l += NT) {
+        const double2 p = rot ? rot[l] : yag_rotate(ql[l], rc, rs);
+        int wx[D], wy[D]; // window column / row of hypothesis i, -1: outside the grid or the window (such a read adds nothing)
+        int first = -1, span = 0;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const double x = xv[i] + p.x, y = yv[i] + p.y;
+            const double gx = rint((x - ox) / res), gy = rint((y - oy) / res);
+            const int _x = (int)gx, _y = (int)gy;
+            const int cx = _x - w0, cy = _y - w0;
+            wx[i] = (i < nx && _x >= 0 && _x < GW && cx >= 0 && cx < ww) ? cx : -1;
+            wy[i] = (i < ny && _y >= 0 && _y < GW && cy >= 0 && cy < ww) ? cy : -1;
+            if (wx[i] >= 0) { // (columns do not decrease with i: the first one inside is the lowest)
+                if (first < 0) first = wx[i];
+                span = wx[i] - first;
+            }
+        }
+        if (first < 0) continue;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            if (wy[j] < 0) continue;
+            const uint8_t *row = grid + (size_t)wy[j] * pitch;
+            const uintptr_t at = reinterpret_cast<uintptr_t>(row + first);
+            const unsigned mis = (unsigned)(at & 3u);
+            if (span + (int)mis <= 7) {
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(at - mis);
+                const unsigned long long v = ((unsigned long long)w[0] | (unsigned long long)w[1] << 32) >> (8u * mis);
+#pragma unroll
+                for (int i = 0; i < D; i++)
+                    if (wx[i] >= 0) sum[j * D + i] += (unsigned)(v >> (8 * (wx[i] - first))) & 0xffu;
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; i++)
+                    if (wx[i] >= 0) sum[j * D + i] += row[wx[i]];
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < D * D; h++) sum[h] = wave_reduce(sum[h], OpAddU());
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int h = 0; h < D * D; h++) s_part[tid >> 6][h] = sum[h];
+    __syncthreads();
+    if (tid < D * D) {
+        const int iy = tid / D, ix = tid - iy * D;
+        if (ix < nx && iy < ny) {
+            unsigned total = 0;
+            for (int w = 0; w < NT / 64; w++) total += s_part[w][tid];
+            yag_store_score(a, st, b, k, iy, ix, nx, ny, total, np, ax[ix], ax[YM_YAG_MAX_DIM + iy], ax[2 * YM_YAG_MAX_DIM + k], ox, oy, res, GW, false);
+        }
+    }
 }
 
 // grid (B), 1024 threads: np.argmax (first maximum in the reference's [ix][iy][k] order), mean of
