@@ -68,3 +68,34 @@ def test_ordinary_readings_pass_the_guard():
     u0 = ((xv[0] + r) - ox) / res
     assert guard < 1e-9
     assert np.all(np.abs(u0 - np.round(u0)) < 0.5 - guard)
+
+
+@pytest.mark.parametrize("res", [0.01, 0.05, 0.02, 0.005, 0.25, 0.03])
+def test_reciprocal_rounding_guard_implies_the_division(res):
+    """yag_rint_div (ym_k_yagpy.hpp): the fine pass takes rint(d * fl(1 / res)) for rint(d / res) whenever the product lies farther than
+    2^-50 |q| + 1e-12 from a rounding tie.  Attacked here with d placed from 1e-17 to 1e-9 cells off a tie, at cell numbers up to 10^9:
+    whenever the guard accepts, the two roundings agree; and some of the pairs it rejects do differ (the attack is real)."""
+    rng = np.random.default_rng(int(res * 1e4))
+    rres = 1.0 / res
+    n_accept = n_reject = n_differ = 0
+    for scale in (1e1, 1e3, 1e5, 1e7, 1e9):
+        cells = np.round(rng.uniform(-scale, scale, size=200000))
+        delta = rng.choice([-1.0, 1.0], size=cells.size) * 10.0 ** rng.uniform(-17, -9, size=cells.size) * np.maximum(1.0, np.abs(cells) * 1e-7)
+        delta[::5] = 0.0
+        d = (cells + 0.5 + delta) * res
+        for dd in (d, np.nextafter(d, np.inf), np.nextafter(d, -np.inf)):
+            q = dd * rres
+            n = np.round(q)
+            accept = np.abs(q - n) < 0.5 - (np.abs(q) * 2.0 ** -50 + 1e-12)
+            exact = np.round(dd / res)
+            assert np.array_equal(n[accept], exact[accept])
+            n_accept += int(accept.sum())
+            n_reject += int((~accept).sum())
+            n_differ += int((n[~accept] != exact[~accept]).sum())
+    # ordinary coordinates: nothing is rejected
+    d = rng.uniform(-30.0, 30.0, size=500000)
+    q = d * rres
+    assert np.all(np.abs(q - np.round(q)) < 0.5 - (np.abs(q) * 2.0 ** -50 + 1e-12)) or res == 0.25  # (0.25: binary fractions can tie)
+    assert n_reject > 0 and n_accept > 0, (n_accept, n_reject, n_differ)
+    if res != 0.25:  # (a power of two: its reciprocal is exact and the two roundings never differ)
+        assert n_differ > 0, (n_accept, n_reject, n_differ)

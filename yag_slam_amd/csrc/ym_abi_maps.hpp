@@ -175,7 +175,7 @@ int ym_match_map(ym_matcher *m, const ym_map *mp, double ox, double oy, const ym
         a.map_w = mp->width; a.map_h = mp->height; a.map_ox = ox; a.map_oy = oy;
         hipLaunchKernelGGL(ym::yag_setup_kernel, dim3(maxt, 1), dim3(256), 0, st, a);
         hipLaunchKernelGGL(ym::yag_score_kernel, dim3((maxd * maxd + 255) / 256, maxt, 1), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(1), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(ym::yag_reduce_kernel<1024>, dim3(1), dim3(1024), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));

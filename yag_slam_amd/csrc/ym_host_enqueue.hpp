@@ -175,10 +175,13 @@ int enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
         if (pass == 1 && m->yag_fast) {
             // the fine pass by rows (ym_k_yagpy.hpp, yag_fine_kernel); yag_score_kernel then only takes the items it left (a wider fine lattice: none)
             a.fine_rows = 1;
-            hipLaunchKernelGGL(ym::yag_fine_kernel, dim3(P.ymaxt, P.B), dim3(256), 0, m->stream, a);
+            a.n_items = P.B;
+            if (P.B >= 64) hipLaunchKernelGGL(ym::yag_fine_kernel<64>, dim3(8 * P.ymaxt * ((P.B + 7) / 8)), dim3(64), 0, m->stream, a);
+            else hipLaunchKernelGGL(ym::yag_fine_kernel<256>, dim3(8 * P.ymaxt * ((P.B + 7) / 8)), dim3(256), 0, m->stream, a);
         }
         hipLaunchKernelGGL(ym::yag_score_kernel, dim3((P.ymaxd * P.ymaxd + 255) / 256, P.ymaxt, P.B), dim3(256), 0, m->stream, a);
-        hipLaunchKernelGGL(ym::yag_reduce_kernel, dim3(P.B), dim3(1024), 0, m->stream, a);
+        if (P.B >= 16) hipLaunchKernelGGL(ym::yag_reduce_kernel<256>, dim3(P.B), dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL(ym::yag_reduce_kernel<1024>, dim3(P.B), dim3(1024), 0, m->stream, a);
     }
     return YM_OK;
 }

@@ -49,7 +49,7 @@ struct YagArgs {
     int32_t *hypcell;        // [B][2][dim_stride]
     const uint32_t *lsums;   // [B][lat_nt][lat_ny][lat_nx] integer sums of the launch lattice (score_kernel / score_hyp_kernel / gather_kernel)
     size_t lsums_stride;
-    int32_t fine_rows, pad_f;     // pass 1: yag_fine_kernel scores the items whose fine lattice is at most YM_YAG_FINE_DIM wide (all of them)
+    int32_t fine_rows, n_items;     // pass 1: yag_fine_kernel scores the items whose fine lattice is at most YM_YAG_FINE_DIM wide (all of them)
     unsigned long long *counters; // [0] items whose coarse pass went through the production kernels, [1] items that fell back to yag_score_kernel,
                                   // [2] (point, angle) pairs that needed the exhaustive check, [3] pairs that failed it
 };
@@ -233,19 +233,39 @@ __global__ __launch_bounds__(256) void yag_score_kernel(YagArgs a) {
     yag_store_score(a, st, b, k, iy, ix, nx, ny, sum, np, xv, yv, tv, ox, oy, res, GW, map);
 }
 
+// rint(d / res) without the division wherever that is provably the same integer.  With rres = fl(1 / res): q = fl(d * rres) and the
+// quotient fl(d / res) each differ from the real d / res by at most two roundings resp. one, i.e. from each other by less than
+// 4 * 2^-53 |q|; so whenever q is farther than 2^-50 |q| + 1e-12 from a tie, both round to the integer n = rint(q).  Otherwise (and for
+// a q so large that the margin exceeds one half, or a NaN) the division decides.  An fp64 division is ~15 instructions, one of them
+// (v_rcp_f64) at a quarter of the rate; yag_fine_kernel makes ten per (point, angle) pair.
+__device__ __forceinline__ double yag_rint_div(double d, double res, double rres) {
+    const double q = d * rres, n = rint(q);
+    if (fabs(q - n) < 0.5 - (fabs(q) * 8.881784197001252e-16 + 1e-12)) return n;
+    return rint(d / res);
+}
+
 // The fine pass (pass 1: search +-2 cells at a step of one cell -- numpy.arange gives 4 or 5 positions per axis), exactly and without a
 // proof.  The cell hypothesis (ix, iy) reads for a point is (rint(((xv[ix] + r.x) - ox) / res), rint(((yv[iy] + r.y) - oy) / res)): its
 // column depends on ix alone and its row on iy alone (helpers.py:149-153), so a (point, angle) pair costs nx + ny roundings -- the same
 // operations on the same operands as yag_score_kernel's, 2 nx ny of them there -- and its nx ny reads are ny rows of nx neighbouring
 // bytes: one 8-byte read per row (two aligned dwords and a shift; a row whose columns do not fit the eight bytes -- a tie that falls
 // to the far side next to a misaligned start -- is read byte by byte).  yag_score_kernel, with a thread per hypothesis, runs this
-// pass on 25 lanes per (item, angle): 7 of the 12 ms of an enqueue of 4096 matches.  Here: grid (maxt, B), 256 threads; block (k, b)
+// pass on 25 lanes per (item, angle): 7 of the 12 ms of an enqueue of 4096 matches.  Here: 256 threads per (item, angle); the block
 // walks the points of item b at fine angle k, a thread keeps its 25 sums in registers, the block adds them up and scores them.
 // Items with a wider fine lattice (none: the search is the reference's constant) are left to yag_score_kernel.
-__global__ __launch_bounds__(256) void yag_fine_kernel(YagArgs a) {
-    constexpr int NT = 256, D = YM_YAG_FINE_DIM;
+// NT = 256: a single match (ten blocks, shortest chain); NT = 64 on batches: a block's fixed part -- item state, axes, cos and sin, the
+// final sums: dependent loads -- is paid once per 17 points of a lane instead of once per 4, no barrier, no idle last round (755 -> 681 us;
+// the rest is the vector L1's: five scattered 8-byte reads per lane and point, a line visit each).
+template <int NT>
+__global__ __launch_bounds__(NT) void yag_fine_kernel(YagArgs a) {
+    constexpr int D = YM_YAG_FINE_DIM;
     __shared__ unsigned s_part[NT / 64][D * D];
-    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    // grid (8 * maxt * ceil(B / 8)): the hardware deals consecutive blocks to the eight XCDs in turn; block id = 8 * j + x goes to XCD x
+    // and takes item 8 * (j / maxt) + x at angle j % maxt, so the angles of an item -- which read the same rows of its window --
+    // share one L2 (with a block (k, b) grid they spread over all eight and every L2 fetched the rows for itself: 816 -> 755 us per 4096 items)
+    const int xcd = blockIdx.x & 7, j_ = blockIdx.x >> 3;
+    const int b = (j_ / a.maxt) * 8 + xcd, k = j_ % a.maxt, tid = threadIdx.x;
+    if (b >= a.n_items) return;
     const YmItemState &st = a.states[b];
     const int nx = st.ydims[1][0], ny = st.ydims[1][1], nt = st.ydims[1][2];
     if (k >= nt || nx > D || ny > D || nx * ny == 0) return; // (block-uniform)
@@ -261,8 +281,10 @@ __global__ __launch_bounds__(256) void yag_fine_kernel(YagArgs a) {
     const int np = st.nq;
     __shared__ double2 s_cs;
     if (tid == 0 && !rot) { const double t = ax[2 * YM_YAG_MAX_DIM + k]; s_cs = make_double2(cos(t), sin(t)); } // (tvals[k], written by yag_setup_kernel)
-    __syncthreads();
+    __syncthreads(); // (one wave: no barrier instruction, the LDS write is waited for)
     const double rc = rot ? 0.0 : s_cs.x, rs = rot ? 0.0 : s_cs.y;
+    const double rres = 1.0 / res;
+    const unsigned gmis = (unsigned)(reinterpret_cast<uintptr_t>(grid) & 3u); // (0: an item's window starts at a multiple of 256 bytes)
     unsigned sum[D * D];
 #pragma unroll
     for (int h = 0; h < D * D; h++) sum[h] = 0u;
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(256) void yag_fine_kernel(YagArgs a) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
             const double x = xv[i] + p.x, y = yv[i] + p.y;
-            const double gx = rint((x - ox) / res), gy = rint((y - oy) / res);
+            const double gx = yag_rint_div(x - ox, res, rres), gy = yag_rint_div(y - oy, res, rres);
             const int _x = (int)gx, _y = (int)gy;
             const int cx = _x - w0, cy = _y - w0;
             wx[i] = (i < nx && _x >= 0 && _x < GW && cx >= 0 && cx < ww) ? cx : -1;
@@ -287,15 +309,19 @@ __global__ __launch_bounds__(256) void yag_fine_kernel(YagArgs a) {
 #pragma unroll
         for (int j = 0; j < D; j++) {
             if (wy[j] < 0) continue;
-            const uint8_t *row = grid + (size_t)wy[j] * pitch;
-            const uintptr_t at = reinterpret_cast<uintptr_t>(row + first);
-            const unsigned mis = (unsigned)(at & 3u);
+            // (32-bit arithmetic throughout: a window is at most 4096 x 4096 bytes; 64-bit shifts and products run at a quarter of the rate)
+            const unsigned off = (unsigned)wy[j] * (unsigned)pitch + (unsigned)first;
+            const uint8_t *row = grid + ((unsigned)wy[j] * (unsigned)pitch);
+            const unsigned mis = (gmis + off) & 3u;
             if (span + (int)mis <= 7) {
-                const uint32_t *w = reinterpret_cast<const uint32_t *>(at - mis);
-                const unsigned long long v = ((unsigned long long)w[0] | (unsigned long long)w[1] << 32) >> (8u * mis);
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(grid + (off - mis));
+                const unsigned w0_ = w[0], w1_ = w[1];
 #pragma unroll
                 for (int i = 0; i < D; i++)
-                    if (wx[i] >= 0) sum[j * D + i] += (unsigned)(v >> (8 * (wx[i] - first))) & 0xffu;
+                    if (wx[i] >= 0) {
+                        const unsigned o = mis + (unsigned)(wx[i] - first); // byte o of the eight
+                        sum[j * D + i] += __builtin_amdgcn_ubfe(o < 4u ? w0_ : w1_, 8u * (o & 3u), 8u);
+                    }
             } else {
 #pragma unroll
                 for (int i = 0; i < D; i++)
@@ -319,10 +345,12 @@ __global__ __launch_bounds__(256) void yag_fine_kernel(YagArgs a) {
     }
 }
 
-// grid (B), 1024 threads: np.argmax (first maximum in the reference's [ix][iy][k] order), mean of
+// grid (B), NT threads: np.argmax (first maximum in the reference's [ix][iy][k] order), mean of
 // all scores >= best - 1e-8, the +-5 covariance windows (helpers.py:214-295).
-__global__ __launch_bounds__(1024) void yag_reduce_kernel(YagArgs a) {
-    constexpr int NT = 1024;
+// NT = 1024: shortest latency for one item; NT = 256 on batches: four blocks per CU hide each other's dependent phases (the
+// floating-point sums are taken in an order that does not depend on NT: block_sum_vec).
+template <int NT>
+__global__ __launch_bounds__(NT) void yag_reduce_kernel(YagArgs a) {
     __shared__ double scratch[16 * 5];
     __shared__ double s_v[16];
     __shared__ int s_f[16];
@@ -361,24 +389,36 @@ __global__ __launch_bounds__(1024) void yag_reduce_kernel(YagArgs a) {
     // bits of that mean, so the additions are done in exactly that order: flags in parallel, one
     // thread walks the set bits.
     __shared__ unsigned s_bits[8192];
-    __shared__ double s_mean[4];
+    __shared__ unsigned long long s_words[8192 / 64]; // per 64 words of s_bits: which of them hold a flag (the walk below skips the rest:
+    __shared__ double s_mean[4];                      //  the set is one or two hypotheses, the words are 196 on a 25 x 25 x 10 lattice)
     double acc[4] = {0, 0, 0, 0};
     if (nh <= 8192 * 32) {
-        for (int w = tid; w < (nh + 31) / 32; w += NT) s_bits[w] = 0u;
+        const int nwords = (nh + 31) / 32;
+        for (int w = tid; w < nwords; w += NT) s_bits[w] = 0u;
         __syncthreads();
         for (int f = tid; f < nh; f += NT) {
             const int ix = f / (ny * nt), iy = (f % (ny * nt)) / nt, k = f % nt;
             if (out[((size_t)k * ny + iy) * nx + ix] >= response - 0.00000001) atomicOr(&s_bits[f >> 5], 1u << (f & 31));
         }
         __syncthreads();
+        for (int w0 = wave * 64; w0 < nwords; w0 += NT) { // (wave-uniform loop: wave w takes the chunks w, w + NT / 64, ...)
+            const unsigned long long m = __ballot(w0 + lane < nwords && s_bits[w0 + lane] != 0u);
+            if (lane == 0) s_words[w0 >> 6] = m;
+        }
+        __syncthreads();
         if (tid == 0) {
-            for (int w = 0; w < (nh + 31) / 32; w++) {
-                unsigned bits = s_bits[w];
-                while (bits) {
-                    const int f = w * 32 + __ffs((int)bits) - 1;
-                    bits &= bits - 1;
-                    const int ix = f / (ny * nt), iy = (f % (ny * nt)) / nt, k = f % nt;
-                    acc[0] += ax[ix]; acc[1] += ax[YM_YAG_MAX_DIM + iy]; acc[2] += ax[2 * YM_YAG_MAX_DIM + k]; acc[3] += 1.0;
+            for (int c = 0; c < (nwords + 63) / 64; c++) {
+                unsigned long long words = s_words[c];
+                while (words) {
+                    const int w = c * 64 + __ffsll((long long)words) - 1;
+                    words &= words - 1;
+                    unsigned bits = s_bits[w];
+                    while (bits) {
+                        const int f = w * 32 + __ffs((int)bits) - 1;
+                        bits &= bits - 1;
+                        const int ix = f / (ny * nt), iy = (f % (ny * nt)) / nt, k = f % nt;
+                        acc[0] += ax[ix]; acc[1] += ax[YM_YAG_MAX_DIM + iy]; acc[2] += ax[2 * YM_YAG_MAX_DIM + k]; acc[3] += 1.0;
+                    }
                 }
             }
             for (int j = 0; j < 4; j++) s_mean[j] = acc[j];
