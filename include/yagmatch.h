@@ -337,9 +337,11 @@ int ym_debug_cells(ym_matcher *m, int item, int32_t *out, int64_t out_count, int
  *   43      80 / 100 / 128                 region height of experimental form 5
  *   45      0                              the pair lists of a single-query batch are built at every call (default: a call whose query,
  *                                          pose, window and lattice equal those of the last list build finds them in place)
- *   46      0                              YM_SEM_YAGPY: every item's coarse pass scored pair by pair, the Python rule as written (default:
- *                                          its integer sums come from the production correlate kernels wherever the item's roundings
- *                                          provably form a lattice: ym_debug_counters)
+ *   46      0 / 2                          YM_SEM_YAGPY, 0: both passes scored pair by pair, the Python rule as written (default: the coarse
+ *                                          pass's integer sums come from the production correlate kernels wherever the item's roundings
+ *                                          provably form a lattice: ym_debug_counters; the fine pass's are taken row by row);
+ *                                          2: the default, with the fine pass reading its rows byte by byte (the path of a row whose
+ *                                          columns do not fit one 8-byte read)
  */
 int ym_debug_option(ym_matcher *m, int option, int value);
 

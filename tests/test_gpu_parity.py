@@ -315,6 +315,8 @@ def test_yagpy_coarse_sums_through_the_production_kernels(name, route):
     if route in ("pairwise", "direct"):
         if route == "pairwise":
             m.debug_option(46, 0)  # the Python rule as written: every (hypothesis, point) pair rounded on its own
+        elif name in SUM_CASES[::2]:
+            m.debug_option(46, 2)  # the fine pass's rows byte by byte (what a row takes whose columns do not fit one 8-byte read)
         r = m.match_scan(q, base, c["penalty"], c["do_fine"])
         cnt = m.debug_counters()
         assert cnt["last_correlate"] == (None if route == "pairwise" else "correlate_kernel")

@@ -112,7 +112,7 @@ int ym_debug_option(ym_matcher *m, int option, int value) {
     else if (option == 17) m->corr_region_parts = value;
     else if (option == 21) m->corr_fuse_score = value;
     else if (option == 45) { m->list_cache_on = value != 0; m->list_key_valid = false; }
-    else if (option == 46) m->yag_fast = value != 0;
+    else if (option == 46) m->yag_fast = value < 0 ? 0 : value > 2 ? 1 : value;
     else if (option == 43) m->rg2_h = value;
     else if (option == 44) {
 #ifndef YM_EXPERIMENTAL

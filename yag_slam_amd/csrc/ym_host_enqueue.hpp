@@ -174,7 +174,7 @@ int enqueue_yagpy_passes(ym_matcher *m, Slot &slot, const CallPlan &P) {
         }
         if (pass == 1 && m->yag_fast) {
             // the fine pass by rows (ym_k_yagpy.hpp, yag_fine_kernel); yag_score_kernel then only takes the items it left (a wider fine lattice: none)
-            a.fine_rows = 1;
+            a.fine_rows = m->yag_fast; // (2: tests, the rows byte by byte)
             a.n_items = P.B;
             if (P.B >= 64) hipLaunchKernelGGL(ym::yag_fine_kernel<64>, dim3(8 * P.ymaxt * ((P.B + 7) / 8)), dim3(64), 0, m->stream, a);
             else hipLaunchKernelGGL(ym::yag_fine_kernel<256>, dim3(8 * P.ymaxt * ((P.B + 7) / 8)), dim3(256), 0, m->stream, a);

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NT) void yag_fine_kernel(YagArgs a) {
             const unsigned off = (unsigned)wy[j] * (unsigned)pitch + (unsigned)first;
             const uint8_t *row = grid + ((unsigned)wy[j] * (unsigned)pitch);
             const unsigned mis = (gmis + off) & 3u;
-            if (span + (int)mis <= 7) {
+            if (span + (int)mis <= 7 && a.fine_rows != 2) { // (fine_rows = 2: tests, every row byte by byte)
                 const uint32_t *w = reinterpret_cast<const uint32_t *>(grid + (off - mis));
                 const unsigned w0_ = w[0], w1_ = w[1];
 #pragma unroll
