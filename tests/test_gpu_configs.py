@@ -478,16 +478,10 @@ def test_match_pairs_every_item_is_its_single_call(n, opts):
             assert per1[i].response == per[i].response and per1[i].covariance == per[i].covariance, i
 
 
-def test_headline_workload_at_full_size():
-    """The enqueue bench.py's metric line times, at its full size: 4096 INDEPENDENT cfg2 problems (every item its own 1081-beam query
-    with its own readings and prior, its own 10-scan chain with its own noise; bench.py generate_inputs, rank 0's seeds), one
-    ym_pairs_create batch, run twice (the second run replays the plan, as every timed step does).  EVERY item must be its single
-    call's result bit for bit, and 32 seeded items the oracle's."""
-    from oracle import oracle as orc
+def _headline_inputs(n):
+    """bench.py's metric workload (generate_inputs, rank 0's seeds): n independent cfg2 problems, resident on device 0"""
     from yag_slam_amd import synth
     from yag_slam_amd.models import native_many
-    from yag_slam_amd.scan_matching import ScanMatcher
-    n = 4096
     scene = synth.Scene()
     base_poses, q_truth, q_prior = synth.single_match_poses()
     exact = [scene.cast(*p) for p in base_poses]
@@ -501,6 +495,18 @@ def test_headline_workload_at_full_size():
     ranges = synth.scan_ranges_many([(tuple(dq_truth[c]), 200000 + c) for c in range(n)], scene)
     queries = [synth.resident_scan(r, p) for r, p in zip(ranges, dq_prior[:n])]
     native_many(queries + [s for ch in chains for s in ch], 0)
+    return queries, chains
+
+
+def test_headline_workload_at_full_size():
+    """The enqueue bench.py's metric line times, at its full size: 4096 INDEPENDENT cfg2 problems (every item its own 1081-beam query
+    with its own readings and prior, its own 10-scan chain with its own noise; bench.py generate_inputs, rank 0's seeds), one
+    ym_pairs_create batch, run twice (the second run replays the plan, as every timed step does).  EVERY item must be its single
+    call's result bit for bit, and 32 seeded items the oracle's."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n = 4096
+    queries, chains = _headline_inputs(n)
     m = ScanMatcher()
     b = m.make_pairs_batch(queries, chains)
     b.run_async(True, True, slot=0)
@@ -526,6 +532,45 @@ def test_headline_workload_at_full_size():
         np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], ro["pose"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
         assert r.meta["hypotheses"] == ro["hypotheses"] and r.meta["expansions"] == ro["expansions"]
+
+
+def test_headline_workload_in_the_reference_python_semantics():
+    """The same enqueue in the semantics the reference's own vectors pin ("yagpy": coarse 25 x 25 x 10 from the production region correlate for
+    every item yag_lattice_kernel proves regular, fine pass by rows): 4096 independent problems in one ym_pairs_create batch.  EVERY item must
+    be the pair-by-pair kernel's single call bit for bit (the Python rule as written, option 46 = 0), and 16 seeded items the oracle's --
+    results and both integer sum volumes."""
+    from oracle import oracle as orc
+    from yag_slam_amd.scan_matching import ScanMatcher
+    n = 4096
+    queries, chains = _headline_inputs(n)
+    m = ScanMatcher(None, semantics="yagpy")
+    b = m.make_pairs_batch(queries, chains)
+    b.run_async(True, True, slot=0)
+    per, _, _ = b.wait(0)
+    cnt = m.debug_counters()
+    assert cnt["last_correlate"] == "correlate_region_kernel" and (cnt["yag_fast_items"], cnt["yag_fallback_items"]) == (n, 0), cnt
+    b.run_async(True, True, slot=1)
+    again, _, _ = b.wait(1)
+    for f in ("response", "pose", "cov", "hypotheses"):
+        assert np.array_equal(per.array[f], again.array[f]), f
+    ms = ScanMatcher(None, semantics="yagpy")
+    ms.debug_option(46, 0)
+    for i in range(n):
+        s = ms.match_scan(queries[i], chains[i], True, True)
+        r = per.array[i]
+        assert s.response == r["response"] and np.array_equal(np.array(s.covariance).ravel(), r["cov"]), i
+        assert (s.best_pose.x, s.best_pose.y, s.best_pose.euler[-1]) == tuple(r["pose"].tolist()), i
+        assert s.meta["hypotheses"] == r["hypotheses"], i
+    o = orc.Oracle(None, "yagpy")
+    for i in sorted(np.random.default_rng(2048).choice(n, size=16, replace=False).tolist()):
+        ro = o.match_scan(_plain(queries[i]), [_plain(s) for s in chains[i]], True, True)
+        r = per[i]
+        assert abs(r.response - ro["response"]) <= 1e-12, (i, r.response, ro["response"])
+        bp = r.best_pose
+        np.testing.assert_allclose([bp.x, bp.y, bp.euler[-1]], ro["pose"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.array(r.covariance), ro["cov"], rtol=1e-9, atol=1e-15)
+        assert np.array_equal(m.debug_sums(0, item=i, dims=r.meta["coarse_dims"]), o.sums(0)), i
+        assert np.array_equal(m.debug_sums(1, item=i, dims=r.meta["fine_dims"]), o.sums(1)), i
 
 
 def test_match_pairs_argument_errors():
